@@ -1,0 +1,27 @@
+"""CPU oracle of the RSPrompter inference hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
+import this package.  Nothing under `rsprompter_amd/` imports it; the product
+path fails loudly if librsp_hip.so is missing instead of falling back here.
+
+What it is: a plain PyTorch (CPU, fp32 or fp64) restatement of the reference's
+predict path.  SAM arithmetic comes straight from the reference's own pinned
+third-party dependency, HuggingFace `transformers.models.sam` (reference pins
+4.38.1, README.md:137; 5.15.0 is what is installed -- arithmetic of HF:803-831
+and HF:461-543 is unchanged), forced to eager attention.
+The mmdet / mmcv glue (RPN, anchors, box coder, RoIAlign, NMS, RoI heads,
+post-processing) is restated from the cited reference lines because mmcv /
+mmengine are not installable here.
+
+Pinning status:
+  * delta2bbox, AnchorGenerator, SinePositionalEncoding, window partition /
+    rel-pos helpers of vit_sam.py, LN2d, RSFeatureAggregator, the mask
+    post-process and the SAM positional embedding are checked against outputs
+    of the REAL reference source files executed in the build container
+    (tests/golden/make_golden.py -> tests/golden/*.pt) and against the two
+    known-answer tests the reference inherits
+    (test_delta_xywh_bbox_coder.py:9-24, test_anchor_generator.py:290-309).
+  * SAM encoder / mask decoder: HF modules themselves (the reference's dependency).
+  * mmcv RoIAlign / nms / batched_nms: source not in /root/reference ->
+    restated from documented semantics: PARITY UNPINNED at that boundary.
+"""

@@ -1,0 +1,386 @@
+// SAM ViT attention for gfx950: flash-style (never materialises the TxT score
+// or bias matrices), fp32 online softmax, fp16x3 split-precision MFMA for both
+// QK^T and PV (see gemm.hip for the numerics), decomposed rel-pos bias added
+// in registers.
+//
+// Reference semantics (HF:803-831, HF:761-801; vit_sam.py:117-157,202-221):
+//   attn = softmax_fp32((q*scale) k^T + rel_h[q,kh] + rel_w[q,kw]) ; out = attn v
+//   rel_h[q,kh] = q . Rh[qh-kh+S-1], rel_w[q,kw] = q . Rw[qw-kw+S-1]   (UNSCALED q)
+//
+// Layout trick: we compute the TRANSPOSED score tile S^T = K Q^T with
+// v_mfma_f32_32x32x16_f16, so every lane owns ONE query column (q = lane&31)
+// and 16 keys per 32-key block.  Row max / row sum are then per-lane scalars
+// (one cross-half shuffle per tile), and the 8 consecutive accumulator
+// registers [8*(s&1), 8*(s&1)+8) of block (s>>1) are exactly the B operand
+// (P^T) of the PV MFMA for k-step s, provided the A operand (V^T) is read with
+// the same key permutation  slot t<4 -> key 16s+4hh+t, t>=4 -> key 16s+8+4hh+t-4.
+// No LDS round trip and no cross-lane traffic for P.
+#include "rsp_common.h"
+
+namespace {
+
+constexpr int KT = 64;        // keys per tile
+constexpr int QB = 128;       // queries per block (4 waves x 32)
+constexpr int VT_LD = 68;     // halves per V^T row (34 dwords: conflict-free b64 reads)
+constexpr int EQ = 6, EK = 6, EV = 6;  // power-of-two operand scales (fp16 range)
+constexpr float P_SCALE = 16384.0f;    // probabilities are scaled by 2^14 before the fp16 split
+
+__device__ __forceinline__ void split8(const float* x, half8_t& hi, half8_t& lo) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    half_t h, l;
+    rsp_split1(x[i], h, l);
+    hi[i] = h; lo[i] = l;
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(256) void vit_attn_kernel(const float* __restrict__ qkv,
+                                                       const float* __restrict__ rel,
+                                                       float* __restrict__ out, int T, int S,
+                                                       int nh, float scale) {
+  constexpr int DSTEPS = DH / 16;
+  constexpr int DBLK = (DH + 31) / 32;
+  constexpr int K_LD = DH + 8;
+  constexpr int DCH = DH / 4;                          // float4 chunks per key row
+  constexpr int MT_TOTAL = 16 * DCH;                   // 4key x 4d micro tiles per K/V tile
+  constexpr int MT_PER_THREAD = (MT_TOTAL + 255) / 256;
+  constexpr int REL_MAX_S = 32;                        // LDS rel table only for S < 64
+
+  __shared__ __attribute__((aligned(16))) half_t sK[2][KT * K_LD];
+  __shared__ __attribute__((aligned(16))) half_t sVt[2][DBLK * 32 * VT_LD];
+  __shared__ float sRel[QB * (2 * REL_MAX_S + 1)];
+  __shared__ int sKmap[REL_MAX_S * REL_MAX_S];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int bp = blockIdx.z, h = blockIdx.y;
+  const int q0 = blockIdx.x * QB;
+  const int ql = wave * 32 + l31;
+  const int q = q0 + ql;
+  const bool aligned = (S == 64);
+  const int64_t tok_stride = (int64_t)3 * nh * DH;
+  const float* qkv_b = qkv + (int64_t)bp * T * tok_stride + (int64_t)h * DH;
+  const float* rel_b = rel + ((int64_t)bp * nh + h) * T * (2 * S);
+
+  // ---- Q fragments (B operand of S^T = K Q^T), scaled and split once ----
+  half8_t qh[DSTEPS], qlo[DSTEPS];
+  {
+    const float qs = scale * ldexpf(1.0f, EQ);
+#pragma unroll
+    for (int st = 0; st < DSTEPS; ++st) {
+      float x[8];
+      if (q < T) {
+        const float* src = qkv_b + (int64_t)q * tok_stride + st * 16 + hh * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = a[i] * qs; x[4 + i] = b[i] * qs; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = 0.f;
+      }
+      split8(x, qh[st], qlo[st]);
+    }
+  }
+
+  // ---- rel-pos bias sources ----
+  float bw[2][16];  // aligned path: rel_w for this lane's 32 key columns (tile invariant)
+  if (aligned) {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kw = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        bw[blk][r] = (q < T) ? rel_b[(int64_t)q * (2 * S) + S + kw] : 0.f;
+      }
+  } else {
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bw[blk][r] = 0.f;
+    const int W2 = 2 * S;
+    for (int idx = tid; idx < QB * W2; idx += 256) {
+      const int r = idx / W2, j = idx - r * W2;
+      const int qq = q0 + r;
+      sRel[r * (W2 + 1) + j] = (qq < T) ? rel_b[(int64_t)qq * W2 + j] : 0.f;
+    }
+    for (int k = tid; k < T; k += 256) {
+      const int kh = k / S;
+      sKmap[k] = kh | ((k - kh * S) << 16);
+    }
+  }
+
+  // ---- K/V staging registers (issue-early / write-late) ----
+  f32x4 kreg[MT_PER_THREAD][4], vreg[MT_PER_THREAD][4];
+  auto load_kv = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < MT_PER_THREAD; ++i) {
+      const int mt = tid + 256 * i;
+      if (mt < MT_TOTAL) {
+        const int kg = mt / DCH, dc = mt - kg * DCH;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int key = kt * KT + kg * 4 + j;
+          if (key < T) {
+            const float* src = qkv_b + (int64_t)key * tok_stride + (int64_t)nh * DH + dc * 4;
+            kreg[i][j] = *reinterpret_cast<const f32x4*>(src);
+            vreg[i][j] = *reinterpret_cast<const f32x4*>(src + (int64_t)nh * DH);
+          } else {
+            kreg[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vreg[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          }
+        }
+      }
+    }
+  };
+  auto store_kv = [&]() {
+    const float ks = ldexpf(1.0f, EK), vs = ldexpf(1.0f, EV);
+#pragma unroll
+    for (int i = 0; i < MT_PER_THREAD; ++i) {
+      const int mt = tid + 256 * i;
+      if (mt < MT_TOTAL) {
+        const int kg = mt / DCH, dc = mt - kg * DCH;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {  // K: row = key, 4 consecutive d
+          half4_t hi, lo;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            half_t a, b;
+            rsp_split1(kreg[i][j][c] * ks, a, b);
+            hi[c] = a; lo[c] = b;
+          }
+          const int off = (kg * 4 + j) * K_LD + dc * 4;
+          *reinterpret_cast<half4_t*>(&sK[0][off]) = hi;
+          *reinterpret_cast<half4_t*>(&sK[1][off]) = lo;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {  // V^T: row = d, 4 consecutive keys
+          half4_t hi, lo;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            half_t a, b;
+            rsp_split1(vreg[i][j][c] * vs, a, b);
+            hi[j] = a; lo[j] = b;
+          }
+          const int off = (dc * 4 + c) * VT_LD + kg * 4;
+          *reinterpret_cast<half4_t*>(&sVt[0][off]) = hi;
+          *reinterpret_cast<half4_t*>(&sVt[1][off]) = lo;
+        }
+      }
+    }
+  };
+
+  // zero the padded V^T rows (d >= DH) once
+  if (DBLK * 32 > DH) {
+    for (int idx = tid; idx < (DBLK * 32 - DH) * VT_LD; idx += 256) {
+      sVt[0][DH * VT_LD + idx] = (half_t)0.f;
+      sVt[1][DH * VT_LD + idx] = (half_t)0.f;
+    }
+  }
+
+  f32x16 acc_o[DBLK];
+#pragma unroll
+  for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float s_unscale = ldexpf(1.0f, -(EQ + EK));
+  const float LOG2E = 1.4426950408889634f;
+
+  const int nt = (T + KT - 1) / KT;
+  load_kv(0);
+  for (int kt = 0; kt < nt; ++kt) {
+    store_kv();
+    __syncthreads();
+    if (kt + 1 < nt) load_kv(kt + 1);
+
+    // ---- S^T = K Q^T ----
+    f32x16 sc[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[blk][r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < DSTEPS; ++st) {
+        const int off = (blk * 32 + l31) * K_LD + st * 16 + hh * 8;
+        const half8_t kh8 = *reinterpret_cast<const half8_t*>(&sK[0][off]);
+        const half8_t kl8 = *reinterpret_cast<const half8_t*>(&sK[1][off]);
+        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[st], sc[blk], 0, 0, 0);
+        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qlo[st], sc[blk], 0, 0, 0);
+        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh[st], sc[blk], 0, 0, 0);
+      }
+    }
+
+    // ---- bias, mask, online softmax (per-lane query column) ----
+    float bh_t = 0.f;
+    if (aligned) bh_t = (q < T) ? rel_b[(int64_t)q * (2 * S) + kt] : 0.f;
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * KT + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        float v = sc[blk][r] * s_unscale;
+        if (aligned) {
+          v += bh_t + bw[blk][r];
+        } else if (key < T) {
+          const int km = sKmap[key];
+          v += sRel[ql * (2 * S + 1) + (km & 0xffff)] + sRel[ql * (2 * S + 1) + S + (km >> 16)];
+        }
+        if (key >= T) v = -INFINITY;
+        sc[blk][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);
+    const float alpha = exp2f((m_run - m_new) * LOG2E);  // m_run=-inf -> 0
+    float psum = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = exp2f((sc[blk][r] - m_new) * LOG2E) * P_SCALE;
+        sc[blk][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float pf[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) pf[t] = sc[s >> 1][8 * (s & 1) + t];
+      half8_t ph, pl;
+      split8(pf, ph, pl);
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db) {
+        const int off = (db * 32 + l31) * VT_LD + 16 * s + 4 * hh;
+        half8_t vh8, vl8;
+        const half4_t a0 = *reinterpret_cast<const half4_t*>(&sVt[0][off]);
+        const half4_t a1 = *reinterpret_cast<const half4_t*>(&sVt[0][off + 8]);
+        const half4_t b0 = *reinterpret_cast<const half4_t*>(&sVt[1][off]);
+        const half4_t b1 = *reinterpret_cast<const half4_t*>(&sVt[1][off + 8]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { vh8[t] = a0[t]; vh8[4 + t] = a1[t]; vl8[t] = b0[t]; vl8[4 + t] = b1[t]; }
+        acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph, acc_o[db], 0, 0, 0);
+        acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl, acc_o[db], 0, 0, 0);
+        acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph, acc_o[db], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- normalise and store: lane holds O[q][d], d = db*32 + (r&3) + 8*(r>>2) + 4*hh ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (q < T) {
+    const float inv = ldexpf(1.0f, -EV) / l_tot;
+    float* dst = out + ((int64_t)bp * T + q) * ((int64_t)nh * DH) + (int64_t)h * DH;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * hh;
+        if (d0 < DH) {
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = acc_o[db][4 * g + c] * inv;
+          *reinterpret_cast<f32x4*>(dst + d0) = o;
+        }
+      }
+  }
+}
+
+// rel[bh, t, 0:S] = q . Rh[qh - kh + S-1], rel[bh, t, S:2S] = q . Rw[qw - kw + S-1]
+// plain fp32 FMA dot products (same arithmetic class as the reference einsum).
+template <int DH>
+__global__ __launch_bounds__(256) void vit_relpos_kernel(const float* __restrict__ qkv,
+                                                         const float* __restrict__ rph,
+                                                         const float* __restrict__ rpw,
+                                                         float* __restrict__ rel, int T, int S,
+                                                         int nh) {
+  extern __shared__ float smem[];
+  constexpr int LD = DH + 1;
+  const int nrow = 2 * S - 1;
+  float* sH = smem;                 // [nrow][LD]
+  float* sW = sH + nrow * LD;       // [nrow][LD]
+  float* sQ = sW + nrow * LD;       // [64][LD]
+  const int tid = threadIdx.x;
+  const int bp = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  for (int idx = tid; idx < nrow * DH; idx += 256) {
+    const int r = idx / DH, d = idx - r * DH;
+    sH[r * LD + d] = rph[idx];
+    sW[r * LD + d] = rpw[idx];
+  }
+  const int64_t tok_stride = (int64_t)3 * nh * DH;
+  for (int idx = tid; idx < 64 * DH; idx += 256) {
+    const int r = idx / DH, d = idx - r * DH;
+    const int q = q0 + r;
+    sQ[r * LD + d] = (q < T) ? qkv[((int64_t)bp * T + q) * tok_stride + (int64_t)h * DH + d] : 0.f;
+  }
+  __syncthreads();
+  const int W2 = 2 * S;
+  for (int o = tid; o < 64 * W2; o += 256) {
+    const int r = o / W2, j = o - r * W2;
+    const int q = q0 + r;
+    if (q >= T) continue;
+    const int qy = q / S, qx = q - qy * S;
+    const float* tab = (j < S) ? (sH + (qy - j + S - 1) * LD) : (sW + (qx - (j - S) + S - 1) * LD);
+    const float* qv = sQ + r * LD;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < DH; ++d) acc = fmaf(qv[d], tab[d], acc);
+    rel[(((int64_t)bp * nh + h) * T + q) * W2 + j] = acc;
+  }
+}
+
+}  // namespace
+
+extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const float* rel_pos_w,
+                              float* rel, int32_t Bp, int32_t S, int32_t nh, int32_t dh,
+                              rsp_stream_t stream) {
+  if (!qkv || !rel_pos_h || !rel_pos_w || !rel || Bp <= 0 || S <= 0 || S > 64 || nh <= 0)
+    return RSP_EINVAL;
+  const int T = S * S;
+  dim3 grid((T + 63) / 64, nh, Bp);
+  const size_t smem = (size_t)(2 * (2 * S - 1) + 64) * (dh + 1) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (dh == 64) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_relpos_kernel<64>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((vit_relpos_kernel<64>), grid, dim3(256), smem, s, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh);
+  } else if (dh == 80) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_relpos_kernel<80>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL((vit_relpos_kernel<80>), grid, dim3(256), smem, s, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh);
+  } else {
+    return RSP_EINVAL;
+  }
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+extern "C" int rsp_vit_attention(const float* qkv, const float* rel, float* out, int32_t Bp,
+                                 int32_t S, int32_t nh, int32_t dh, float scale,
+                                 rsp_stream_t stream) {
+  if (!qkv || !rel || !out || Bp <= 0 || S <= 0 || nh <= 0) return RSP_EINVAL;
+  if (!(S == 64 || S <= 32)) return RSP_EINVAL;
+  const int T = S * S;
+  dim3 grid((T + QB - 1) / QB, nh, Bp);
+  hipStream_t s = (hipStream_t)stream;
+  if (dh == 64) {
+    hipLaunchKernelGGL((vit_attn_kernel<64>), grid, dim3(256), 0, s, qkv, rel, out, T, S, nh, scale);
+  } else if (dh == 80) {
+    hipLaunchKernelGGL((vit_attn_kernel<80>), grid, dim3(256), 0, s, qkv, rel, out, T, S, nh, scale);
+  } else {
+    return RSP_EINVAL;
+  }
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}

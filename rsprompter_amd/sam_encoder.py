@@ -1,0 +1,244 @@
+"""SAM ViT image encoder on hand-written gfx950 kernels.
+
+Drop-in for the reference's `RSSamVisionEncoder` (mmdet/rsprompter/models.py:762-809),
+which wraps HuggingFace `SamVisionEncoder` (HF:1013-1072; layer HF:885-972,
+attention HF:700-831, neck HF:975-992).  Same registry name, same ctor kwargs,
+same `state_dict` keys (`vision_encoder.patch_embed.projection.weight`, ...),
+same output object (`[0]` = image embeddings [B,256,64,64], `[1]` = L+1 hidden
+states [B,64,64,D]).
+
+Data layout: the residual stream is one fp32 [B*4096, D] matrix
+(NHWC); every Linear is `rsp_gemm`; window partition / unpartition are row maps
+folded into the qkv GEMM's A-loader and the proj GEMM's epilogue, so no padded
+[B*25,14,14,D] tensor is ever copied.
+"""
+import math
+
+import torch
+
+from . import ops
+from .nnutil import (HIPModule, SAM_ARCH, add_param, infer_sam_arch, load_checkpoint_into,
+                     nchw_view)
+from .registry import MODELS
+
+
+class SamVisionEncoderOutput(tuple):
+    """Tuple-like stand-in of transformers' SamVisionEncoderOutput (models.py:99-101)."""
+
+    def __new__(cls, last_hidden_state, hidden_states=None):
+        items = (last_hidden_state,) if hidden_states is None else (last_hidden_state, hidden_states)
+        self = super().__new__(cls, items)
+        self.last_hidden_state = last_hidden_state
+        self.hidden_states = hidden_states
+        return self
+
+
+def resize_rel_pos(rel_pos, size):
+    """HF get_rel_pos (HF:729-759): linear interpolation of the table to 2*size-1 rows.
+    Load-time constant preparation (identity when the table already has that length)."""
+    n = 2 * size - 1
+    if rel_pos.shape[0] == n:
+        return rel_pos
+    r = torch.nn.functional.interpolate(
+        rel_pos.reshape(1, rel_pos.shape[0], -1).transpose(1, 2).float(), size=n, mode='linear')
+    return r.reshape(-1, n).permute(1, 0).contiguous()
+
+
+class SamVisionEncoderHIP(HIPModule):
+    def __init__(self, arch='base', image_size=1024, patch_size=16, window_size=14,
+                 out_channels=256, output_hidden_states=False, layer_norm_eps=1e-6):
+        super().__init__()
+        a = SAM_ARCH[arch]
+        self.arch = arch
+        self.D, self.depth, self.heads = a['hidden'], a['depth'], a['heads']
+        self.global_idx, self.mlp_dim = tuple(a['global_idx']), a['mlp']
+        self.dh = self.D // self.heads
+        self.image_size, self.patch_size, self.window_size = image_size, patch_size, window_size
+        self.grid = image_size // patch_size
+        self.out_channels = out_channels
+        self.output_hidden_states = output_hidden_states
+        self.eps = layer_norm_eps
+        D, g = self.D, self.grid
+        add_param(self, 'patch_embed.projection.weight', (D, 3, patch_size, patch_size))
+        add_param(self, 'patch_embed.projection.bias', (D,))
+        add_param(self, 'pos_embed', (1, g, g, D))
+        for i in range(self.depth):
+            s = g if i in self.global_idx else window_size
+            p = f'layers.{i}.'
+            add_param(self, p + 'layer_norm1.weight', (D,), 1.0)
+            add_param(self, p + 'layer_norm1.bias', (D,))
+            add_param(self, p + 'attn.qkv.weight', (3 * D, D))
+            add_param(self, p + 'attn.qkv.bias', (3 * D,))
+            add_param(self, p + 'attn.proj.weight', (D, D))
+            add_param(self, p + 'attn.proj.bias', (D,))
+            add_param(self, p + 'attn.rel_pos_h', (2 * s - 1, self.dh))
+            add_param(self, p + 'attn.rel_pos_w', (2 * s - 1, self.dh))
+            add_param(self, p + 'layer_norm2.weight', (D,), 1.0)
+            add_param(self, p + 'layer_norm2.bias', (D,))
+            add_param(self, p + 'mlp.lin1.weight', (self.mlp_dim, D))
+            add_param(self, p + 'mlp.lin1.bias', (self.mlp_dim,))
+            add_param(self, p + 'mlp.lin2.weight', (D, self.mlp_dim))
+            add_param(self, p + 'mlp.lin2.bias', (D,))
+        add_param(self, 'neck.conv1.weight', (out_channels, D, 1, 1))
+        add_param(self, 'neck.layer_norm1.weight', (out_channels,), 1.0)
+        add_param(self, 'neck.layer_norm1.bias', (out_channels,))
+        add_param(self, 'neck.conv2.weight', (out_channels, out_channels, 3, 3))
+        add_param(self, 'neck.layer_norm2.weight', (out_channels,), 1.0)
+        add_param(self, 'neck.layer_norm2.bias', (out_channels,))
+        self.lora = None  # optional dict name -> (A [r,D], B [3D,r], scale), merged at pack time
+        self._maps = {}
+
+    # ------------------------------------------------------------------ packing
+    def _pack(self):
+        dev = self.pos_embed.device
+        if dev.type != 'cuda':
+            raise RuntimeError('SamVisionEncoderHIP runs on the HIP device only (no CPU fallback); '
+                               'move the model with .to("cuda")')
+        P = {}
+        w = self.patch_embed.projection.weight
+        P['patch'] = ops.PackedWeight(w.reshape(w.shape[0], -1), self.patch_embed.projection.bias)
+        P['pos'] = self.pos_embed.detach().reshape(-1, self.D).contiguous()
+        P['layers'] = []
+        for i in range(self.depth):
+            L = getattr(self.layers, str(i))
+            s = self.grid if i in self.global_idx else self.window_size
+            wq = L.attn.qkv.weight.detach()
+            if self.lora is not None and i in self.lora:
+                A, Bm, sc = self.lora[i]
+                wq = wq + sc * (Bm.to(wq) @ A.to(wq))   # load-time merge W += (alpha/r) B A (models.py:785-797)
+            P['layers'].append(dict(
+                S=s,
+                ln1=(L.layer_norm1.weight.detach(), L.layer_norm1.bias.detach()),
+                ln2=(L.layer_norm2.weight.detach(), L.layer_norm2.bias.detach()),
+                qkv=ops.PackedWeight(wq, L.attn.qkv.bias),
+                proj=ops.PackedWeight(L.attn.proj.weight, L.attn.proj.bias),
+                lin1=ops.PackedWeight(L.mlp.lin1.weight, L.mlp.lin1.bias),
+                lin2=ops.PackedWeight(L.mlp.lin2.weight, L.mlp.lin2.bias),
+                rph=resize_rel_pos(L.attn.rel_pos_h.detach(), s).contiguous(),
+                rpw=resize_rel_pos(L.attn.rel_pos_w.detach(), s).contiguous(),
+            ))
+        P['neck1'] = ops.PackedWeight(self.neck.conv1.weight.reshape(self.out_channels, self.D))
+        # 3x3 conv weight [O, I, ky, kx] -> [O, (ky, kx, I)] to match the NHWC implicit-GEMM K order
+        P['neck2'] = ops.PackedWeight(self.neck.conv2.weight.permute(0, 2, 3, 1).reshape(self.out_channels, -1))
+        P['nln1'] = (self.neck.layer_norm1.weight.detach(), self.neck.layer_norm1.bias.detach())
+        P['nln2'] = (self.neck.layer_norm2.weight.detach(), self.neck.layer_norm2.bias.detach())
+        self._packed = P
+        self._maps = {}
+
+    def _window_map(self, B, device):
+        """row map of window_partition (HF:900-922): GEMM row (b, wy, wx, iy, ix) -> token row or -1 (pad)."""
+        key = (B, str(device))
+        if key in self._maps:
+            return self._maps[key]
+        g, w = self.grid, self.window_size
+        nw = (g + w - 1) // w
+        idx = torch.arange(B * nw * nw * w * w, dtype=torch.int64)
+        ix = idx % w
+        iy = (idx // w) % w
+        wx = (idx // (w * w)) % nw
+        wy = (idx // (w * w * nw)) % nw
+        b = idx // (w * w * nw * nw)
+        y, x = wy * w + iy, wx * w + ix
+        src = torch.where((y < g) & (x < g), b * g * g + y * g + x, torch.full_like(idx, -1))
+        m = src.to(torch.int32).to(device)
+        self._maps[key] = (m, nw)
+        return self._maps[key]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, pixel_values, output_hidden_states=None):
+        if pixel_values.dim() != 4 or pixel_values.shape[1] != 3:
+            raise ValueError('Make sure that the channel dimension of the pixel values match with the one set '
+                             'in the configuration.')
+        B, _, H, W = pixel_values.shape
+        if H != self.image_size or W != self.image_size:
+            raise ValueError(f"Input image size ({H}*{W}) doesn't match model ({self.image_size}*{self.image_size}).")
+        if self._packed is None:
+            self._pack()
+        P = self._packed
+        want_hidden = self.output_hidden_states if output_hidden_states is None else output_hidden_states
+        g, D, nh, dh = self.grid, self.D, self.heads, self.dh
+        T = g * g
+        x_in = pixel_values.to(torch.float32).contiguous()
+        patches = ops.patchify(x_in, self.patch_size)
+        # conv16x16 + bias + pos_embed (HF:118-129, 1064-1066): pos_embed is a residual broadcast over the batch
+        x = ops.gemm(patches, P['patch'], res=P['pos'], res_mod=T)
+        del patches
+        hidden = [x] if want_hidden else None
+        scale = dh ** -0.5
+        for i in range(self.depth):
+            L = P['layers'][i]
+            S = L['S']
+            xn = ops.layernorm(x, L['ln1'][0], L['ln1'][1], self.eps)
+            if S == g:  # global attention layer
+                qkv = ops.gemm(xn, L['qkv'])
+                Bp, rowmap = B, None
+            else:       # windowed: partition is a row gather in the qkv GEMM (pad rows -> bias only, HF:913-915)
+                rowmap, nw = self._window_map(B, x.device)
+                Bp = B * nw * nw
+                qkv = ops.gemm(xn, L['qkv'], a_rowmap=rowmap, M=Bp * S * S)
+            rel = ops.vit_relpos(qkv, L['rph'], L['rpw'], Bp, S, nh, dh)
+            att = ops.vit_attention(qkv, rel, Bp, S, nh, dh, scale)
+            # proj + window_unpartition + crop + residual (HF:830, 924-952, 969)
+            x1 = ops.gemm(att, L['proj'], res=x, c_rowmap=rowmap, out_rows=B * T)
+            del qkv, rel, att, xn
+            xn2 = ops.layernorm(x1, L['ln2'][0], L['ln2'][1], self.eps)
+            hmid = ops.gemm(xn2, L['lin1'], act=ops.ACT_GELU)
+            x = ops.gemm(hmid, L['lin2'], res=x1)
+            del hmid, xn2, x1
+            if want_hidden:
+                hidden.append(x)
+        # neck (HF:985-992): 1x1 conv -> LN over C -> 3x3 conv -> LN over C, all NHWC
+        y = ops.gemm(x, P['neck1'], bias=None)
+        y = ops.layernorm(y, P['nln1'][0], P['nln1'][1], 1e-6)
+        y = ops.gemm(y.view(B, g, g, self.out_channels), P['neck2'], bias=None, conv=(3, 1, 1))
+        y = ops.layernorm(y, P['nln2'][0], P['nln2'][1], 1e-6)
+        emb = nchw_view(y.view(B, g, g, self.out_channels))
+        hs = tuple(h.view(B, g, g, D) for h in hidden) if want_hidden else None
+        return SamVisionEncoderOutput(emb, hs)
+
+
+@MODELS.register_module()
+class RSSamVisionEncoder(HIPModule):
+    """Registry-compatible wrapper (reference models.py:762-809)."""
+
+    def __init__(self, hf_pretrain_name, extra_config=None, peft_config=None, init_cfg=None):
+        super().__init__()
+        extra_config = dict(extra_config or {})
+        arch = infer_sam_arch(hf_pretrain_name)
+        self.vision_encoder = SamVisionEncoderHIP(
+            arch=arch, output_hidden_states=bool(extra_config.get('output_hidden_states', False)))
+        if init_cfg is not None:
+            load_checkpoint_into(self.vision_encoder, init_cfg.get('checkpoint'),
+                                 revise_keys=[(r'^module\.', ''), (r'^vision_encoder\.', '')])
+        self.peft_config = peft_config
+        if peft_config is not None and isinstance(peft_config, dict):
+            self._add_lora(peft_config)
+        self.vision_encoder.is_init = True
+
+    def _add_lora(self, peft_config):
+        cfg = dict(r=16, lora_alpha=32)
+        cfg.update(peft_config)
+        r = cfg['r']
+        enc = self.vision_encoder
+        enc.lora_scale = cfg['lora_alpha'] / r
+        for i in range(enc.depth):
+            add_param(enc, f'layers.{i}.attn.qkv.lora_A.default.weight', (r, enc.D))
+            add_param(enc, f'layers.{i}.attn.qkv.lora_B.default.weight', (3 * enc.D, r))
+        enc.lora = _LoraView(enc)
+
+    def forward(self, *args, **kwargs):
+        return self.vision_encoder(*args, **kwargs)
+
+
+class _LoraView:
+    """index -> (A, B, scale) view over the LoRA parameters registered on the encoder."""
+
+    def __init__(self, enc):
+        self.enc = enc
+
+    def __contains__(self, i):
+        return True
+
+    def __getitem__(self, i):
+        q = getattr(self.enc.layers, str(i)).attn.qkv
+        return q.lora_A.default.weight.detach(), q.lora_B.default.weight.detach(), self.enc.lora_scale
