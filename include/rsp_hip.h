@@ -75,6 +75,14 @@ typedef struct RspGemmDesc {
   int32_t conv_stride, conv_pad;
   int32_t conv_H, conv_W, conv_C; /* input  spatial size / channels           */
   int32_t conv_Ho, conv_Wo;       /* output spatial size; M = B*Ho*Wo         */
+  /* ConvTranspose2d(k=2,s=2) as two GEMMs (one per output row parity dy) with  */
+  /* N = 2*Cout (dx, co): GEMM row (y*W + x) -> C row ((y*2 + dy)*W + x) of an   */
+  /* output viewed as [B*2H*W, 2*Cout].  ct_W == 0 disables.                     */
+  int32_t ct_W, ct_dy;
+  /* residual batch gather: residual row = res_bmap[crow / res_brows] * res_brows */
+  /* + crow % res_brows  (per-RoI rows adding their image's rows). NULL disables. */
+  const int32_t* res_bmap;
+  int32_t res_brows;
 } RspGemmDesc;
 
 int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream);
@@ -106,6 +114,88 @@ int rsp_vit_attention(const float* qkv, const float* rel, float* out,
                       int32_t Bp, int32_t S, int32_t nh, int32_t dh, float scale,
                       rsp_stream_t stream);
 
+/* Generic multi-head attention out = softmax((q*scale) k^T) v with strided    */
+/* operands (element strides; all multiples of 4), used by the SAM mask        */
+/* decoder: SamAttention.forward HF:231-270 (self-attn dh=32, token<->image    */
+/* cross-attn dh=16 with 4096 image keys).  kv_batch_map lets several query    */
+/* batches (RoIs) share one K/V batch (their image).  dh in {16, 32, 64}.      */
+typedef struct RspAttnDesc {
+  const float* q; const float* k; const float* v; float* out;
+  const int32_t* kv_batch_map;   /* [B] or NULL */
+  const int32_t* q_batch_map;    /* [B] or NULL: batch b reads Q of batch q_batch_map[b] */
+  int64_t q_bs, q_ts, q_hs;      /* batch / token / head strides (elements)   */
+  int64_t k_bs, k_ts, k_hs;
+  int64_t v_bs, v_ts, v_hs;
+  int64_t o_bs, o_ts, o_hs;
+  int32_t B, nh, dh, Tq, Tk;
+  float scale;
+} RspAttnDesc;
+int rsp_attention(const RspAttnDesc* desc, rsp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* RoI feature extraction (single_level_roi_extractor.py:44-119 + mmcv RoIAlign, */
+/* sampling_ratio=0, aligned=True) over <=4 NHWC levels; `pe` adds an          */
+/* input-independent positional map per level (models.py:1566-1574) on the fly. */
+/* out: [K, P, P, C].                                                          */
+/* ------------------------------------------------------------------------ */
+typedef struct RspRoiAlignDesc {
+  const float* feat[4];      /* [B, H, W, C] per level                         */
+  const float* pe[4];        /* [H, W, C] per level or NULL                    */
+  int32_t H[4], W[4];
+  float spatial_scale[4];    /* 1/stride                                       */
+  const float* rois;         /* [K, 5] (batch index, x1, y1, x2, y2)           */
+  float* out;
+  int32_t K, P, C, num_levels, finest_scale;
+} RspRoiAlignDesc;
+int rsp_roi_align(const RspRoiAlignDesc* desc, rsp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* Proposal / detection selection (rpn_head.py:134-304, bbox_head.py:476-571, */
+/* bbox_nms.py:12-105, delta_xywh_bbox_coder.py:264-361, mmcv batched_nms).    */
+/* Deterministic: ties are (score desc, position asc).                         */
+/* ------------------------------------------------------------------------ */
+typedef struct RspRpnDesc {
+  const float* head[5];      /* per level [B*H*W, ld]: cols [0,A) objectness,  */
+                             /* cols [A, 5A) deltas (anchor-major)             */
+  int32_t H[5], W[5];
+  float stride[5];
+  int32_t ld, A, nms_pre, num_levels;
+  const float* base_anchors; /* device [L, A, 4] (anchor_generator.py:161-205) */
+  float max_ratio;           /* |log(wh_ratio_clip)|                           */
+  float min_bbox_size;       /* <0 disables the w/h filter                     */
+} RspRpnDesc;
+/* sel_idx/sel_score [B, L, nms_pre], sel_cnt [B, L] */
+int rsp_rpn_topk(const RspRpnDesc* d, int32_t B, int32_t* sel_idx, float* sel_score,
+                 int32_t* sel_cnt, rsp_stream_t stream);
+/* decode + min-size filter -> per-image compacted candidates (level-major)    */
+int rsp_rpn_decode(const RspRpnDesc* d, int32_t B, const int32_t* sel_idx, const float* sel_score,
+                   const int32_t* sel_cnt, const float* img_hw, int32_t cap, float* cand_boxes,
+                   float* cand_scores, int32_t* cand_ids, int32_t* cand_src, int32_t* cand_cnt,
+                   rsp_stream_t stream);
+/* softmax + per-class decode + score threshold -> candidates ((roi, class) order) */
+int rsp_bbox_post(const float* head, int32_t ld, const float* rois, const int32_t* roi_start,
+                  const float* img_hw, int32_t B, int32_t num_classes, float score_thr,
+                  const float* std4 /*host*/, float max_ratio, int32_t cap, float* cand_boxes,
+                  float* cand_scores, int32_t* cand_ids, int32_t* cand_src, int32_t* cand_cnt,
+                  rsp_stream_t stream);
+int64_t rsp_nms_workspace_bytes(int32_t B, int32_t cap);
+/* greedy NMS per image with per-id coordinate offsets; outputs [B, max_out(,4)] */
+int rsp_batched_nms(const float* boxes, const float* scores, const int32_t* ids, const int32_t* src,
+                    const int32_t* cnt, int32_t B, int32_t cap, float iou_thr, int32_t max_out,
+                    void* workspace, int32_t* keep, int32_t* keep_cnt, float* out_boxes,
+                    float* out_scores, int32_t* out_ids, int32_t* out_src, rsp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* SAM decoder tail / mask post-process                                        */
+/* ------------------------------------------------------------------------ */
+/* out[r, pix] = sum_c up[r, pix, c] * hyper[r, c]     (HF:523-531)             */
+int rsp_hyper_mask(const float* up, const float* hyper, float* out, int32_t R, int32_t npix,
+                   int32_t C, rsp_stream_t stream);
+/* models.py:1746-1784: sigmoid, bilinear (h,w)->(Hb,Wb), crop (crop_h,crop_w),  */
+/* bilinear -> (out_h,out_w), >= thr.  out_prob optional.                        */
+int rsp_mask_post(const float* low_res, int32_t k, int32_t h, int32_t w, int32_t Hb, int32_t Wb,
+                  int32_t crop_h, int32_t crop_w, int32_t out_h, int32_t out_w, float thr,
+                  uint8_t* out_mask, float* out_prob, rsp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* Data movement                                                              */
@@ -122,6 +212,19 @@ int rsp_preprocess(const void* src, int32_t src_is_u8, float* dst, int32_t H, in
 /* [B*gh*gw, C*p*p] rows, k = (c, ky, kx) (the conv weight's own flattening). */
 int rsp_patchify(const float* img, float* out, int32_t B, int32_t C, int32_t H, int32_t W,
                  int32_t patch, rsp_stream_t stream);
+/* NHWC pooling: mode 0 = MaxPool2d(2,2) (models.py:1307), mode 1 = max_pool2d(k=1,s=2) (:1362) */
+int rsp_pool2(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t mode,
+              rsp_stream_t stream);
+/* y[r,:] = x[r,:] + v[r % vmod, :] */
+int rsp_add_rows(const float* x, const float* v, float* y, int64_t rows, int32_t C, int32_t vmod,
+                 rsp_stream_t stream);
+/* y[i] = sin(x[2i]) + x[2i+1]  (models.py:1672) */
+int rsp_sincos_pairs(const float* x, float* y, int64_t n_out, rsp_stream_t stream);
+/* out[i, j] = boxes[i, j] / sf4[j]   (bboxes /= scale_factor, models.py:1763-1764); sf4 is a HOST pointer */
+int rsp_div_boxes(const float* boxes, float* out, int64_t n, const float* sf4, rsp_stream_t stream);
+/* dst[i,:] = src[idx[i],:] (idx<0 -> 0) */
+int rsp_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows, int32_t C,
+                    rsp_stream_t stream);
 
 #ifdef __cplusplus
 }

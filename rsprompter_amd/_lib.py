@@ -26,6 +26,37 @@ class RspGemmDesc(ctypes.Structure):
         ("conv_k", c_int), ("conv_stride", c_int), ("conv_pad", c_int),
         ("conv_H", c_int), ("conv_W", c_int), ("conv_C", c_int),
         ("conv_Ho", c_int), ("conv_Wo", c_int),
+        ("ct_W", c_int), ("ct_dy", c_int),
+        ("res_bmap", c_void_p), ("res_brows", c_int),
+    ]
+
+
+class RspAttnDesc(ctypes.Structure):
+    _fields_ = [
+        ("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("kv_batch_map", c_void_p),
+        ("q_batch_map", c_void_p),
+        ("q_bs", c_int64), ("q_ts", c_int64), ("q_hs", c_int64),
+        ("k_bs", c_int64), ("k_ts", c_int64), ("k_hs", c_int64),
+        ("v_bs", c_int64), ("v_ts", c_int64), ("v_hs", c_int64),
+        ("o_bs", c_int64), ("o_ts", c_int64), ("o_hs", c_int64),
+        ("B", c_int), ("nh", c_int), ("dh", c_int), ("Tq", c_int), ("Tk", c_int),
+        ("scale", c_float),
+    ]
+
+
+class RspRoiAlignDesc(ctypes.Structure):
+    _fields_ = [
+        ("feat", c_void_p * 4), ("pe", c_void_p * 4), ("H", c_int * 4), ("W", c_int * 4),
+        ("spatial_scale", c_float * 4), ("rois", c_void_p), ("out", c_void_p),
+        ("K", c_int), ("P", c_int), ("C", c_int), ("num_levels", c_int), ("finest_scale", c_int),
+    ]
+
+
+class RspRpnDesc(ctypes.Structure):
+    _fields_ = [
+        ("head", c_void_p * 5), ("H", c_int * 5), ("W", c_int * 5), ("stride", c_float * 5),
+        ("ld", c_int), ("A", c_int), ("nms_pre", c_int), ("num_levels", c_int),
+        ("base_anchors", c_void_p), ("max_ratio", c_float), ("min_bbox_size", c_float),
     ]
 
 
@@ -41,6 +72,25 @@ PROTOTYPES = {
     "rsp_preprocess": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_float, c_void_p]),
     "rsp_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rsp_attention": (c_int, [ctypes.POINTER(RspAttnDesc), c_void_p]),
+    "rsp_roi_align": (c_int, [ctypes.POINTER(RspRoiAlignDesc), c_void_p]),
+    "rsp_rpn_topk": (c_int, [ctypes.POINTER(RspRpnDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rsp_rpn_decode": (c_int, [ctypes.POINTER(RspRpnDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                               c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rsp_bbox_post": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
+                              ctypes.POINTER(c_float), c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                              c_void_p, c_void_p]),
+    "rsp_nms_workspace_bytes": (c_int64, [c_int, c_int]),
+    "rsp_batched_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "rsp_hyper_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rsp_mask_post": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                              c_void_p, c_void_p, c_void_p]),
+    "rsp_pool2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rsp_add_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "rsp_sincos_pairs": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "rsp_div_boxes": (c_int, [c_void_p, c_void_p, c_int64, ctypes.POINTER(c_float), c_void_p]),
+    "rsp_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
 }
 
 _lib = None

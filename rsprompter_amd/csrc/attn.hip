@@ -34,18 +34,28 @@ __device__ __forceinline__ void split8(const float* x, half8_t& hi, half8_t& lo)
   }
 }
 
-template <int DH>
-__global__ __launch_bounds__(256) void vit_attn_kernel(const float* __restrict__ qkv,
-                                                       const float* __restrict__ rel,
-                                                       float* __restrict__ out, int T, int S,
-                                                       int nh, float scale) {
+struct AttnP {
+  const float* q; const float* k; const float* v; const float* rel; float* out;
+  const int32_t* kv_batch_map;  // optional: batch b reads K/V of batch kv_batch_map[b]
+  const int32_t* q_batch_map;   // optional: batch b reads Q of batch q_batch_map[b]
+  int64_t q_bs, q_ts, q_hs;     // element strides: batch, token, head
+  int64_t k_bs, k_ts, k_hs;
+  int64_t v_bs, v_ts, v_hs;
+  int64_t o_bs, o_ts, o_hs;
+  int Tq, Tk, S, nh;
+  float scale;
+};
+
+// HAS_REL: decomposed rel-pos bias (ViT); requires Tq == Tk == S*S.
+template <int DH, bool HAS_REL>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   constexpr int DSTEPS = DH / 16;
   constexpr int DBLK = (DH + 31) / 32;
   constexpr int K_LD = DH + 8;
   constexpr int DCH = DH / 4;                          // float4 chunks per key row
   constexpr int MT_TOTAL = 16 * DCH;                   // 4key x 4d micro tiles per K/V tile
   constexpr int MT_PER_THREAD = (MT_TOTAL + 255) / 256;
-  constexpr int REL_MAX_S = 32;                        // LDS rel table only for S < 64
+  constexpr int REL_MAX_S = HAS_REL ? 32 : 1;          // LDS rel table only for S < 64
 
   __shared__ __attribute__((aligned(16))) half_t sK[2][KT * K_LD];
   __shared__ __attribute__((aligned(16))) half_t sVt[2][DBLK * 32 * VT_LD];
@@ -58,10 +68,16 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float* __restrict__
   const int q0 = blockIdx.x * QB;
   const int ql = wave * 32 + l31;
   const int q = q0 + ql;
-  const bool aligned = (S == 64);
-  const int64_t tok_stride = (int64_t)3 * nh * DH;
-  const float* qkv_b = qkv + (int64_t)bp * T * tok_stride + (int64_t)h * DH;
-  const float* rel_b = rel + ((int64_t)bp * nh + h) * T * (2 * S);
+  const int T = p.Tq, TK = p.Tk, S = p.S, nh = p.nh;
+  const float scale = p.scale;
+  const bool aligned = HAS_REL && (S == 64);
+  const int kvb = p.kv_batch_map ? p.kv_batch_map[bp] : bp;
+  const int qbi = p.q_batch_map ? p.q_batch_map[bp] : bp;
+  const float* q_b = p.q + (int64_t)qbi * p.q_bs + (int64_t)h * p.q_hs;
+  const float* k_b = p.k + (int64_t)kvb * p.k_bs + (int64_t)h * p.k_hs;
+  const float* v_b = p.v + (int64_t)kvb * p.v_bs + (int64_t)h * p.v_hs;
+  const float* rel_b = HAS_REL ? p.rel + ((int64_t)bp * nh + h) * T * (2 * S) : nullptr;
+  float* out = p.out;
 
   // ---- Q fragments (B operand of S^T = K Q^T), scaled and split once ----
   half8_t qh[DSTEPS], qlo[DSTEPS];
@@ -71,7 +87,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float* __restrict__
     for (int st = 0; st < DSTEPS; ++st) {
       float x[8];
       if (q < T) {
-        const float* src = qkv_b + (int64_t)q * tok_stride + st * 16 + hh * 8;
+        const float* src = q_b + (int64_t)q * p.q_ts + st * 16 + hh * 8;
         const f32x4 a = *reinterpret_cast<const f32x4*>(src);
         const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
 #pragma unroll
@@ -94,7 +110,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float* __restrict__
         const int kw = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hh;
         bw[blk][r] = (q < T) ? rel_b[(int64_t)q * (2 * S) + S + kw] : 0.f;
       }
-  } else {
+  } else if (HAS_REL) {
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -122,10 +138,9 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float* __restrict__
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int key = kt * KT + kg * 4 + j;
-          if (key < T) {
-            const float* src = qkv_b + (int64_t)key * tok_stride + (int64_t)nh * DH + dc * 4;
-            kreg[i][j] = *reinterpret_cast<const f32x4*>(src);
-            vreg[i][j] = *reinterpret_cast<const f32x4*>(src + (int64_t)nh * DH);
+          if (key < TK) {
+            kreg[i][j] = *reinterpret_cast<const f32x4*>(k_b + (int64_t)key * p.k_ts + dc * 4);
+            vreg[i][j] = *reinterpret_cast<const f32x4*>(v_b + (int64_t)key * p.v_ts + dc * 4);
           } else {
             kreg[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             vreg[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -188,7 +203,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float* __restrict__
   const float s_unscale = ldexpf(1.0f, -(EQ + EK));
   const float LOG2E = 1.4426950408889634f;
 
-  const int nt = (T + KT - 1) / KT;
+  const int nt = (TK + KT - 1) / KT;
   load_kv(0);
   for (int kt = 0; kt < nt; ++kt) {
     store_kv();
@@ -224,11 +239,11 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float* __restrict__
         float v = sc[blk][r] * s_unscale;
         if (aligned) {
           v += bh_t + bw[blk][r];
-        } else if (key < T) {
+        } else if (HAS_REL && key < TK) {
           const int km = sKmap[key];
           v += sRel[ql * (2 * S + 1) + (km & 0xffff)] + sRel[ql * (2 * S + 1) + S + (km >> 16)];
         }
-        if (key >= T) v = -INFINITY;
+        if (key >= TK) v = -INFINITY;
         sc[blk][r] = v;
         tmax = fmaxf(tmax, v);
       }
@@ -281,7 +296,7 @@ __global__ __launch_bounds__(256) void vit_attn_kernel(const float* __restrict__
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   if (q < T) {
     const float inv = ldexpf(1.0f, -EV) / l_tot;
-    float* dst = out + ((int64_t)bp * T + q) * ((int64_t)nh * DH) + (int64_t)h * DH;
+    float* dst = out + (int64_t)bp * p.o_bs + (int64_t)q * p.o_ts + (int64_t)h * p.o_hs;
 #pragma unroll
     for (int db = 0; db < DBLK; ++db)
 #pragma unroll
@@ -366,21 +381,53 @@ extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const fl
   return RSP_OK;
 }
 
+template <int DH, bool HAS_REL>
+static int launch_attn(const AttnP& p, int B, hipStream_t s) {
+  dim3 grid((p.Tq + QB - 1) / QB, p.nh, B);
+  hipLaunchKernelGGL((attn_kernel<DH, HAS_REL>), grid, dim3(256), 0, s, p);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
 extern "C" int rsp_vit_attention(const float* qkv, const float* rel, float* out, int32_t Bp,
                                  int32_t S, int32_t nh, int32_t dh, float scale,
                                  rsp_stream_t stream) {
   if (!qkv || !rel || !out || Bp <= 0 || S <= 0 || nh <= 0) return RSP_EINVAL;
   if (!(S == 64 || S <= 32)) return RSP_EINVAL;
   const int T = S * S;
-  dim3 grid((T + QB - 1) / QB, nh, Bp);
+  const int64_t D = (int64_t)nh * dh;
+  AttnP p;
+  p.q = qkv; p.k = qkv + D; p.v = qkv + 2 * D; p.rel = rel; p.out = out; p.kv_batch_map = nullptr; p.q_batch_map = nullptr;
+  p.q_bs = p.k_bs = p.v_bs = (int64_t)T * 3 * D;
+  p.q_ts = p.k_ts = p.v_ts = 3 * D;
+  p.q_hs = p.k_hs = p.v_hs = dh;
+  p.o_bs = (int64_t)T * D; p.o_ts = D; p.o_hs = dh;
+  p.Tq = T; p.Tk = T; p.S = S; p.nh = nh; p.scale = scale;
   hipStream_t s = (hipStream_t)stream;
-  if (dh == 64) {
-    hipLaunchKernelGGL((vit_attn_kernel<64>), grid, dim3(256), 0, s, qkv, rel, out, T, S, nh, scale);
-  } else if (dh == 80) {
-    hipLaunchKernelGGL((vit_attn_kernel<80>), grid, dim3(256), 0, s, qkv, rel, out, T, S, nh, scale);
-  } else {
-    return RSP_EINVAL;
+  if (dh == 64) return launch_attn<64, true>(p, Bp, s);
+  if (dh == 80) return launch_attn<80, true>(p, Bp, s);
+  return RSP_EINVAL;
+}
+
+extern "C" int rsp_attention(const RspAttnDesc* d, rsp_stream_t stream) {
+  if (!d || !d->q || !d->k || !d->v || !d->out) return RSP_EINVAL;
+  if (d->B <= 0 || d->nh <= 0 || d->Tq <= 0 || d->Tk <= 0) return RSP_EINVAL;
+  if ((d->q_ts & 3) || (d->k_ts & 3) || (d->v_ts & 3) || (d->o_ts & 3) || (d->q_hs & 3) ||
+      (d->k_hs & 3) || (d->v_hs & 3) || (d->o_hs & 3))
+    return RSP_EINVAL;  // float4 loads/stores
+  AttnP p;
+  p.q = d->q; p.k = d->k; p.v = d->v; p.rel = nullptr; p.out = d->out;
+  p.kv_batch_map = d->kv_batch_map; p.q_batch_map = d->q_batch_map;
+  p.q_bs = d->q_bs; p.q_ts = d->q_ts; p.q_hs = d->q_hs;
+  p.k_bs = d->k_bs; p.k_ts = d->k_ts; p.k_hs = d->k_hs;
+  p.v_bs = d->v_bs; p.v_ts = d->v_ts; p.v_hs = d->v_hs;
+  p.o_bs = d->o_bs; p.o_ts = d->o_ts; p.o_hs = d->o_hs;
+  p.Tq = d->Tq; p.Tk = d->Tk; p.S = 0; p.nh = d->nh; p.scale = d->scale;
+  hipStream_t s = (hipStream_t)stream;
+  switch (d->dh) {
+    case 16: return launch_attn<16, false>(p, d->B, s);
+    case 32: return launch_attn<32, false>(p, d->B, s);
+    case 64: return launch_attn<64, false>(p, d->B, s);
+    default: return RSP_EINVAL;
   }
-  RSP_CHECK_LAUNCH();
-  return RSP_OK;
 }

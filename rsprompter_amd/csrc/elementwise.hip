@@ -89,3 +89,138 @@ extern "C" int rsp_preprocess(const void* src, int32_t src_is_u8, float* dst, in
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
+
+namespace {
+
+// NHWC 2x2/s2 max pooling (mode 0) or stride-2 subsampling = max_pool2d(k=1, s=2) (mode 1)
+__global__ __launch_bounds__(256) void pool2_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                    int B, int H, int W, int C, int mode) {
+  const int Ho = mode == 0 ? H / 2 : (H + 1) / 2, Wo = mode == 0 ? W / 2 : (W + 1) / 2;
+  const int c4n = C / 4;
+  const int64_t total = (int64_t)B * Ho * Wo * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % c4n) * 4;
+    int64_t t = i / c4n;
+    const int xo = (int)(t % Wo); t /= Wo;
+    const int yo = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const float* p = x + (((int64_t)b * H + 2 * yo) * W + 2 * xo) * C + c;
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    if (mode == 0) {
+      const f32x4 v1 = *reinterpret_cast<const f32x4*>(p + C);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (int64_t)W * C);
+      const f32x4 v3 = *reinterpret_cast<const f32x4*>(p + (int64_t)W * C + C);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = fmaxf(fmaxf(v[j], v1[j]), fmaxf(v2[j], v3[j]));
+    }
+    *reinterpret_cast<f32x4*>(y + i * 4) = v;
+  }
+}
+
+// y[r, c] = x[r, c] + v[(r % vmod), c]   (vmod rows of v; vmod==1: per-channel vector)
+__global__ __launch_bounds__(256) void add_rows_kernel(const float* __restrict__ x,
+                                                       const float* __restrict__ v,
+                                                       float* __restrict__ y, int64_t rows, int C,
+                                                       int vmod) {
+  const int c4n = C / 4;
+  const int64_t total = rows * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + r * C + c);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(v + (r % vmod) * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = a[j] + b[j];
+    *reinterpret_cast<f32x4*>(y + r * C + c) = o;
+  }
+}
+
+// point-embedding post-processing (models.py:1670-1672): x [R, n*2c] viewed [R, n, 2c];
+// y[r, n, j] = sin(x[r, n, 2j]) + x[r, n, 2j+1]
+__global__ __launch_bounds__(256) void sincos_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                     int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    y[i] = sinf(x[2 * i]) + x[2 * i + 1];
+  }
+}
+
+// copy rows: dst[i, :] = src[idx[i], :]   (idx < 0 -> zeros)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src,
+                                                          const int32_t* __restrict__ idx,
+                                                          float* __restrict__ dst, int64_t rows, int C) {
+  const int c4n = C / 4;
+  const int64_t total = rows * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / c4n;
+    const int c = (int)(i - r * c4n) * 4;
+    const int s = idx[r];
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s >= 0) v = *reinterpret_cast<const f32x4*>(src + (int64_t)s * C + c);
+    *reinterpret_cast<f32x4*>(dst + r * C + c) = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int rsp_pool2(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C,
+                         int32_t mode, rsp_stream_t stream) {
+  if (!x || !y || B <= 0 || H <= 0 || W <= 0 || C <= 0 || (C & 3) || (mode != 0 && mode != 1)) return RSP_EINVAL;
+  if (mode == 0 && ((H | W) & 1)) return RSP_EINVAL;
+  const int Ho = mode == 0 ? H / 2 : (H + 1) / 2, Wo = mode == 0 ? W / 2 : (W + 1) / 2;
+  const int64_t total = (int64_t)B * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(pool2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, y, B, H, W, C, mode);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+extern "C" int rsp_add_rows(const float* x, const float* v, float* y, int64_t rows, int32_t C,
+                            int32_t vmod, rsp_stream_t stream) {
+  if (!x || !v || !y || rows < 0 || C <= 0 || (C & 3) || vmod <= 0) return RSP_EINVAL;
+  if (rows == 0) return RSP_OK;
+  hipLaunchKernelGGL(add_rows_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, v, y, rows, C, vmod);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+extern "C" int rsp_sincos_pairs(const float* x, float* y, int64_t n_out, rsp_stream_t stream) {
+  if (!x || !y || n_out < 0) return RSP_EINVAL;
+  if (n_out == 0) return RSP_OK;
+  hipLaunchKernelGGL(sincos_kernel, dim3(grid_for(n_out)), dim3(256), 0, (hipStream_t)stream, x, y, n_out);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+extern "C" int rsp_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows,
+                               int32_t C, rsp_stream_t stream) {
+  if (!src || !idx || !dst || rows < 0 || C <= 0 || (C & 3)) return RSP_EINVAL;
+  if (rows == 0) return RSP_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, src, idx, dst, rows, C);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+namespace {
+__global__ void div_boxes_kernel(const float* __restrict__ b, float* __restrict__ o, int64_t n4, float s0,
+                                 float s1, float s2, float s3) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int j = (int)(i & 3);
+  const float s = j == 0 ? s0 : (j == 1 ? s1 : (j == 2 ? s2 : s3));
+  o[i] = b[i] / s;
+}
+}  // namespace
+
+/* bboxes /= scale_factor.repeat(2)  (models.py:1763-1764) */
+extern "C" int rsp_div_boxes(const float* boxes, float* out, int64_t n, const float* sf4, rsp_stream_t stream) {
+  if (!boxes || !out || !sf4 || n < 0) return RSP_EINVAL;
+  if (n == 0) return RSP_OK;
+  hipLaunchKernelGGL(div_boxes_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     boxes, out, n * 4, sf4[0], sf4[1], sf4[2], sf4[3]);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}

@@ -209,7 +209,15 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const GemmP p) {
       if (row >= M) continue;
       int crow = d.c_rowmap ? d.c_rowmap[row] : row;
       if (crow < 0) continue;
-      const int rrow = d.res_mod > 0 ? crow % d.res_mod : crow;
+      if (d.ct_W > 0) {  // ConvTranspose2d(k=2, s=2): pixel (y*W + x) -> output row ((y*2 + dy)*W + x)
+        const int yy = crow / d.ct_W;
+        crow = (yy * 2 + d.ct_dy) * d.ct_W + (crow - yy * d.ct_W);
+      }
+      int64_t rrow = d.res_mod > 0 ? crow % d.res_mod : crow;
+      if (d.res_bmap) {
+        const int rb = crow / d.res_brows;
+        rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (crow - rb * d.res_brows);
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * WTN + j * 32 + l31;
@@ -217,7 +225,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const GemmP p) {
         float v = acc[i][j][r] * alpha;
         if (d.bias) v += d.bias[col];
         v = rsp_act(v, d.act);
-        if (d.res) v += d.res[(int64_t)rrow * d.ldr + col];
+        if (d.res) v += d.res[rrow * d.ldr + col];
         d.C[(int64_t)crow * d.ldc + col] = v;
       }
     }

@@ -1,0 +1,114 @@
+// SAM mask-decoder tail + mask post-processing (HBM-bound kernels).
+//   hyper-network mask product  HF:523-531  (masks = hyper_in @ upscaled_embedding; only mask
+//                               token 0 is kept because multimask_output=False, HF:537-542)
+//   mask post-process           models.py:1746-1784 (sigmoid -> bilinear to batch_input_shape ->
+//                               crop -> bilinear to ori_shape -> >= thr)
+#include "rsp_common.h"
+
+namespace {
+
+// out[r, pix] = sum_c up[r, pix, c] * hyper[r, c];  8 lanes per pixel (C == 32: one float4 each)
+__global__ __launch_bounds__(256) void hyper_mask_kernel(const float* __restrict__ up,
+                                                         const float* __restrict__ hyper,
+                                                         float* __restrict__ out, int npix, int C) {
+  const int r = blockIdx.y;
+  const int part = threadIdx.x & 7;
+  const float* hv = hyper + (int64_t)r * C;
+  const float* ur = up + (int64_t)r * npix * C;
+  for (int pix = blockIdx.x * 32 + (threadIdx.x >> 3); pix < npix; pix += gridDim.x * 32) {
+    float acc = 0.f;
+    for (int c = part * 4; c < C; c += 32) {
+      const f32x4 u = *reinterpret_cast<const f32x4*>(ur + (int64_t)pix * C + c);
+      const f32x4 h = *reinterpret_cast<const f32x4*>(hv + c);
+      acc += u[0] * h[0] + u[1] * h[1] + u[2] * h[2] + u[3] * h[3];
+    }
+    acc += __shfl_xor(acc, 1, 64);
+    acc += __shfl_xor(acc, 2, 64);
+    acc += __shfl_xor(acc, 4, 64);
+    if (part == 0) out[(int64_t)r * npix + pix] = acc;
+  }
+}
+
+struct Lin { int i0, i1; float l0, l1; };
+// torch upsample_bilinear2d(align_corners=False) source index / weights
+__device__ __forceinline__ Lin lin_coef(int dst, float scale, int in_size) {
+  float src = scale * ((float)dst + 0.5f) - 0.5f;
+  if (src < 0.f) src = 0.f;
+  Lin c;
+  c.i0 = (int)src;
+  if (c.i0 > in_size - 1) c.i0 = in_size - 1;
+  c.i1 = c.i0 + (c.i0 < in_size - 1 ? 1 : 0);
+  c.l1 = src - (float)c.i0;
+  c.l0 = 1.0f - c.l1;
+  return c;
+}
+
+struct MaskPostP {
+  const float* low;   // [k, h, w] logits
+  uint8_t* out;       // [k, oh, ow] bool
+  float* prob;        // optional [k, oh, ow]
+  int k, h, w, Hb, Wb, ch, cw, oh, ow;
+  float thr;
+};
+
+__global__ __launch_bounds__(256) void mask_post_kernel(const MaskPostP p) {
+  const int m = blockIdx.y;
+  const float* low = p.low + (int64_t)m * p.h * p.w;
+  const float s1h = (float)p.h / (float)p.Hb, s1w = (float)p.w / (float)p.Wb;
+  const float s2h = (float)p.ch / (float)p.oh, s2w = (float)p.cw / (float)p.ow;
+  const int64_t total = (int64_t)p.oh * p.ow;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int oy = (int)(i / p.ow), ox = (int)(i - (int64_t)oy * p.ow);
+    const Lin cy = lin_coef(oy, s2h, p.ch), cx = lin_coef(ox, s2w, p.cw);
+    float v[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int Y = a == 0 ? cy.i0 : cy.i1;
+      const Lin ay = lin_coef(Y, s1h, p.h);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const int X = b == 0 ? cx.i0 : cx.i1;
+        const Lin ax = lin_coef(X, s1w, p.w);
+        const float v00 = 1.0f / (1.0f + expf(-low[ay.i0 * p.w + ax.i0]));
+        const float v01 = 1.0f / (1.0f + expf(-low[ay.i0 * p.w + ax.i1]));
+        const float v10 = 1.0f / (1.0f + expf(-low[ay.i1 * p.w + ax.i0]));
+        const float v11 = 1.0f / (1.0f + expf(-low[ay.i1 * p.w + ax.i1]));
+        v[a][b] = ay.l0 * (ax.l0 * v00 + ax.l1 * v01) + ay.l1 * (ax.l0 * v10 + ax.l1 * v11);
+      }
+    }
+    const float val = cy.l0 * (cx.l0 * v[0][0] + cx.l1 * v[0][1]) + cy.l1 * (cx.l0 * v[1][0] + cx.l1 * v[1][1]);
+    p.out[(int64_t)m * total + i] = val >= p.thr ? 1 : 0;
+    if (p.prob) p.prob[(int64_t)m * total + i] = val;
+  }
+}
+
+}  // namespace
+
+extern "C" int rsp_hyper_mask(const float* up, const float* hyper, float* out, int32_t R, int32_t npix,
+                              int32_t C, rsp_stream_t stream) {
+  if (!up || !hyper || !out || R < 0 || npix <= 0 || C <= 0 || (C & 3)) return RSP_EINVAL;
+  if (R == 0) return RSP_OK;
+  int gx = (npix + 31) / 32;
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(hyper_mask_kernel, dim3(gx, R), dim3(256), 0, (hipStream_t)stream, up, hyper, out, npix, C);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+extern "C" int rsp_mask_post(const float* low_res, int32_t k, int32_t h, int32_t w, int32_t Hb, int32_t Wb,
+                             int32_t crop_h, int32_t crop_w, int32_t out_h, int32_t out_w, float thr,
+                             uint8_t* out_mask, float* out_prob, rsp_stream_t stream) {
+  if (!low_res || !out_mask || k < 0 || h <= 0 || w <= 0 || Hb <= 0 || Wb <= 0 || crop_h <= 0 || crop_w <= 0 ||
+      crop_h > Hb || crop_w > Wb || out_h <= 0 || out_w <= 0)
+    return RSP_EINVAL;
+  if (k == 0) return RSP_OK;
+  MaskPostP p;
+  p.low = low_res; p.out = out_mask; p.prob = out_prob; p.k = k; p.h = h; p.w = w; p.Hb = Hb; p.Wb = Wb;
+  p.ch = crop_h; p.cw = crop_w; p.oh = out_h; p.ow = out_w; p.thr = thr;
+  int64_t gx = ((int64_t)out_h * out_w + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  hipLaunchKernelGGL(mask_post_kernel, dim3((unsigned)gx, k), dim3(256), 0, (hipStream_t)stream, p);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}

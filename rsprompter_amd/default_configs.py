@@ -1,0 +1,74 @@
+"""Programmatic `model = dict(...)` trees equal to the ones the reference's config files produce
+(configs/rsprompter/_base_/rsprompter_anchor.py:57-200 merged with rsprompter_anchor-<dataset>.py).
+Used by bench.py / tests on machines where /root/reference is absent; tests/test_config_parity.py
+checks them field by field against the real config files when those are present.
+"""
+
+SELECT_LAYERS = {'base': range(1, 13, 2), 'large': range(1, 25, 2), 'huge': range(1, 33, 2)}
+MEAN = [0.485 * 255, 0.456 * 255, 0.406 * 255]
+STD = [0.229 * 255, 0.224 * 255, 0.225 * 255]
+
+
+def rsprompter_anchor(arch='base', num_classes=10, prompt_shape=(70, 5), pretrain_name=None, ckpt=None):
+    name = pretrain_name or f'work_dirs/sam_cache/sam_vit_{arch}'
+    init = dict(type='Pretrained', checkpoint=ckpt or f'{name}/pytorch_model.bin')
+    crop = (1024, 1024)
+    pre = dict(type='DetDataPreprocessor', mean=MEAN, std=STD, bgr_to_rgb=True, pad_mask=True,
+               pad_size_divisor=32,
+               batch_augments=[dict(type='BatchFixedSizePad', size=crop, img_pad_value=0, pad_mask=True,
+                                    mask_pad_value=0, pad_seg=False)])
+    return dict(
+        type='RSPrompterAnchor', data_preprocessor=pre, decoder_freeze=False,
+        shared_image_embedding=dict(type='RSSamPositionalEmbedding', hf_pretrain_name=name, init_cfg=init),
+        backbone=dict(type='RSSamVisionEncoder', hf_pretrain_name=name,
+                      extra_config=dict(output_hidden_states=True), init_cfg=init),
+        neck=dict(type='RSFPN',
+                  feature_aggregator=dict(type='RSFeatureAggregator', in_channels=name, out_channels=256,
+                                          hidden_channels=32, select_layers=SELECT_LAYERS[arch]),
+                  feature_spliter=dict(type='RSSimpleFPN', backbone_channel=256, in_channels=[64, 128, 256, 256],
+                                       out_channels=256, num_outs=5,
+                                       norm_cfg=dict(type='LN2d', requires_grad=True))),
+        rpn_head=dict(type='RPNHead', in_channels=256, feat_channels=256,
+                      anchor_generator=dict(type='AnchorGenerator', scales=[4, 8], ratios=[0.5, 1.0, 2.0],
+                                            strides=[4, 8, 16, 32, 64]),
+                      bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[.0, .0, .0, .0],
+                                      target_stds=[1.0, 1.0, 1.0, 1.0]),
+                      loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                      loss_bbox=dict(type='SmoothL1Loss', loss_weight=1.0)),
+        roi_head=dict(
+            type='RSPrompterAnchorRoIPromptHead', with_extra_pe=True,
+            bbox_roi_extractor=dict(type='SingleRoIExtractor',
+                                    roi_layer=dict(type='RoIAlign', output_size=7, sampling_ratio=0),
+                                    out_channels=256, featmap_strides=[4, 8, 16, 32]),
+            bbox_head=dict(type='Shared2FCBBoxHead', in_channels=256, fc_out_channels=1024, roi_feat_size=7,
+                           num_classes=num_classes,
+                           bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.],
+                                           target_stds=[0.1, 0.1, 0.2, 0.2]),
+                           reg_class_agnostic=False,
+                           loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0),
+                           loss_bbox=dict(type='SmoothL1Loss', loss_weight=1.0)),
+            mask_roi_extractor=dict(type='SingleRoIExtractor',
+                                    roi_layer=dict(type='RoIAlign', output_size=14, sampling_ratio=0),
+                                    out_channels=256, featmap_strides=[4, 8, 16, 32]),
+            mask_head=dict(type='RSPrompterAnchorMaskHead',
+                           mask_decoder=dict(type='RSSamMaskDecoder', hf_pretrain_name=name, init_cfg=init),
+                           in_channels=256, roi_feat_size=14, per_pointset_point=prompt_shape[1],
+                           with_sincos=True, multimask_output=False, class_agnostic=True,
+                           loss_mask=dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0))),
+        train_cfg=dict(
+            rpn=dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.7, neg_iou_thr=0.3, min_pos_iou=0.3,
+                                   match_low_quality=True, ignore_iof_thr=-1),
+                     sampler=dict(type='RandomSampler', num=256, pos_fraction=0.5, neg_pos_ub=-1,
+                                  add_gt_as_proposals=False),
+                     allowed_border=-1, pos_weight=-1, debug=False),
+            rpn_proposal=dict(nms_pre=2000, max_per_img=1000, nms=dict(type='nms', iou_threshold=0.7),
+                              min_bbox_size=0),
+            rcnn=dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.5,
+                                    match_low_quality=True, ignore_iof_thr=-1),
+                      sampler=dict(type='RandomSampler', num=256, pos_fraction=0.25, neg_pos_ub=-1,
+                                   add_gt_as_proposals=True),
+                      mask_size=crop, pos_weight=-1, debug=False)),
+        test_cfg=dict(rpn=dict(nms_pre=1000, max_per_img=1000, nms=dict(type='nms', iou_threshold=0.7),
+                               min_bbox_size=0),
+                      rcnn=dict(score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100,
+                                mask_thr_binary=0.5)))

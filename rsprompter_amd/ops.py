@@ -58,7 +58,8 @@ class PackedWeight:
 
 
 def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, c_rowmap=None,
-         M=None, out_rows=None, res_mod=0, a_scale_log2=DEFAULT_A_SCALE_LOG2, conv=None):
+         M=None, out_rows=None, res_mod=0, a_scale_log2=DEFAULT_A_SCALE_LOG2, conv=None,
+         res_bmap=None, res_brows=0):
     """C = act(A @ W^T + bias) + res   (see RspGemmDesc in include/rsp_hip.h).
 
     a: [rows, K] fp32 (row stride = a.stride(0)) or, with conv=(k, stride, pad),
@@ -103,6 +104,7 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.M, d.N, d.K = m, n, w.K
     d.ldc = out.stride(0)
     d.res_mod = res_mod
+    d.res_bmap, d.res_brows = _ptr(res_bmap), res_brows
     d.act = act
     d.a_scale_log2 = a_scale_log2
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
@@ -174,4 +176,225 @@ def preprocess(imgs, mean, std, swap_rb, pad_divisor=1, pad_value=0.0, device=No
         _lib.check(lib.rsp_preprocess(im.data_ptr(), is_u8, out[b].data_ptr(), int(im.shape[1]),
                                       int(im.shape[2]), Hp, Wp, m3, s3, 1 if swap_rb else 0,
                                       float(pad_value), _stream()), "rsp_preprocess")
+    return out
+
+
+def conv_transpose2x2(x_nhwc, w_dy, bias, act=ACT_NONE, a_scale_log2=DEFAULT_A_SCALE_LOG2):
+    """ConvTranspose2d(k=2, s=2) on NHWC as two GEMMs (one per output-row parity).
+
+    x_nhwc: [B, H, W, Cin]; w_dy: (PackedWeight, PackedWeight) each [(dx, co), Cin] for dy=0/1;
+    bias: [2*Cout] = bias tiled over dx.  returns [B, 2H, 2W, Cout].
+    """
+    B, H, W, Cin = x_nhwc.shape
+    n2 = w_dy[0].N
+    cout = n2 // 2
+    out = torch.empty((B, 2 * H, 2 * W, cout), dtype=torch.float32, device=x_nhwc.device)
+    a = x_nhwc.view(B * H * W, Cin)
+    o2 = out.view(B * 2 * H * W, n2)
+    for dy in (0, 1):
+        _gemm_ct(a, w_dy[dy], o2, bias, act, W, dy, a_scale_log2)
+    return out
+
+
+def _gemm_ct(a, w, out, bias, act, ct_W, ct_dy, a_scale_log2):
+    lib = _lib.load()
+    d = _lib.RspGemmDesc()
+    d.A, d.Bhi, d.Blo, d.C = a.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), out.data_ptr()
+    d.bias = _ptr(bias)
+    d.M, d.N, d.K = a.shape[0], w.N, w.K
+    d.lda, d.ldc = a.stride(0), out.stride(0)
+    d.act = act
+    d.a_scale_log2 = a_scale_log2
+    d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
+    d.ct_W, d.ct_dy = ct_W, ct_dy
+    _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm(convT)")
+
+
+def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v_strides, o_strides,
+              kv_batch_map=None, q_batch_map=None):
+    """Generic strided multi-head attention (RspAttnDesc). strides = (batch, token, head) in elements."""
+    lib = _lib.load()
+    d = _lib.RspAttnDesc()
+    d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    d.kv_batch_map = _ptr(kv_batch_map)
+    d.q_batch_map = _ptr(q_batch_map)
+    d.q_bs, d.q_ts, d.q_hs = q_strides
+    d.k_bs, d.k_ts, d.k_hs = k_strides
+    d.v_bs, d.v_ts, d.v_hs = v_strides
+    d.o_bs, d.o_ts, d.o_hs = o_strides
+    d.B, d.nh, d.dh, d.Tq, d.Tk, d.scale = B, nh, dh, Tq, Tk, scale
+    _lib.check(lib.rsp_attention(d, _stream()), "rsp_attention")
+    return out
+
+
+def roi_align(feats_nhwc, pes, rois, P, strides, finest_scale=56):
+    """feats_nhwc: list of [B,H,W,C]; pes: list of [H,W,C] or None; rois [K,5] -> [K,P,P,C]."""
+    lib = _lib.load()
+    K = rois.shape[0]
+    C = feats_nhwc[0].shape[-1]
+    out = torch.empty((K, P, P, C), dtype=torch.float32, device=rois.device)
+    if K == 0:
+        return out
+    d = _lib.RspRoiAlignDesc()
+    for i, f in enumerate(feats_nhwc):
+        _chk_f32(f, "feat")
+        if not f.is_contiguous():
+            raise ValueError("roi_align expects contiguous NHWC levels")
+        d.feat[i] = f.data_ptr()
+        d.pe[i] = 0 if pes is None or pes[i] is None else pes[i].data_ptr()
+        d.H[i], d.W[i] = f.shape[1], f.shape[2]
+        d.spatial_scale[i] = 1.0 / strides[i]
+    d.rois, d.out = rois.data_ptr(), out.data_ptr()
+    d.K, d.P, d.C, d.num_levels, d.finest_scale = K, P, C, len(feats_nhwc), finest_scale
+    _lib.check(lib.rsp_roi_align(d, _stream()), "rsp_roi_align")
+    return out
+
+
+def pool2(x_nhwc, mode):
+    lib = _lib.load()
+    B, H, W, C = x_nhwc.shape
+    Ho, Wo = (H // 2, W // 2) if mode == 0 else ((H + 1) // 2, (W + 1) // 2)
+    out = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x_nhwc.device)
+    _lib.check(lib.rsp_pool2(x_nhwc.data_ptr(), out.data_ptr(), B, H, W, C, mode, _stream()), "rsp_pool2")
+    return out
+
+
+def add_rows(x, v, vmod=None, out=None):
+    """x [rows, C] + v[(row % vmod), C]."""
+    lib = _lib.load()
+    C = x.shape[-1]
+    rows = x.numel() // C
+    vmod = v.numel() // C if vmod is None else vmod
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(lib.rsp_add_rows(x.data_ptr(), v.data_ptr(), out.data_ptr(), rows, C, vmod, _stream()),
+               "rsp_add_rows")
+    return out
+
+
+def sincos_pairs(x):
+    lib = _lib.load()
+    out = torch.empty(x.shape[:-1] + (x.shape[-1] // 2,), dtype=torch.float32, device=x.device)
+    _lib.check(lib.rsp_sincos_pairs(x.data_ptr(), out.data_ptr(), out.numel(), _stream()), "rsp_sincos_pairs")
+    return out
+
+
+def gather_rows(src, idx):
+    lib = _lib.load()
+    C = src.shape[-1]
+    out = torch.empty((idx.numel(), C), dtype=torch.float32, device=src.device)
+    _lib.check(lib.rsp_gather_rows(src.data_ptr(), idx.data_ptr(), out.data_ptr(), idx.numel(), C, _stream()),
+               "rsp_gather_rows")
+    return out
+
+
+def hyper_mask(up, hyper):
+    """up [R, npix, C], hyper [R, C] -> [R, npix]."""
+    lib = _lib.load()
+    R, npix, C = up.shape
+    out = torch.empty((R, npix), dtype=torch.float32, device=up.device)
+    _lib.check(lib.rsp_hyper_mask(up.data_ptr(), hyper.data_ptr(), out.data_ptr(), R, npix, C, _stream()),
+               "rsp_hyper_mask")
+    return out
+
+
+def mask_post(low_res, batch_input_shape, crop_hw, out_hw, thr, want_prob=False):
+    """low_res [k, h, w] logits -> bool [k, out_h, out_w] (+ optional probabilities)."""
+    lib = _lib.load()
+    k, h, w = low_res.shape
+    out = torch.empty((k, out_hw[0], out_hw[1]), dtype=torch.bool, device=low_res.device)
+    prob = torch.empty((k, out_hw[0], out_hw[1]), dtype=torch.float32, device=low_res.device) if want_prob else None
+    _lib.check(lib.rsp_mask_post(low_res.data_ptr(), k, h, w, batch_input_shape[0], batch_input_shape[1],
+                                 crop_hw[0], crop_hw[1], out_hw[0], out_hw[1], thr, out.data_ptr(), _ptr(prob),
+                                 _stream()), "rsp_mask_post")
+    return (out, prob) if want_prob else out
+
+
+class RpnSelector:
+    """rpn_topk -> rpn_decode -> batched_nms on the device (rpn_head.py:134-304)."""
+
+    def __init__(self, base_anchors, strides, nms_pre, max_per_img, iou_thr, min_bbox_size, max_ratio, device):
+        self.base = base_anchors.to(torch.float32).contiguous().to(device)   # [L, A, 4]
+        self.strides = list(strides)
+        self.L, self.A = self.base.shape[0], self.base.shape[1]
+        self.nms_pre, self.max_per_img, self.iou_thr = nms_pre, max_per_img, iou_thr
+        self.min_bbox_size, self.max_ratio = min_bbox_size, max_ratio
+
+    def __call__(self, heads, sizes, ld, img_hw):
+        """heads: per-level [B*H*W, ld] outputs; sizes: [(H, W)]; img_hw: device [B, 2] float."""
+        lib = _lib.load()
+        dev = heads[0].device
+        B = img_hw.shape[0]
+        d = _lib.RspRpnDesc()
+        for i, (hd, (H, W)) in enumerate(zip(heads, sizes)):
+            d.head[i] = hd.data_ptr()
+            d.H[i], d.W[i], d.stride[i] = H, W, float(self.strides[i])
+        d.ld, d.A, d.nms_pre, d.num_levels = ld, self.A, self.nms_pre, len(heads)
+        d.base_anchors = self.base.data_ptr()
+        d.max_ratio, d.min_bbox_size = self.max_ratio, float(self.min_bbox_size)
+        L, k = len(heads), self.nms_pre
+        sel_idx = torch.empty((B, L, k), dtype=torch.int32, device=dev)
+        sel_score = torch.empty((B, L, k), dtype=torch.float32, device=dev)
+        sel_cnt = torch.empty((B, L), dtype=torch.int32, device=dev)
+        _lib.check(lib.rsp_rpn_topk(d, B, sel_idx.data_ptr(), sel_score.data_ptr(), sel_cnt.data_ptr(),
+                                    _stream()), "rsp_rpn_topk")
+        cap = L * k
+        cand = _cand_buffers(B, cap, dev)
+        _lib.check(lib.rsp_rpn_decode(d, B, sel_idx.data_ptr(), sel_score.data_ptr(), sel_cnt.data_ptr(),
+                                      img_hw.data_ptr(), cap, *[c.data_ptr() for c in cand], _stream()),
+                   "rsp_rpn_decode")
+        return batched_nms(cand, B, cap, self.iou_thr, self.max_per_img)
+
+
+def _cand_buffers(B, cap, dev):
+    return (torch.empty((B, cap, 4), dtype=torch.float32, device=dev),
+            torch.empty((B, cap), dtype=torch.float32, device=dev),
+            torch.empty((B, cap), dtype=torch.int32, device=dev),
+            torch.empty((B, cap), dtype=torch.int32, device=dev),
+            torch.empty((B,), dtype=torch.int32, device=dev))
+
+
+def batched_nms(cand, B, cap, iou_thr, max_out):
+    """cand = (boxes [B,cap,4], scores, ids, src, cnt).  returns dict of [B, max_out] outputs + counts."""
+    lib = _lib.load()
+    boxes, scores, ids, src, cnt = cand
+    dev = boxes.device
+    ws = torch.empty((int(lib.rsp_nms_workspace_bytes(B, cap)),), dtype=torch.uint8, device=dev)
+    keep = torch.empty((B, max_out), dtype=torch.int32, device=dev)
+    keep_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
+    ob = torch.empty((B, max_out, 4), dtype=torch.float32, device=dev)
+    os_ = torch.empty((B, max_out), dtype=torch.float32, device=dev)
+    oi = torch.empty((B, max_out), dtype=torch.int32, device=dev)
+    osrc = torch.empty((B, max_out), dtype=torch.int32, device=dev)
+    _lib.check(lib.rsp_batched_nms(boxes.data_ptr(), scores.data_ptr(), ids.data_ptr(), src.data_ptr(),
+                                   cnt.data_ptr(), B, cap, iou_thr, max_out, ws.data_ptr(), keep.data_ptr(),
+                                   keep_cnt.data_ptr(), ob.data_ptr(), os_.data_ptr(), oi.data_ptr(),
+                                   osrc.data_ptr(), _stream()), "rsp_batched_nms")
+    return dict(boxes=ob, scores=os_, ids=oi, src=osrc, count=keep_cnt, keep=keep, cand_count=cnt)
+
+
+def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, max_ratio, iou_thr, max_out):
+    """R-CNN head post-processing + multiclass NMS (bbox_head.py:476-571, bbox_nms.py:12-105)."""
+    import ctypes
+    lib = _lib.load()
+    dev = head.device
+    B = img_hw.shape[0]
+    n_max = int((roi_start[1:] - roi_start[:-1]).max()) if roi_start.numel() > 1 else 0
+    cap = max(n_max * num_classes, 1)
+    cand = _cand_buffers(B, cap, dev)
+    std4 = (ctypes.c_float * 4)(*[float(s) for s in stds])
+    rs = roi_start.to(device=dev, dtype=torch.int32)
+    _lib.check(lib.rsp_bbox_post(head.data_ptr(), ld, rois.data_ptr(), rs.data_ptr(), img_hw.data_ptr(), B,
+                                 num_classes, score_thr, std4, max_ratio, cap, *[c.data_ptr() for c in cand],
+                                 _stream()), "rsp_bbox_post")
+    return batched_nms(cand, B, cap, iou_thr, max_out)
+
+
+def div_boxes(boxes, sf4):
+    """boxes [k,4] / (sf_w, sf_h, sf_w, sf_h)."""
+    import ctypes
+    lib = _lib.load()
+    boxes = boxes.contiguous()
+    out = torch.empty_like(boxes)
+    arr = (ctypes.c_float * 4)(*[float(v) for v in sf4])
+    _lib.check(lib.rsp_div_boxes(boxes.data_ptr(), out.data_ptr(), boxes.shape[0], arr, _stream()), "rsp_div_boxes")
     return out

@@ -1,0 +1,361 @@
+"""SAM mask decoder / positional embedding / prompt-encoder leftovers on HIP kernels.
+
+Reference wrappers: mmdet/rsprompter/models.py  RSSamPositionalEmbedding :744-759,
+RSSamPromptEncoder :881-896, RSSamMaskDecoder :899-914 around HuggingFace
+SamPositionalEmbedding HF:552-566, SamMaskEmbedding HF:584-593, SamMaskDecoder HF:432-543,
+SamTwoWayTransformer HF:351-405, SamTwoWayAttentionBlock HF:272-348, SamAttention HF:194-270.
+
+MI355X design: the reference repeats the [256,64,64] image embedding, its
+positional encoding and the dense prompt once per RoI (`repeat_interleave`, models.py:1680-1683)
+before entering the decoder.  Here the per-image tensors stay per image: RoI -> image index maps
+are applied inside the kernels (attention `kv_batch_map` / `q_batch_map`, GEMM `res_bmap`), the
+positional encoding enters every key/query projection as a precomputed broadcast term
+`pe @ W^T + b`, and layer-0 image-side projections are computed once per image.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .nnutil import HIPModule, add_param, infer_sam_arch, nchw_view, nhwc_view
+from .registry import MODELS
+
+HID = 256          # SamMaskDecoderConfig.hidden_size
+HEADS = 8
+MLP_DIM = 2048
+N_MASK_TOKENS = 4  # num_multimask_outputs + 1
+
+
+def _add_linear(root, name, cout, cin):
+    add_param(root, name + '.weight', (cout, cin))
+    add_param(root, name + '.bias', (cout,))
+
+
+def _add_ln(root, name, c):
+    add_param(root, name + '.weight', (c,), 1.0)
+    add_param(root, name + '.bias', (c,))
+
+
+def _add_attn(root, name, internal):
+    for p in ('q_proj', 'k_proj', 'v_proj'):
+        _add_linear(root, f'{name}.{p}', internal, HID)
+    _add_linear(root, f'{name}.out_proj', HID, internal)
+
+
+def _g(root, dotted):
+    for p in dotted.split('.'):
+        root = getattr(root, p)
+    return root
+
+
+class SamMaskDecoderHIP(HIPModule):
+    """Parameters in HF `SamMaskDecoder` layout."""
+
+    def __init__(self):
+        super().__init__()
+        add_param(self, 'iou_token.weight', (1, HID))
+        add_param(self, 'mask_tokens.weight', (N_MASK_TOKENS, HID))
+        for i in range(2):
+            p = f'transformer.layers.{i}'
+            _add_attn(self, p + '.self_attn', HID)
+            _add_attn(self, p + '.cross_attn_token_to_image', HID // 2)
+            _add_attn(self, p + '.cross_attn_image_to_token', HID // 2)
+            for j in range(1, 5):
+                _add_ln(self, f'{p}.layer_norm{j}', HID)
+            _add_linear(self, p + '.mlp.lin1', MLP_DIM, HID)
+            _add_linear(self, p + '.mlp.lin2', HID, MLP_DIM)
+        _add_attn(self, 'transformer.final_attn_token_to_image', HID // 2)
+        _add_ln(self, 'transformer.layer_norm_final_attn', HID)
+        add_param(self, 'upscale_conv1.weight', (HID, HID // 4, 2, 2))
+        add_param(self, 'upscale_conv1.bias', (HID // 4,))
+        add_param(self, 'upscale_conv2.weight', (HID // 4, HID // 8, 2, 2))
+        add_param(self, 'upscale_conv2.bias', (HID // 8,))
+        _add_ln(self, 'upscale_layer_norm', HID // 4)
+        for i in range(N_MASK_TOKENS):
+            p = f'output_hypernetworks_mlps.{i}'
+            _add_linear(self, p + '.proj_in', HID, HID)
+            _add_linear(self, p + '.layers.0', HID, HID)
+            _add_linear(self, p + '.proj_out', HID // 8, HID)
+        _add_linear(self, 'iou_prediction_head.proj_in', HID, HID)
+        _add_linear(self, 'iou_prediction_head.layers.0', HID, HID)
+        _add_linear(self, 'iou_prediction_head.proj_out', N_MASK_TOKENS, HID)
+        self._pe_cache = {}
+
+    # ------------------------------------------------------------------ packing
+    def _pw(self, name, with_bias=True):
+        m = _g(self, name)
+        return ops.PackedWeight(m.weight, m.bias if with_bias else None)
+
+    def _pack(self):
+        from .necks import convt_weights
+        P = {}
+        for i in range(2):
+            p = f'transformer.layers.{i}'
+            for a in ('self_attn', 'cross_attn_token_to_image', 'cross_attn_image_to_token'):
+                for pr in ('q_proj', 'k_proj', 'v_proj', 'out_proj'):
+                    P[f'{i}.{a}.{pr}'] = self._pw(f'{p}.{a}.{pr}')
+            P[f'{i}.lin1'] = self._pw(p + '.mlp.lin1')
+            P[f'{i}.lin2'] = self._pw(p + '.mlp.lin2')
+        for pr in ('q_proj', 'k_proj', 'v_proj', 'out_proj'):
+            P[f'final.{pr}'] = self._pw(f'transformer.final_attn_token_to_image.{pr}')
+        P['up1'] = convt_weights(self.upscale_conv1.weight, self.upscale_conv1.bias)
+        P['up2'] = convt_weights(self.upscale_conv2.weight, self.upscale_conv2.bias)
+        for i in range(N_MASK_TOKENS):
+            for l in ('proj_in', 'layers.0', 'proj_out'):
+                P[f'hyper{i}.{l}'] = self._pw(f'output_hypernetworks_mlps.{i}.{l}')
+        for l in ('proj_in', 'layers.0', 'proj_out'):
+            P[f'iou.{l}'] = self._pw(f'iou_prediction_head.{l}')
+        self._packed = P
+        self._pe_cache = {}
+
+    def _pe_terms(self, pe_rows):
+        """pe @ W^T + b for every image-side projection that consumes keys + pe (HF:326-343, 397-400)."""
+        key = (pe_rows.data_ptr(), tuple(pe_rows.shape))
+        if key not in self._pe_cache:
+            P = self._packed
+            t = {}
+            for name in ('0.cross_attn_token_to_image.k_proj', '1.cross_attn_token_to_image.k_proj',
+                         '0.cross_attn_image_to_token.q_proj', '1.cross_attn_image_to_token.q_proj',
+                         'final.k_proj'):
+                t[name] = ops.gemm(pe_rows, P[name])      # includes the projection bias
+            self._pe_cache = {key: t}
+        return self._pe_cache[key]
+
+    # ------------------------------------------------------------------ pieces
+    def _ln(self, x, name, eps=1e-6):
+        m = _g(self, name)
+        return ops.layernorm(x, m.weight, m.bias, eps)
+
+    def _token_attn(self, q_in, k_in, v_in, pfx, R, T, res=None):
+        """SamAttention among the T prompt tokens of each RoI (self attention, internal dim 256)."""
+        P = self._packed
+        q = ops.gemm(q_in, P[pfx + '.q_proj'])
+        k = ops.gemm(k_in, P[pfx + '.k_proj'])
+        v = ops.gemm(v_in, P[pfx + '.v_proj'])
+        dh = HID // HEADS
+        o = torch.empty_like(q)
+        st = (T * HID, HID, dh)
+        ops.attention(q, k, v, o, B=R, nh=HEADS, dh=dh, Tq=T, Tk=T, scale=dh ** -0.5,
+                      q_strides=st, k_strides=st, v_strides=st, o_strides=st)
+        return ops.gemm(o, P[pfx + '.out_proj'], res=res)
+
+    def decode(self, image_embeddings, image_pe, sparse, dense_vec, roi_img, want_iou=True):
+        """image_embeddings [B,256,h,w] (logical NCHW, channels-last), image_pe [1|B,256,h,w] (input
+        independent; batch entry 0 is used), sparse [R, n_pts, 256], dense_vec [256] (the broadcast
+        `no_mask_embed`, models.py:1680), roi_img int32 [R] image index of every RoI (sorted).
+        Returns low_res_masks [R, 1, 4h, 4w] (mask token 0, multimask_output=False) and iou [R, 1]."""
+        if self._packed is None:
+            self._pack()
+        P = self._packed
+        emb = nhwc_view(image_embeddings)
+        B, h, w, C = emb.shape
+        N = h * w
+        R, npts = sparse.shape[0], sparse.shape[1]
+        T = 1 + N_MASK_TOKENS + npts
+        dev = emb.device
+        pe_rows = nhwc_view(image_pe[:1]).reshape(N, C)
+        pe_t = self._pe_terms(pe_rows)
+        d2, dh2 = HID // 2, (HID // 2) // HEADS
+
+        # tokens = [iou, mask x4, sparse prompts] (HF:489-496)
+        out_tok = torch.cat([self.iou_token.weight, self.mask_tokens.weight], 0)
+        tokens0 = torch.cat([out_tok.unsqueeze(0).expand(R, -1, -1), sparse.reshape(R, npts, HID)], 1)
+        tokens0 = tokens0.reshape(R * T, HID).contiguous()
+        # keys of layer 0: image embedding + dense prompt, ONE copy per image (HF:499)
+        src = ops.add_rows(emb.reshape(B * N, C), dense_vec.reshape(1, C), vmod=1)
+
+        # ---------------- layer 0 (HF:306-348 with skip_first_layer_pe) ----------------
+        q = self._token_attn(tokens0, tokens0, tokens0, '0.self_attn', R, T)          # replaces queries
+        q = self._ln(q, 'transformer.layers.0.layer_norm1')
+        # tokens -> image
+        qpe = ops.add_rows(q, tokens0)
+        tq = ops.gemm(qpe, P['0.cross_attn_token_to_image.q_proj'])
+        k_img = ops.gemm(src, P['0.cross_attn_token_to_image.k_proj'], bias=None,
+                         res=pe_t['0.cross_attn_token_to_image.k_proj'], res_mod=N)      # per image
+        v_img = ops.gemm(src, P['0.cross_attn_token_to_image.v_proj'])
+        ao = torch.empty_like(tq)
+        ops.attention(tq, k_img, v_img, ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
+                      q_strides=(T * d2, d2, dh2), k_strides=(N * d2, d2, dh2), v_strides=(N * d2, d2, dh2),
+                      o_strides=(T * d2, d2, dh2), kv_batch_map=roi_img)
+        q = ops.gemm(ao, P['0.cross_attn_token_to_image.out_proj'], res=q)
+        q = self._ln(q, 'transformer.layers.0.layer_norm2')
+        hmid = ops.gemm(q, P['0.lin1'], act=ops.ACT_RELU)
+        q = ops.gemm(hmid, P['0.lin2'], res=q)
+        q = self._ln(q, 'transformer.layers.0.layer_norm3')
+        # image -> tokens: image-side queries are per image, keys/values per RoI
+        qpe = ops.add_rows(q, tokens0)
+        qi = ops.gemm(src, P['0.cross_attn_image_to_token.q_proj'], bias=None,
+                      res=pe_t['0.cross_attn_image_to_token.q_proj'], res_mod=N)
+        kt = ops.gemm(qpe, P['0.cross_attn_image_to_token.k_proj'])
+        vt = ops.gemm(q, P['0.cross_attn_image_to_token.v_proj'])
+        ai = torch.empty((R * N, d2), dtype=torch.float32, device=dev)
+        ops.attention(qi, kt, vt, ai, B=R, nh=HEADS, dh=dh2, Tq=N, Tk=T, scale=dh2 ** -0.5,
+                      q_strides=(N * d2, d2, dh2), k_strides=(T * d2, d2, dh2), v_strides=(T * d2, d2, dh2),
+                      o_strides=(N * d2, d2, dh2), q_batch_map=roi_img)
+        keys = ops.gemm(ai, P['0.cross_attn_image_to_token.out_proj'], res=src, res_bmap=roi_img, res_brows=N)
+        keys = self._ln(keys, 'transformer.layers.0.layer_norm4')                        # [R*N, 256]
+        del ai, qi, k_img, v_img
+
+        # ---------------- layer 1 ----------------
+        qpe = ops.add_rows(q, tokens0)
+        q = self._token_attn(qpe, qpe, q, '1.self_attn', R, T, res=q)
+        q = self._ln(q, 'transformer.layers.1.layer_norm1')
+        qpe = ops.add_rows(q, tokens0)
+        tq = ops.gemm(qpe, P['1.cross_attn_token_to_image.q_proj'])
+        kk = ops.gemm(keys, P['1.cross_attn_token_to_image.k_proj'], bias=None,
+                      res=pe_t['1.cross_attn_token_to_image.k_proj'], res_mod=N)
+        vv = ops.gemm(keys, P['1.cross_attn_token_to_image.v_proj'])
+        ops.attention(tq, kk, vv, ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
+                      q_strides=(T * d2, d2, dh2), k_strides=(N * d2, d2, dh2), v_strides=(N * d2, d2, dh2),
+                      o_strides=(T * d2, d2, dh2))
+        q = ops.gemm(ao, P['1.cross_attn_token_to_image.out_proj'], res=q)
+        q = self._ln(q, 'transformer.layers.1.layer_norm2')
+        hmid = ops.gemm(q, P['1.lin1'], act=ops.ACT_RELU)
+        q = ops.gemm(hmid, P['1.lin2'], res=q)
+        q = self._ln(q, 'transformer.layers.1.layer_norm3')
+        qpe = ops.add_rows(q, tokens0)
+        qi = ops.gemm(keys, P['1.cross_attn_image_to_token.q_proj'], bias=None,
+                      res=pe_t['1.cross_attn_image_to_token.q_proj'], res_mod=N)
+        kt = ops.gemm(qpe, P['1.cross_attn_image_to_token.k_proj'])
+        vt = ops.gemm(q, P['1.cross_attn_image_to_token.v_proj'])
+        ai = kk  # reuse the [R*N, 128] buffer
+        ops.attention(qi, kt, vt, ai, B=R, nh=HEADS, dh=dh2, Tq=N, Tk=T, scale=dh2 ** -0.5,
+                      q_strides=(N * d2, d2, dh2), k_strides=(T * d2, d2, dh2), v_strides=(T * d2, d2, dh2),
+                      o_strides=(N * d2, d2, dh2))
+        keys = ops.gemm(ai, P['1.cross_attn_image_to_token.out_proj'], res=keys)
+        keys = self._ln(keys, 'transformer.layers.1.layer_norm4')
+
+        # ---------------- final token -> image attention (HF:396-404; LayerNorm default eps 1e-5) ----
+        qpe = ops.add_rows(q, tokens0)
+        tq = ops.gemm(qpe, P['final.q_proj'])
+        kk = ops.gemm(keys, P['final.k_proj'], bias=None, res=pe_t['final.k_proj'], res_mod=N, out=kk)
+        vv = ops.gemm(keys, P['final.v_proj'], out=vv)
+        ops.attention(tq, kk, vv, ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
+                      q_strides=(T * d2, d2, dh2), k_strides=(N * d2, d2, dh2), v_strides=(N * d2, d2, dh2),
+                      o_strides=(T * d2, d2, dh2))
+        q = ops.gemm(ao, P['final.out_proj'], res=q)
+        q = self._ln(q, 'transformer.layer_norm_final_attn', eps=1e-5)
+        del kk, vv, qi
+        q3 = q.view(R, T, HID)
+
+        # ---------------- upscaling + hyper-network (HF:513-531) ----------------
+        up = ops.conv_transpose2x2(keys.view(R, h, w, HID), *P['up1'])
+        del keys
+        up = ops.layernorm(up, self.upscale_layer_norm.weight, self.upscale_layer_norm.bias, 1e-6,
+                           act=ops.ACT_GELU)
+        up = ops.conv_transpose2x2(up, *P['up2'], act=ops.ACT_GELU)                     # [R, 4h, 4w, 32]
+        mt = q3[:, 1, :].contiguous()           # mask token 0 -> the only mask kept (HF:537-542)
+        hy = ops.gemm(mt, P['hyper0.proj_in'], act=ops.ACT_RELU)
+        hy = ops.gemm(hy, P['hyper0.layers.0'], act=ops.ACT_RELU)
+        hy = ops.gemm(hy, P['hyper0.proj_out'])
+        masks = ops.hyper_mask(up.view(R, 16 * N, HID // 8), hy).view(R, 1, 4 * h, 4 * w)
+        iou = None
+        if want_iou:
+            it = q3[:, 0, :].contiguous()
+            io = ops.gemm(it, P['iou.proj_in'], act=ops.ACT_RELU)
+            io = ops.gemm(io, P['iou.layers.0'], act=ops.ACT_RELU)
+            iou = ops.gemm(io, P['iou.proj_out'])[:, 0:1]
+        return masks, iou
+
+    def forward(self, image_embeddings, image_positional_embeddings, sparse_prompt_embeddings,
+                dense_prompt_embeddings, multimask_output=False, attention_similarity=None,
+                target_embedding=None, output_attentions=None):
+        """HF-compatible signature (HF:461-543) for callers that already repeated the image tensors per
+        prompt set: every batch entry is treated as its own image.  Only the configuration used by
+        RSPrompter (point_batch_size 1, multimask_output=False, constant dense prompt) is supported."""
+        if multimask_output or attention_similarity is not None or target_embedding is not None:
+            raise NotImplementedError('only multimask_output=False without attention_similarity/target_embedding')
+        R = image_embeddings.shape[0]
+        if sparse_prompt_embeddings.dim() == 4:
+            if sparse_prompt_embeddings.shape[1] != 1:
+                raise NotImplementedError('point_batch_size must be 1')
+            sparse = sparse_prompt_embeddings[:, 0]
+        else:
+            sparse = sparse_prompt_embeddings
+        d = nhwc_view(dense_prompt_embeddings)
+        if d.shape[0] != 1 and not bool((d[0, 0, 0] == d[-1, -1, -1]).all()):
+            raise NotImplementedError('per-pixel dense prompts go through decode_dense()')
+        dense_vec = d[0, 0, 0].contiguous()
+        roi_img = torch.arange(R, dtype=torch.int32, device=image_embeddings.device)
+        masks, iou = self.decode(image_embeddings, image_positional_embeddings, sparse.contiguous(), dense_vec,
+                                 roi_img)
+        return masks.unsqueeze(1), iou.unsqueeze(1), None
+
+
+@MODELS.register_module()
+class RSSamMaskDecoder(HIPModule):
+    def __init__(self, hf_pretrain_name, extra_config=None, init_cfg=None):
+        super().__init__()
+        self.mask_decoder = SamMaskDecoderHIP()
+
+    def forward(self, *args, **kwargs):
+        return self.mask_decoder(*args, **kwargs)
+
+
+class _PosEmb(HIPModule):
+    def __init__(self):
+        super().__init__()
+        add_param(self, 'positional_embedding', (2, 128))
+
+
+@MODELS.register_module()
+class RSSamPositionalEmbedding(HIPModule):
+    """models.py:744-759.  The image-wide table (models.py:85-95 + HF:552-566) depends only on the
+    [2,128] Gaussian matrix, so it is computed once per (size, weights) on the host at pack time
+    (constant preparation, exactly the reference's fp32 expression) and kept on the device."""
+
+    def __init__(self, hf_pretrain_name, extra_config=None, init_cfg=None):
+        super().__init__()
+        self.shared_image_embedding = _PosEmb()
+        self._cache = {}
+
+    def _apply(self, fn, *a, **kw):
+        self._cache = {}
+        return super()._apply(fn, *a, **kw)
+
+    def image_wide(self, size):
+        G = self.shared_image_embedding.positional_embedding
+        key = (size, G.data_ptr(), G._version)
+        if key not in self._cache:
+            g = G.detach().float().cpu()
+            grid = torch.ones((size, size), dtype=torch.float32)
+            y = (grid.cumsum(dim=0) - 0.5) / size
+            x = (grid.cumsum(dim=1) - 0.5) / size
+            c = torch.stack([x, y], dim=-1)
+            c = 2 * c - 1
+            c = c @ g
+            c = 2 * np.pi * c
+            pe = torch.cat([torch.sin(c), torch.cos(c)], dim=-1)          # [size, size, 256] == NHWC
+            self._cache = {key: nchw_view(pe.unsqueeze(0).contiguous().to(G.device))}
+        return self._cache[key]
+
+    def forward(self, input_coords, input_shape=None):
+        raise NotImplementedError('only the image-wide table is on the RSPrompter path (models.py:85-95)')
+
+
+class _PromptEncoder(HIPModule):
+    def __init__(self):
+        super().__init__()
+        add_param(self, 'no_mask_embed.weight', (1, HID))
+        # SamMaskEmbedding (HF:569-593), used by the query variant's sam_mask_embed (models.py:305)
+        add_param(self, 'mask_embed.conv1.weight', (4, 1, 2, 2))
+        add_param(self, 'mask_embed.conv1.bias', (4,))
+        add_param(self, 'mask_embed.conv2.weight', (16, 4, 2, 2))
+        add_param(self, 'mask_embed.conv2.bias', (16,))
+        add_param(self, 'mask_embed.conv3.weight', (HID, 16, 1, 1))
+        add_param(self, 'mask_embed.conv3.bias', (HID,))
+        _add_ln(self, 'mask_embed.layer_norm1', 4)
+        _add_ln(self, 'mask_embed.layer_norm2', 16)
+
+
+@MODELS.register_module()
+class RSSamPromptEncoder(HIPModule):
+    """models.py:881-896; only `no_mask_embed` / `mask_embed` are used downstream (:1635, :305)."""
+
+    def __init__(self, hf_pretrain_name, extra_config=None, init_cfg=None):
+        super().__init__()
+        self.prompt_encoder = _PromptEncoder()
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError('RSPrompter only borrows no_mask_embed / mask_embed from the prompt encoder')

@@ -1,0 +1,53 @@
+"""CPU: the reference's own config files build, unchanged, through our registry/config loader
+(only where /root/reference is present, i.e. in the build container)."""
+import os
+import warnings
+
+import pytest
+
+REF = '/root/reference/configs/rsprompter'
+
+
+def _norm(x):
+    if isinstance(x, dict):
+        return {k: _norm(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple, range)):
+        return [_norm(v) for v in x]
+    return x
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
+@pytest.mark.parametrize('fname,arch,nc,ps', [('rsprompter_anchor-nwpu.py', 'base', 10, (70, 5)),
+                                              ('rsprompter_anchor-ssdd.py', 'base', 1, (30, 5)),
+                                              ('rsprompter_anchor-whu.py', 'base', 1, (100, 5))])
+def test_reference_anchor_configs_build(fname, arch, nc, ps):
+    import rsprompter_amd as ra
+    from rsprompter_amd.default_configs import rsprompter_anchor
+    cfg = ra.Config.fromfile(os.path.join(REF, fname))
+    ours = rsprompter_anchor(arch, nc, ps)
+    assert _norm(cfg.model) == _norm(ours)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = ra.build_model(cfg)
+    assert type(m).__name__ == 'RSPrompterAnchor'
+    assert m.roi_head.bbox_head.num_classes == nc
+    # parameters follow the reference state_dict layout
+    keys = set(m.state_dict())
+    for k in ['backbone.vision_encoder.layers.0.attn.qkv.weight',
+              'shared_image_embedding.shared_image_embedding.positional_embedding',
+              'neck.feature_aggregator.downconvs.0.0.weight', 'neck.feature_spliter.fpn1.0.weight',
+              'neck.feature_spliter.lateral_convs.0.norm_layer.weight', 'rpn_head.rpn_conv.weight',
+              'roi_head.bbox_head.shared_fcs.0.weight', 'roi_head.mask_head.no_mask_embed.weight',
+              'roi_head.mask_head.mask_decoder.mask_decoder.transformer.layers.0.self_attn.q_proj.weight',
+              'roi_head.mask_head.point_emb.8.weight']:
+        assert k in keys, k
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
+def test_config_loader_base_and_delete():
+    import rsprompter_amd as ra
+    cfg = ra.Config.fromfile(os.path.join(REF, 'rsprompter_anchor-nwpu-peft-512.py'))
+    assert cfg.model.backbone.type == 'MMPretrainSamVisionEncoder'      # `_delete_=True` replaced the base dict
+    assert 'extra_config' not in cfg.model.backbone
+    assert cfg.model.neck.feature_aggregator.type == 'PseudoFeatureAggregator'
+    assert cfg.model.rpn_head.anchor_generator.strides == [4, 8, 16, 32, 64]   # inherited from _base_

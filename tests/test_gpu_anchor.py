@@ -1,0 +1,197 @@
+"""-m gpu: RSPrompterAnchor (HIP) against the CPU oracle, stage by stage and end to end,
+on identical seeded weights and inputs (ViT-B, 2 x 1024^2 synthetic tiles).
+
+Float stages are compared with an absolute tolerance (the north-star bound is 1e-3 on mask
+logits); index-producing stages are fed the ORACLE's tensors so that their outputs must be
+bit-exact (proposal anchor indices, level ids, detection labels and candidate indices).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+B = 2
+MEAN = [123.675, 116.28, 103.53]
+STD = [58.395, 57.12, 57.375]
+
+
+def _cl(x, dev):
+    """oracle NCHW tensor -> device tensor with channels-last strides (what our modules exchange)."""
+    return x.to(dev).contiguous(memory_format=torch.channels_last)
+
+
+@pytest.fixture(scope='module')
+def setup(dev):
+    import rsprompter_amd as ra
+    from oracle import glue
+    from oracle.anchor import AnchorOracle
+    from rsprompter_amd.default_configs import rsprompter_anchor
+    from rsprompter_amd.synth import synth_images, synth_metas, synth_state_dict
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = ra.build_model(rsprompter_anchor('base', 10))
+    oracle = AnchorOracle('base', 10)
+    sd = synth_state_dict(oracle, seed=0)
+    oracle.load_state_dict(sd)
+    missing = model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    model = model.to(dev)
+    imgs = synth_images(B)
+    metas = synth_metas(B)
+    x = glue.data_preprocess(imgs, MEAN, STD, True, 32)
+    results, trace = oracle.predict(x, metas)
+    return dict(model=model, oracle=oracle, imgs=imgs, metas=metas, x=x, results=results, trace=trace)
+
+
+def _maxerr(a, b):
+    return float((a.detach().float().cpu() - b.detach().float().cpu()).abs().max())
+
+
+def test_preprocess_and_extract_feat(setup, dev):
+    m, tr = setup['model'], setup['trace']
+    from rsprompter_amd.structures import DetDataSample
+    samples = [DetDataSample(metainfo=dict(mm)) for mm in setup['metas']]
+    data = m.data_preprocessor(dict(inputs=[i.to(dev) for i in setup['imgs']], data_samples=samples))
+    assert _maxerr(data['inputs'], setup['x']) < 1e-5
+    assert data['data_samples'][0].metainfo['batch_input_shape'] == (1024, 1024)
+    feats, emb, ipe = m.extract_feat(data['inputs'])
+    e = dict(emb=_maxerr(emb, tr['image_embeddings']), ipe=_maxerr(ipe, tr['image_pe']))
+    for i, (a, b) in enumerate(zip(feats, tr['fpn'])):
+        assert a.shape == b.shape
+        e[f'fpn{i}'] = _maxerr(a, b)
+    print('extract_feat max abs err:', {k: '%.2e' % v for k, v in e.items()})
+    assert max(e.values()) < 1e-3
+    setup['hip_feats'] = (feats, emb, ipe)
+
+
+def test_neck_given_oracle_hidden_states(setup, dev):
+    m, tr = setup['model'], setup['trace']
+    hs = tuple(h.to(dev).contiguous() for h in tr['hidden_states'])
+    agg = m.neck.feature_aggregator(hs)
+    assert _maxerr(agg, tr['aggregated']) < 2e-4 * max(1.0, float(tr['aggregated'].abs().max()))
+    outs = m.neck.feature_spliter(_cl(tr['aggregated'], dev))
+    for a, b in zip(outs, tr['fpn']):
+        assert _maxerr(a, b) < 2e-4
+
+
+def test_rpn_head_and_selection(setup, dev):
+    m, tr = setup['model'], setup['trace']
+    feats = [_cl(f, dev) for f in tr['fpn']]
+    cls, reg = m.rpn_head(feats)
+    for a, b in zip(cls, tr['cls']):
+        assert _maxerr(a, b) < 2e-4
+    for a, b in zip(reg, tr['reg']):
+        assert _maxerr(a, b) < 2e-4
+    # --- selection on the oracle's own head outputs: indices must be bit-exact ---
+    A, LD = 6, m.rpn_head.LD
+    heads, sizes = [], []
+    for c, r in zip(tr['cls'], tr['reg']):
+        Bn, _, H, W = c.shape
+        h = torch.zeros((Bn, H, W, LD))
+        h[..., :A] = c.permute(0, 2, 3, 1)
+        h[..., A:5 * A] = r.permute(0, 2, 3, 1)
+        heads.append(h.reshape(Bn * H * W, LD).to(dev).contiguous())
+        sizes.append((H, W))
+    out = m.rpn_head.select(heads, sizes, setup['metas'])
+    props = m.rpn_head._to_instances(out)
+    for b in range(B):
+        ref = tr['proposals'][b]
+        got = props[b]
+        n = ref['bboxes'].shape[0]
+        assert got.bboxes.shape[0] == n
+        same = (got.anchor_index.cpu().long() == ref['anchor_index']) & (got.level_ids.cpu().long() == ref['level_ids'])
+        print(f'img {b}: {n} proposals, index mismatches: {int((~same).sum())}')
+        assert bool(same.all()), 'proposal (level, anchor) indices must be bit-exact'
+        assert _maxerr(got.bboxes, ref['bboxes']) < 1e-3
+        assert _maxerr(got.scores, ref['scores']) < 1e-6
+
+
+def test_bbox_head_and_detection_selection(setup, dev):
+    from rsprompter_amd import ops
+    from rsprompter_amd.structures import InstanceData
+    m, tr = setup['model'], setup['trace']
+    feats = [_cl(f, dev) for f in tr['fpn']]
+    pes = m.roi_head.extra_pe_tables(feats)
+    for t, ref in zip(pes, tr['x_pe']):
+        pass
+    rois = tr['rois'].to(dev)
+    rf = m.roi_head.bbox_roi_extractor(feats[:4], rois, pes=pes[:4])
+    assert _maxerr(rf, tr['roi_feats']) < 2e-4
+    cls, reg = m.roi_head.bbox_head(_cl(tr['roi_feats'], dev))
+    assert _maxerr(cls, tr['cls_score']) < 2e-4 and _maxerr(reg, tr['bbox_pred']) < 2e-4
+    # --- detection selection on the oracle's logits: labels / candidate indices bit-exact ---
+    nc, LD = 10, m.roi_head.bbox_head.LD
+    head = torch.zeros((rois.shape[0], LD))
+    head[:, :nc + 1] = tr['cls_score']
+    head[:, nc + 1:5 * nc + 1] = tr['bbox_pred']
+    counts = [p['bboxes'].shape[0] for p in tr['proposals']]
+    roi_start = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int64)
+    from rsprompter_amd.anchor_heads import _img_hw
+    out = ops.bbox_post(head.to(dev), LD, rois, roi_start, _img_hw(setup['metas'], dev), nc, 0.05,
+                        (0.1, 0.1, 0.2, 0.2), m.roi_head.bbox_head.bbox_coder.max_ratio, 0.5, 100)
+    kept = out['count'].tolist()
+    for b in range(B):
+        ref = tr['dets'][b]
+        k = ref['labels'].shape[0]
+        assert kept[b] == k
+        assert torch.equal(out['ids'][b, :k].cpu().long(), ref['labels'])
+        assert torch.equal(out['src'][b, :k].cpu().long(), ref['cand'])
+        assert _maxerr(out['boxes'][b, :k], ref['bboxes']) < 1e-3
+        assert _maxerr(out['scores'][b, :k], ref['scores']) < 1e-6
+
+
+def test_mask_head_given_oracle_detections(setup, dev):
+    from rsprompter_amd.structures import InstanceData
+    m, tr = setup['model'], setup['trace']
+    feats = [_cl(f, dev) for f in tr['fpn']]
+    pes = m.roi_head.extra_pe_tables(feats)
+    emb = _cl(tr['image_embeddings'], dev)
+    ipe = _cl(tr['image_pe'], dev)
+    mrois = tr['mask_rois'].to(dev)
+    mf = m.roi_head.mask_roi_extractor(feats[:4], mrois, pes=pes[:4])
+    assert _maxerr(mf, tr['mask_feats']) < 2e-4
+    sparse = m.roi_head.mask_head.point_embeddings(_cl(tr['mask_feats'], dev))
+    e_sp = _maxerr(sparse, tr['sparse_embeddings'][:, 0])
+    low, iou = m.roi_head.mask_head(_cl(tr['mask_feats'], dev), emb, ipe, mrois[:, 0])
+    e_low = _maxerr(low, tr['low_res_masks'])
+    e_iou = _maxerr(iou, tr['iou_predictions'])
+    print('sparse err %.2e, low_res_masks err %.2e (range %.2f), iou err %.2e' %
+          (e_sp, e_low, float(tr['low_res_masks'].abs().max()), e_iou))
+    assert e_sp < 2e-4 and e_low < 1e-3 and e_iou < 1e-3
+    # post-processing on the oracle's logits
+    start = 0
+    for b in range(B):
+        d = tr['dets'][b]
+        k = d['bboxes'].shape[0]
+        res = InstanceData(bboxes=d['bboxes'].to(dev).clone(), scores=d['scores'].to(dev), labels=d['labels'].to(dev))
+        masks, prob = m.roi_head.mask_head._predict_by_feat_single(
+            tr['low_res_masks'][start:start + k].to(dev), res, setup['metas'][b], dict(mask_thr_binary=0.5),
+            rescale=True, want_prob=True)
+        start += k
+        ref = setup['results'][b]['masks']
+        assert _maxerr(prob, tr['mask_probs'][b]) < 1e-5
+        mism = float((masks.cpu() != ref).float().mean())
+        print(f'img {b}: mask pixel mismatch fraction {mism:.2e}')
+        assert mism < 1e-5
+
+
+def test_end_to_end_predict(setup, dev):
+    from rsprompter_amd.structures import DetDataSample
+    m = setup['model']
+    samples = [DetDataSample(metainfo=dict(mm)) for mm in setup['metas']]
+    out = m.test_step(dict(inputs=[i.to(dev) for i in setup['imgs']], data_samples=samples))
+    for b in range(B):
+        pi = out[b].pred_instances
+        ref = setup['results'][b]
+        k = ref['labels'].shape[0]
+        assert pi.masks.dtype == torch.bool and tuple(pi.masks.shape[1:]) == (1024, 1024)
+        n_same = min(k, pi.labels.shape[0])
+        lab_eq = float((pi.labels[:n_same].cpu() == ref['labels'][:n_same]).float().mean())
+        box_err = _maxerr(pi.bboxes[:n_same], ref['bboxes'][:n_same])
+        sc_err = _maxerr(pi.scores[:n_same], ref['scores'][:n_same])
+        mism = float((pi.masks[:n_same].cpu() != ref['masks'][:n_same]).float().mean())
+        print(f'e2e img {b}: dets {pi.labels.shape[0]}/{k}, label agreement {lab_eq:.3f}, box err {box_err:.2e}, '
+              f'score err {sc_err:.2e}, mask mismatch {mism:.2e}')
+        assert pi.labels.shape[0] == k
+        assert lab_eq == 1.0 and sc_err < 1e-4 and box_err < 1e-2 and mism < 1e-3

@@ -163,3 +163,193 @@ def test_patchify_preprocess(dev):
     p = ops.patchify(x.to(dev), 16).cpu()
     ref = F.unfold(x, 16, stride=16).transpose(1, 2).reshape(-1, 768)
     assert torch.equal(p, ref)
+
+
+def test_conv_transpose_pool_add_sincos(dev):
+    from rsprompter_amd import ops
+    from rsprompter_amd.necks import convt_weights
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 64, 6, 10, generator=g)
+    w = torch.randn(64, 32, 2, 2, generator=g) * 0.1
+    b = torch.randn(32, generator=g)
+    ref = F.conv_transpose2d(x.double(), w.double(), b.double(), stride=2)
+    packed, bias2 = convt_weights(w.to(dev), b.to(dev))
+    got = ops.conv_transpose2x2(x.permute(0, 2, 3, 1).contiguous().to(dev), packed, bias2)
+    assert _rel_err(got.permute(0, 3, 1, 2), ref) < 2e-6
+    got = ops.conv_transpose2x2(x.permute(0, 2, 3, 1).contiguous().to(dev), packed, bias2, act=ops.ACT_GELU)
+    assert _rel_err(got.permute(0, 3, 1, 2), F.gelu(ref)) < 2e-6
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    assert torch.equal(ops.pool2(xh, 0).permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 2, 2))
+    assert torch.equal(ops.pool2(xh, 1).permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 1, stride=2))
+    v = torch.randn(5, 64, generator=g)
+    a = torch.randn(20, 64, generator=g)
+    assert torch.equal(ops.add_rows(a.to(dev), v.to(dev)).cpu(), a + v[torch.arange(20) % 5])
+    s = torch.randn(7, 5, 512, generator=g)
+    ref = torch.sin(s[..., ::2]) + s[..., 1::2]
+    assert float((ops.sincos_pairs(s.to(dev)).cpu() - ref).abs().max()) < 1e-6
+    sf = (2.0, 1.5, 2.0, 1.5)
+    bx = torch.rand(9, 4, generator=g) * 100
+    assert torch.equal(ops.div_boxes(bx.to(dev), sf).cpu(), bx / torch.tensor(sf))
+
+
+@pytest.mark.parametrize('dh,Tq,Tk,nh', [(16, 10, 4096, 8), (16, 4096, 10, 8), (32, 10, 10, 8), (64, 70, 130, 2)])
+def test_generic_attention_with_batch_maps(dev, dh, Tq, Tk, nh):
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(8)
+    R, Bk = 5, 2
+    D = nh * dh
+    q = torch.randn(R, Tq, D, generator=g)
+    k = torch.randn(Bk, Tk, D, generator=g)
+    v = torch.randn(Bk, Tk, D, generator=g)
+    kvmap = torch.tensor([0, 0, 1, 1, 1], dtype=torch.int32)
+    scale = dh ** -0.5
+    qh = q.double().view(R, Tq, nh, dh).transpose(1, 2)
+    kh = k.double()[kvmap.long()].view(R, Tk, nh, dh).transpose(1, 2)
+    vh = v.double()[kvmap.long()].view(R, Tk, nh, dh).transpose(1, 2)
+    ref = ((qh * scale) @ kh.transpose(-1, -2)).softmax(-1) @ vh
+    ref = ref.transpose(1, 2).reshape(R, Tq, D)
+    out = torch.empty(R, Tq, D, device=dev)
+    ops.attention(q.to(dev), k.to(dev), v.to(dev), out, B=R, nh=nh, dh=dh, Tq=Tq, Tk=Tk, scale=scale,
+                  q_strides=(Tq * D, D, dh), k_strides=(Tk * D, D, dh), v_strides=(Tk * D, D, dh),
+                  o_strides=(Tq * D, D, dh), kv_batch_map=kvmap.to(dev))
+    assert float((out.cpu().double() - ref).abs().max()) < 2e-5
+    # q_batch_map: queries shared per image, keys per RoI
+    q2 = torch.randn(Bk, Tq, D, generator=g)
+    k2 = torch.randn(R, Tk, D, generator=g)
+    v2 = torch.randn(R, Tk, D, generator=g)
+    qh = q2.double()[kvmap.long()].view(R, Tq, nh, dh).transpose(1, 2)
+    kh = k2.double().view(R, Tk, nh, dh).transpose(1, 2)
+    vh = v2.double().view(R, Tk, nh, dh).transpose(1, 2)
+    ref = (((qh * scale) @ kh.transpose(-1, -2)).softmax(-1) @ vh).transpose(1, 2).reshape(R, Tq, D)
+    ops.attention(q2.to(dev), k2.to(dev), v2.to(dev), out, B=R, nh=nh, dh=dh, Tq=Tq, Tk=Tk, scale=scale,
+                  q_strides=(Tq * D, D, dh), k_strides=(Tk * D, D, dh), v_strides=(Tk * D, D, dh),
+                  o_strides=(Tq * D, D, dh), q_batch_map=kvmap.to(dev))
+    assert float((out.cpu().double() - ref).abs().max()) < 2e-5
+
+
+def test_roi_align_matches_oracle(dev):
+    from oracle import cops, glue
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(9)
+    strides = [4, 8, 16, 32]
+    feats = [torch.randn(2, 256, 256 // s * 4, 256 // s * 4, generator=g) for s in strides]  # 1024-px image
+    pes = [torch.randn(f.shape[2], f.shape[3], 256, generator=g) for f in feats]
+    K = 300
+    xy = torch.rand(K, 2, generator=g) * 900
+    wh = torch.exp(torch.rand(K, 2, generator=g) * 6.5)          # 1 .. 665 px, spans all 4 levels
+    rois = torch.cat([torch.randint(0, 2, (K, 1), generator=g).float(), xy, xy + wh], 1)
+    rois[0, 1:] = torch.tensor([-50., -20., 30., 10.])           # partly outside
+    rois[1, 1:] = torch.tensor([10., 10., 10., 10.])             # degenerate
+    rois[2, 1:] = torch.tensor([1000., 1000., 1100., 1090.])     # beyond the border
+    for P in (7, 14):
+        ref = glue.roi_extract([f + pe.permute(2, 0, 1)[None] for f, pe in zip(feats, pes)], rois, P, strides)
+        got = ops.roi_align([f.permute(0, 2, 3, 1).contiguous().to(dev) for f in feats],
+                            [p.to(dev) for p in pes], rois.to(dev), P, strides)
+        err = float((got.permute(0, 3, 1, 2).cpu() - ref).abs().max())
+        assert err < 1e-4, err
+    assert ops.roi_align([f.permute(0, 2, 3, 1).contiguous().to(dev) for f in feats], None,
+                         torch.zeros((0, 5), device=dev), 7, strides).shape == (0, 7, 7, 256)
+
+
+def _rand_boxes(n, g, size=1024.):
+    xy = torch.rand(n, 2, generator=g) * size * 0.8
+    wh = torch.rand(n, 2, generator=g) * size * 0.3 + 1
+    return torch.cat([xy, (xy + wh).clamp(max=size)], 1)
+
+
+@pytest.mark.parametrize('n,nid,thr,max_out', [(5000, 5, 0.7, 1000), (10000, 10, 0.5, 100), (37, 1, 0.5, 100),
+                                                (0, 1, 0.5, 10)])
+def test_batched_nms_matches_oracle(dev, n, nid, thr, max_out):
+    from oracle import glue
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(10 + n)
+    Bn, cap = 2, max(n, 1)
+    boxes = torch.zeros(Bn, cap, 4)
+    scores = torch.zeros(Bn, cap)
+    ids = torch.zeros(Bn, cap, dtype=torch.int32)
+    cnt = torch.tensor([n, max(n - 3, 0)], dtype=torch.int32)
+    for b in range(Bn):
+        boxes[b] = _rand_boxes(cap, g)
+        scores[b] = (torch.rand(cap, generator=g) * 50).round() / 50        # many exact ties
+        ids[b] = torch.randint(0, nid, (cap,), generator=g, dtype=torch.int32)
+    cand = (boxes.to(dev), scores.to(dev), ids.to(dev), torch.arange(cap, dtype=torch.int32).repeat(Bn, 1).to(dev),
+            cnt.to(dev))
+    out = ops.batched_nms(cand, Bn, cap, thr, max_out)
+    for b in range(Bn):
+        m = int(cnt[b])
+        dets, keep = glue.batched_nms(boxes[b, :m], scores[b, :m], ids[b, :m].long(), thr)
+        keep = keep[:max_out]
+        k = int(out['count'][b])
+        assert k == keep.numel()
+        assert torch.equal(out['keep'][b, :k].cpu().long(), keep)
+        assert torch.equal(out['boxes'][b, :k].cpu(), boxes[b, :m][keep])
+
+
+def test_rpn_topk_ties_and_small_levels(dev):
+    """rpn_head.py:198-212: stable descending sort, top nms_pre; levels with n <= nms_pre keep natural order."""
+    from rsprompter_amd import _lib, ops
+    import ctypes
+    g = torch.Generator().manual_seed(11)
+    Bn, A, LD, k = 2, 6, 32, 1000
+    sizes = [(64, 64), (16, 16), (8, 8), (4, 4)]
+    heads = []
+    for li, (H, W) in enumerate(sizes):
+        h = torch.randn(Bn * H * W, LD, generator=g)
+        if li == 0:
+            h[:, :A] = (h[:, :A] * 4).round() / 4          # heavy ties
+        if li == 1:
+            h[:, :A] = 0.25                                 # constant input: pure index order
+        heads.append(h)
+    lib = _lib.load()
+    d = _lib.RspRpnDesc()
+    dheads = [h.to(dev) for h in heads]
+    for i, (hd, (H, W)) in enumerate(zip(dheads, sizes)):
+        d.head[i] = hd.data_ptr(); d.H[i], d.W[i], d.stride[i] = H, W, 4.0 * 2 ** i
+    d.ld, d.A, d.nms_pre, d.num_levels = LD, A, k, len(sizes)
+    L = len(sizes)
+    sel_idx = torch.full((Bn, L, k), -7, dtype=torch.int32, device=dev)
+    sel_score = torch.zeros((Bn, L, k), device=dev)
+    sel_cnt = torch.zeros((Bn, L), dtype=torch.int32, device=dev)
+    _lib.check(lib.rsp_rpn_topk(d, Bn, sel_idx.data_ptr(), sel_score.data_ptr(), sel_cnt.data_ptr(),
+                                torch.cuda.current_stream().cuda_stream), 'topk')
+    for b in range(Bn):
+        for li, (H, W) in enumerate(sizes):
+            n = H * W * A
+            logits = heads[li].view(Bn, H * W, LD)[b, :, :A].reshape(-1)
+            sc = logits.sigmoid()
+            cnt = int(sel_cnt[b, li])
+            if n > k:
+                ranked, inds = sc.sort(descending=True, stable=True)
+                assert cnt == k
+                assert torch.equal(sel_idx[b, li, :k].cpu().long(), inds[:k]), (b, li)
+                assert float((sel_score[b, li, :k].cpu() - ranked[:k]).abs().max()) < 1e-6
+            else:
+                assert cnt == n
+                assert torch.equal(sel_idx[b, li, :n].cpu().long(), torch.arange(n))
+
+
+def test_mask_post_matches_reference_formula(dev):
+    from oracle import glue
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(12)
+    low = torch.randn(3, 1, 256, 256, generator=g) * 3
+    for meta in (dict(ori_shape=(1024, 1024), scale_factor=(1.0, 1.0), batch_input_shape=(1024, 1024)),
+                 dict(ori_shape=(512, 512), scale_factor=(2.0, 2.0), batch_input_shape=(1024, 1024)),
+                 dict(ori_shape=(600, 400), scale_factor=(1.5, 1.5), batch_input_shape=(1024, 1024))):
+        boxes = torch.rand(3, 4, generator=g) * 100
+        ref_mask, _, ref_prob = glue.mask_postprocess_single(low, boxes.clone(), meta, 0.5, True)
+        sf_w, sf_h = meta['scale_factor']
+        h, w = meta['ori_shape']
+        crop = (min(int(h * sf_h), 1024), min(int(w * sf_w), 1024))
+        got, prob = ops.mask_post(low[:, 0].contiguous().to(dev), (1024, 1024), crop, (h, w), 0.5, want_prob=True)
+        assert float((prob.cpu() - ref_prob).abs().max()) < 2e-6
+        assert float((got.cpu() != ref_mask).float().mean()) < 1e-5
+
+
+def test_hyper_mask(dev):
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(13)
+    up = torch.randn(3, 1000, 32, generator=g)
+    hy = torch.randn(3, 32, generator=g)
+    ref = torch.einsum('rpc,rc->rp', up.double(), hy.double())
+    assert float((ops.hyper_mask(up.to(dev), hy.to(dev)).cpu().double() - ref).abs().max()) < 1e-4
