@@ -11,6 +11,12 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
 DEFAULT_A_SCALE_LOG2 = 6
 
 
+def require_device(dev):
+    if torch.device(dev).type != 'cuda':
+        raise RuntimeError('rsprompter_amd runs on the HIP device only (there is no CPU fallback); '
+                           'move the model with .to("cuda")')
+
+
 def _stream():
     return torch.cuda.current_stream().cuda_stream
 

@@ -91,9 +91,7 @@ class SamVisionEncoderHIP(HIPModule):
     # ------------------------------------------------------------------ packing
     def _pack(self):
         dev = self.pos_embed.device
-        if dev.type != 'cuda':
-            raise RuntimeError('SamVisionEncoderHIP runs on the HIP device only (no CPU fallback); '
-                               'move the model with .to("cuda")')
+        ops.require_device(dev)
         P = {}
         w = self.patch_embed.projection.weight
         P['patch'] = ops.PackedWeight(w.reshape(w.shape[0], -1), self.patch_embed.projection.bias)

@@ -39,9 +39,9 @@ def synth_tensor(name, ref, seed=0):
         return torch.randn(shape, generator=g) * 0.05
     if leaf == 'weight' and len(shape) == 1:      # LayerNorm / BatchNorm / LN2d scale
         return 1.0 + torch.randn(shape, generator=g) * 0.02
-    if 'token' in name or 'no_mask_embed' in name or 'query_embed' in name or 'query_feat' in name \
-            or 'level_embed' in name:
-        return torch.randn(shape, generator=g) * 0.5
+    parent = name.split('.')[-2] if '.' in name else ''
+    if parent in ('iou_token', 'mask_tokens', 'no_mask_embed', 'query_embed', 'query_feat', 'level_embed'):
+        return torch.randn(shape, generator=g) * 0.5      # nn.Embedding tables
     if len(shape) >= 2:                            # Linear / Conv / ConvTranspose
         if 'upscale_conv' in name or '.fpn1.' in name or '.fpn2.' in name:
             fan_in = shape[0]                      # ConvTranspose2d weight is [Cin, Cout, k, k]

@@ -1,0 +1,127 @@
+"""CPU (`-m "not gpu"`): the HOST side of every facade module -- weight packing / BN folding /
+weight permutations / row maps / decoder wiring -- checked against the oracle by swapping
+`rsprompter_amd.ops` for a plain-torch stand-in (tests/torch_ops_mock.py, test-only).
+The HIP kernels themselves are checked in the `-m gpu` suite.
+"""
+import sys
+import os
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch_ops_mock as mock  # noqa: E402
+
+
+@pytest.fixture()
+def mocked(monkeypatch):
+    import rsprompter_amd.anchor_heads as ah
+    import rsprompter_amd.necks as necks
+    import rsprompter_amd.sam_decoder as sd
+    import rsprompter_amd.sam_encoder as se
+    for m in (ah, necks, sd, se):
+        monkeypatch.setattr(m, 'ops', mock)
+    return mock
+
+
+def _err(a, b):
+    return float((a.float() - b.float()).abs().max())
+
+
+def test_decoder_wiring_matches_hf(mocked):
+    from oracle import hf_sam
+    from rsprompter_amd.sam_decoder import SamMaskDecoderHIP
+    from rsprompter_amd.synth import synth_state_dict
+    dec = SamMaskDecoderHIP()
+    w = synth_state_dict(dec, 0)
+    dec.load_state_dict(w)
+    ref = hf_sam.build_mask_decoder()
+    ref.load_state_dict(w, strict=True)
+    g = torch.Generator().manual_seed(0)
+    B, R, h = 2, 5, 16
+    emb = torch.randn(B, 256, h, h, generator=g)
+    pe = torch.randn(1, 256, h, h, generator=g)
+    sparse = torch.randn(R, 5, 256, generator=g)
+    dense = torch.randn(256, generator=g)
+    roi = torch.tensor([0, 0, 1, 1, 1], dtype=torch.int32)
+    masks, iou = dec.decode(emb, pe, sparse, dense, roi)
+    with torch.no_grad():
+        rm, ri = ref(image_embeddings=emb[roi.long()], image_positional_embeddings=pe.expand(R, -1, -1, -1),
+                     sparse_prompt_embeddings=sparse.unsqueeze(1),
+                     dense_prompt_embeddings=dense.view(1, -1, 1, 1).expand(R, -1, h, h), multimask_output=False)
+    assert _err(masks, rm[:, 0]) < 5e-5 and _err(iou, ri[:, 0]) < 5e-5
+    # HF-signature forward (per-RoI repeated inputs)
+    m2, i2, _ = dec(emb[roi.long()], pe.expand(R, -1, -1, -1), sparse.unsqueeze(1),
+                    dense.view(1, -1, 1, 1).expand(R, -1, h, h), multimask_output=False)
+    assert _err(m2, rm) < 5e-5 and _err(i2, ri) < 5e-5
+
+
+def test_neck_and_heads_packing_matches_oracle(mocked):
+    import rsprompter_amd as ra
+    from oracle.anchor import AnchorOracle
+    from rsprompter_amd.default_configs import rsprompter_anchor
+    from rsprompter_amd.synth import synth_state_dict
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = ra.build_model(rsprompter_anchor('base', 10))
+    oracle = AnchorOracle('base', 10)
+    sd = synth_state_dict(oracle, 0)
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(1)
+    hs = tuple(torch.randn(1, 16, 16, 768, generator=g) for _ in range(13))
+    with torch.no_grad():
+        agg_ref = oracle.neck.feature_aggregator(hs)
+        fpn_ref = oracle.neck.feature_spliter(agg_ref)
+        cls_ref, reg_ref = oracle.rpn_head(fpn_ref)
+    agg = model.neck.feature_aggregator(hs)
+    assert _err(agg, agg_ref) < 1e-4 * max(1.0, float(agg_ref.abs().max()))
+    fpn = model.neck.feature_spliter(agg_ref.contiguous(memory_format=torch.channels_last))
+    for a, b in zip(fpn, fpn_ref):
+        assert a.shape == b.shape and _err(a, b) < 1e-4
+    cls, reg = model.rpn_head([f.contiguous(memory_format=torch.channels_last) for f in fpn_ref])
+    for a, b in zip(cls + reg, cls_ref + reg_ref):
+        assert a.shape == b.shape and _err(a, b) < 1e-4
+    rf = torch.randn(6, 256, 7, 7, generator=g)
+    with torch.no_grad():
+        c_ref, r_ref = oracle.roi_head.bbox_head(rf)
+    c, r = model.roi_head.bbox_head(rf.contiguous(memory_format=torch.channels_last))
+    assert _err(c, c_ref) < 1e-4 and _err(r, r_ref) < 1e-4
+    mf = torch.randn(4, 256, 14, 14, generator=g)
+    mh = oracle.roi_head.mask_head
+    with torch.no_grad():
+        pe = mh.point_emb(mf)
+        pe = pe.view(4, 5, -1)
+        pe = torch.sin(pe[..., ::2]) + pe[..., 1::2]
+    got = model.roi_head.mask_head.point_embeddings(mf.contiguous(memory_format=torch.channels_last))
+    assert _err(got, pe) < 1e-4
+
+
+def test_encoder_window_maps_match_hf(mocked):
+    """one windowed + one global layer on a small ViT: window partition / unpartition row maps,
+    rel-pos tables, neck -- against HF (oracle) with identical weights."""
+    from oracle import hf_sam
+    from rsprompter_amd import sam_encoder as se
+    from rsprompter_amd.nnutil import SAM_ARCH
+    from rsprompter_amd.synth import synth_state_dict
+    SAM_ARCH['tiny-test'] = dict(hidden=128, depth=2, heads=2, global_idx=(1,), mlp=256)
+    try:
+        enc = se.SamVisionEncoderHIP('tiny-test', image_size=320, output_hidden_states=True)
+        sd = synth_state_dict(enc, 3)
+        enc.load_state_dict(sd)
+        from transformers.models.sam.configuration_sam import SamVisionConfig
+        from transformers.models.sam import modeling_sam as hf
+        cfg = SamVisionConfig(hidden_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=320,
+                              global_attn_indexes=[1], mlp_dim=256)
+        cfg._attn_implementation = 'eager'
+        ref = hf.SamVisionEncoder(cfg).eval()
+        ref.load_state_dict(sd, strict=True)
+        x = torch.randn(2, 3, 320, 320, generator=torch.Generator().manual_seed(4))
+        emb_ref, hs_ref = hf_sam.run_vision_encoder(ref, x)
+        out = enc(x)
+        assert _err(out[0], emb_ref) < 1e-4
+        for a, b in zip(out[1], hs_ref):
+            assert _err(a, b) < 1e-4
+    finally:
+        SAM_ARCH.pop('tiny-test')

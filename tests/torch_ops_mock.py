@@ -1,0 +1,140 @@
+"""TEST-ONLY stand-in for `rsprompter_amd.ops` built from plain torch CPU ops.
+
+It lets the `-m "not gpu"` suite exercise the HOST orchestration (weight packing, row maps,
+BN folding, window partition maps, decoder wiring ...) against the oracle without a GPU.
+It is never imported by the package; the product path has no such fallback.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
+DEFAULT_A_SCALE_LOG2 = 6
+
+
+def require_device(dev):
+    pass
+
+
+def _act(x, act):
+    return {0: lambda t: t, 1: F.relu, 2: F.gelu, 3: torch.sigmoid}[act](x)
+
+
+class PackedWeight:
+    def __init__(self, w, bias=None, device=None):
+        self.w = w.detach().float()
+        self.N, self.K = self.w.shape
+        self.bias = None if bias is None else bias.detach().float()
+        self.scale_log2 = 0
+
+
+def gemm(a, w, *, out=None, bias='auto', res=None, act=0, a_rowmap=None, c_rowmap=None, M=None, out_rows=None,
+         res_mod=0, a_scale_log2=6, conv=None, res_bmap=None, res_brows=0):
+    if conv is not None:
+        k, s, p = conv
+        B, H, W, C = a.shape
+        wt = w.w.view(w.N, k, k, C).permute(0, 3, 1, 2)
+        y = F.conv2d(a.permute(0, 3, 1, 2), wt, None, stride=s, padding=p).permute(0, 2, 3, 1)
+        y = y.reshape(-1, w.N)
+    else:
+        src = a
+        if a_rowmap is not None:
+            idx = a_rowmap.long()
+            src = torch.where((idx >= 0)[:, None], a[idx.clamp(min=0)], torch.zeros(1))
+        y = src[:M] @ w.w.t() if M is not None else src @ w.w.t()
+    if bias == 'auto':
+        bias = w.bias
+    if bias is not None:
+        y = y + bias
+    y = _act(y, act)
+    m = y.shape[0]
+    rows = torch.arange(m)
+    crow = rows if c_rowmap is None else c_rowmap.long()
+    keep = crow >= 0
+    if out is None:
+        out = torch.zeros((m if out_rows is None else out_rows, w.N))
+    if res is not None:
+        rr = crow.clamp(min=0)
+        if res_mod > 0:
+            rr = rr % res_mod
+        if res_bmap is not None:
+            rr = res_bmap.long()[rr // res_brows] * res_brows + rr % res_brows
+        y = y + res[rr]
+    out[crow[keep]] = y[keep]
+    return out
+
+
+def layernorm(x, gamma, beta, eps=1e-6, act=0, out=None):
+    return _act(F.layer_norm(x, (x.shape[-1],), gamma, beta, eps), act)
+
+
+def vit_relpos(qkv, rph, rpw, Bp, S, nh, dh):
+    T = S * S
+    q = qkv.view(Bp, T, 3, nh, dh)[:, :, 0].permute(0, 2, 1, 3).reshape(Bp * nh, S, S, dh)
+    idx = torch.arange(S)[:, None] - torch.arange(S)[None, :] + (S - 1)
+    rh = torch.einsum('bhwc,hkc->bhwk', q, rph[idx])
+    rw = torch.einsum('bhwc,wkc->bhwk', q, rpw[idx])
+    return torch.cat([rh, rw], -1).reshape(Bp * nh, T, 2 * S)
+
+
+def vit_attention(qkv, rel, Bp, S, nh, dh, scale):
+    T = S * S
+    q, k, v = qkv.view(Bp, T, 3, nh, dh).permute(2, 0, 3, 1, 4).reshape(3, Bp * nh, T, dh).unbind(0)
+    attn = (q * scale) @ k.transpose(-2, -1)
+    bias = rel[..., :S].reshape(-1, T, S, 1) + rel[..., S:].reshape(-1, T, 1, S)
+    attn = (attn.view(-1, T, S, S) + bias).view(-1, T, T).softmax(-1)
+    return (attn @ v).view(Bp, nh, T, dh).permute(0, 2, 1, 3).reshape(Bp * T, nh * dh)
+
+
+def patchify(img, patch):
+    return F.unfold(img, patch, stride=patch).transpose(1, 2).reshape(-1, img.shape[1] * patch * patch)
+
+
+def conv_transpose2x2(x, w_dy, bias, act=0, a_scale_log2=6):
+    B, H, W, C = x.shape
+    cout = w_dy[0].N // 2
+    out = torch.zeros(B, 2 * H, 2 * W, cout)
+    for dy in (0, 1):
+        y = x.reshape(-1, C) @ w_dy[dy].w.t()
+        if bias is not None:
+            y = y + bias
+        y = _act(y, act).view(B, H, W, 2, cout)
+        out[:, dy::2] = y.reshape(B, H, 2 * W, cout)
+    return out
+
+
+def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v_strides, o_strides,
+              kv_batch_map=None, q_batch_map=None):
+    def view(t, st, T, bmap):
+        nb = t.numel() // st[0] if st[0] else 1
+        tt = torch.as_strided(t, (nb, T, nh, dh), (st[0], st[1], st[2], 1))
+        if bmap is not None:
+            tt = tt[bmap.long()]
+        return tt.permute(0, 2, 1, 3)
+    qq, kk, vv = view(q, q_strides, Tq, q_batch_map), view(k, k_strides, Tk, kv_batch_map), view(v, v_strides, Tk, kv_batch_map)
+    o = ((qq * scale) @ kk.transpose(-1, -2)).softmax(-1) @ vv
+    ov = torch.as_strided(out, (B, Tq, nh, dh), (o_strides[0], o_strides[1], o_strides[2], 1))
+    ov.copy_(o.permute(0, 2, 1, 3))
+    return out
+
+
+def add_rows(x, v, vmod=None, out=None):
+    C = x.shape[-1]
+    rows = x.numel() // C
+    vmod = v.numel() // C if vmod is None else vmod
+    return (x.reshape(rows, C) + v.reshape(-1, C)[torch.arange(rows) % vmod]).view(x.shape)
+
+
+def sincos_pairs(x):
+    return torch.sin(x[..., ::2]) + x[..., 1::2]
+
+
+def hyper_mask(up, hyper):
+    return torch.einsum('rpc,rc->rp', up, hyper)
+
+
+def pool2(x, mode):
+    y = x.permute(0, 3, 1, 2)
+    y = F.max_pool2d(y, 2, 2) if mode == 0 else F.max_pool2d(y, 1, stride=2)
+    return y.permute(0, 2, 3, 1).contiguous()
