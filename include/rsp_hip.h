@@ -222,6 +222,9 @@ int rsp_add_rows(const float* x, const float* v, float* y, int64_t rows, int32_t
 int rsp_sincos_pairs(const float* x, float* y, int64_t n_out, rsp_stream_t stream);
 /* out[i, j] = boxes[i, j] / sf4[j]   (bboxes /= scale_factor, models.py:1763-1764); sf4 is a HOST pointer */
 int rsp_div_boxes(const float* boxes, float* out, int64_t n, const float* sf4, rsp_stream_t stream);
+/* bool bytes -> bits (little-endian in a byte) : the payload of the multi-GPU result all-gather,  */
+/* replacing CocoMetric's per-rank RLE + mmengine collect_results (coco_metric.py:356-391).       */
+int rsp_pack_bits(const uint8_t* src, uint8_t* dst, int64_t n_bits, rsp_stream_t stream);
 /* dst[i,:] = src[idx[i],:] (idx<0 -> 0) */
 int rsp_gather_rows(const float* src, const int32_t* idx, float* dst, int64_t rows, int32_t C,
                     rsp_stream_t stream);

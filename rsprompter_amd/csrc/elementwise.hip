@@ -224,3 +224,28 @@ extern "C" int rsp_div_boxes(const float* boxes, float* out, int64_t n, const fl
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
+
+namespace {
+// bool bytes -> bits, little-endian within a byte (== numpy.packbits(bitorder='little'))
+__global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t* __restrict__ src,
+                                                        uint8_t* __restrict__ dst, int64_t nbytes_out) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nbytes_out;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned long long x = *reinterpret_cast<const unsigned long long*>(src + i * 8);
+    unsigned int o = 0;
+#pragma unroll
+    for (int b = 0; b < 8; ++b) o |= (unsigned int)(((x >> (8 * b)) & 0xffull) != 0ull) << b;
+    dst[i] = (uint8_t)o;
+  }
+}
+}  // namespace
+
+/* instance masks bool[k,H,W] -> bit-packed u8[k*H*W/8] for the result all-gather */
+extern "C" int rsp_pack_bits(const uint8_t* src, uint8_t* dst, int64_t n_bits, rsp_stream_t stream) {
+  if (!src || !dst || n_bits < 0 || (n_bits & 7)) return RSP_EINVAL;
+  if (n_bits == 0) return RSP_OK;
+  hipLaunchKernelGGL(pack_bits_kernel, dim3(grid_for(n_bits / 8)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     n_bits / 8);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}

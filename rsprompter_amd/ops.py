@@ -11,6 +11,44 @@ ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
 DEFAULT_A_SCALE_LOG2 = 6
 
 
+class Profiler:
+    """Per-kernel HIP-event timing on the launch stream (bench.py's roofline leg; off by default)."""
+
+    def __init__(self):
+        self.records = []
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, flops, nbytes, e0, e1 in self.records:
+            a = agg.setdefault(name, dict(ms=0.0, calls=0, flops=0.0, bytes=0.0))
+            a['ms'] += e0.elapsed_time(e1)
+            a['calls'] += 1
+            a['flops'] += flops
+            a['bytes'] += nbytes
+        return agg
+
+
+_prof = None
+
+
+def set_profiler(p):
+    global _prof
+    _prof = p
+
+
+def _timed(name, flops, nbytes, fn):
+    if _prof is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    _prof.records.append((name, float(flops), float(nbytes), e0, e1))
+    return r
+
+
 def require_device(dev):
     if torch.device(dev).type != 'cuda':
         raise RuntimeError('rsprompter_amd runs on the HIP device only (there is no CPU fallback); '
@@ -114,7 +152,9 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.act = act
     d.a_scale_log2 = a_scale_log2
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
-    _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm")
+    tile = '128x128' if n > 64 else ('128x64' if n > 32 else '128x32')
+    _timed(f'gemm_f16x3_kernel<{tile}>', 2.0 * m * n * w.K, 4.0 * (m * w.K + m * n) + 4.0 * n * w.K,
+           lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm"))
     return out
 
 
@@ -127,24 +167,28 @@ def layernorm(x, gamma, beta, eps=1e-6, act=ACT_NONE, out=None):
     rows = x.numel() // C
     if out is None:
         out = torch.empty_like(x)
-    _lib.check(lib.rsp_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
-                                 rows, C, eps, act, _stream()), "rsp_layernorm")
+    _timed('layernorm_kernel', 0, 8.0 * x.numel(),
+           lambda: _lib.check(lib.rsp_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                                rows, C, eps, act, _stream()), "rsp_layernorm"))
     return out
 
 
 def vit_relpos(qkv, rel_pos_h, rel_pos_w, Bp, S, nh, dh):
     lib = _lib.load()
     rel = torch.empty((Bp * nh, S * S, 2 * S), dtype=torch.float32, device=qkv.device)
-    _lib.check(lib.rsp_vit_relpos(qkv.data_ptr(), rel_pos_h.data_ptr(), rel_pos_w.data_ptr(),
-                                  rel.data_ptr(), Bp, S, nh, dh, _stream()), "rsp_vit_relpos")
+    _timed('vit_relpos_kernel', 2.0 * Bp * nh * S * S * 2 * S * dh, 0,
+           lambda: _lib.check(lib.rsp_vit_relpos(qkv.data_ptr(), rel_pos_h.data_ptr(), rel_pos_w.data_ptr(),
+                                                 rel.data_ptr(), Bp, S, nh, dh, _stream()), "rsp_vit_relpos"))
     return rel
 
 
 def vit_attention(qkv, rel, Bp, S, nh, dh, scale):
     lib = _lib.load()
     out = torch.empty((Bp * S * S, nh * dh), dtype=torch.float32, device=qkv.device)
-    _lib.check(lib.rsp_vit_attention(qkv.data_ptr(), rel.data_ptr(), out.data_ptr(), Bp, S, nh, dh,
-                                     scale, _stream()), "rsp_vit_attention")
+    kind = 'global' if S * S > 1024 else 'window'
+    _timed(f'attn_kernel<vit,{kind}>', 4.0 * Bp * nh * (S * S) ** 2 * dh, 0,
+           lambda: _lib.check(lib.rsp_vit_attention(qkv.data_ptr(), rel.data_ptr(), out.data_ptr(), Bp, S, nh, dh,
+                                                    scale, _stream()), "rsp_vit_attention"))
     return out
 
 
@@ -213,7 +257,8 @@ def _gemm_ct(a, w, out, bias, act, ct_W, ct_dy, a_scale_log2):
     d.a_scale_log2 = a_scale_log2
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
     d.ct_W, d.ct_dy = ct_W, ct_dy
-    _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm(convT)")
+    _timed('gemm_f16x3_kernel<convT>', 2.0 * d.M * d.N * d.K, 4.0 * (d.M * d.K + d.M * d.N),
+           lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm(convT)"))
 
 
 def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v_strides, o_strides,
@@ -229,7 +274,8 @@ def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v
     d.v_bs, d.v_ts, d.v_hs = v_strides
     d.o_bs, d.o_ts, d.o_hs = o_strides
     d.B, d.nh, d.dh, d.Tq, d.Tk, d.scale = B, nh, dh, Tq, Tk, scale
-    _lib.check(lib.rsp_attention(d, _stream()), "rsp_attention")
+    _timed('attn_kernel<sam_decoder>', 4.0 * B * nh * Tq * Tk * dh, 0,
+           lambda: _lib.check(lib.rsp_attention(d, _stream()), "rsp_attention"))
     return out
 
 
@@ -252,7 +298,8 @@ def roi_align(feats_nhwc, pes, rois, P, strides, finest_scale=56):
         d.spatial_scale[i] = 1.0 / strides[i]
     d.rois, d.out = rois.data_ptr(), out.data_ptr()
     d.K, d.P, d.C, d.num_levels, d.finest_scale = K, P, C, len(feats_nhwc), finest_scale
-    _lib.check(lib.rsp_roi_align(d, _stream()), "rsp_roi_align")
+    _timed('roi_align_kernel', 0, 4.0 * out.numel(),
+           lambda: _lib.check(lib.rsp_roi_align(d, _stream()), "rsp_roi_align"))
     return out
 
 
@@ -403,4 +450,18 @@ def div_boxes(boxes, sf4):
     out = torch.empty_like(boxes)
     arr = (ctypes.c_float * 4)(*[float(v) for v in sf4])
     _lib.check(lib.rsp_div_boxes(boxes.data_ptr(), out.data_ptr(), boxes.shape[0], arr, _stream()), "rsp_div_boxes")
+    return out
+
+
+def pack_masks(masks):
+    """bool [k, H, W] -> uint8 [k, H*W/8] (bit i of byte j = pixel 8j+i)."""
+    lib = _lib.load()
+    k = masks.shape[0]
+    n = masks[0].numel() if k else 0
+    if n % 8:
+        raise ValueError('mask area must be a multiple of 8')
+    out = torch.empty((k, n // 8), dtype=torch.uint8, device=masks.device)
+    if k:
+        m = masks.contiguous()
+        _lib.check(lib.rsp_pack_bits(m.data_ptr(), out.data_ptr(), m.numel(), _stream()), "rsp_pack_bits")
     return out
