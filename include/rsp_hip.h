@@ -83,6 +83,13 @@ typedef struct RspGemmDesc {
   /* + crow % res_brows  (per-RoI rows adding their image's rows). NULL disables. */
   const int32_t* res_bmap;
   int32_t res_brows;
+  /* fp16 "plane" operands/results: A given as two fp16 matrices (hi, lo) of     */
+  /* x * 2^a_scale_log2, same [*, lda] layout (lda in elements, multiple of 8) -> the DMA fast   */
+  /* path (global_load_lds, no register staging).  Chi/Clo: additionally (or, with C == NULL,    */
+  /* only) write the result pre-split with scale 2^c_scale_log2 for the next GEMM.               */
+  const uint16_t* Ahi; const uint16_t* Alo;
+  uint16_t* Chi; uint16_t* Clo;
+  int32_t c_scale_log2;
 } RspGemmDesc;
 
 int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream);
@@ -96,6 +103,11 @@ int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream);
 /* ------------------------------------------------------------------------ */
 int rsp_layernorm(const float* x, const float* gamma, const float* beta, float* y,
                   int64_t rows, int32_t C, float eps, int32_t act, rsp_stream_t stream);
+/* same, optionally writing the result as fp16 planes (hi, lo of y * 2^scale_log2) for a       */
+/* following plane-mode GEMM; y may then be NULL.                                              */
+int rsp_layernorm_ex(const float* x, const float* gamma, const float* beta, float* y,
+                     uint16_t* yhi, uint16_t* ylo, int32_t scale_log2, int64_t rows, int32_t C,
+                     float eps, int32_t act, rsp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* SAM ViT attention (windowed and global) with decomposed rel-pos bias.      */
@@ -113,6 +125,10 @@ int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const float* rel_po
 int rsp_vit_attention(const float* qkv, const float* rel, float* out,
                       int32_t Bp, int32_t S, int32_t nh, int32_t dh, float scale,
                       rsp_stream_t stream);
+/* same with an optional fp16-plane copy of the output (feeds the proj GEMM's DMA path)        */
+int rsp_vit_attention_ex(const float* qkv, const float* rel, float* out, uint16_t* out_hi,
+                         uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t S,
+                         int32_t nh, int32_t dh, float scale, rsp_stream_t stream);
 
 /* Generic multi-head attention out = softmax((q*scale) k^T) v with strided    */
 /* operands (element strides; all multiples of 4), used by the SAM mask        */
@@ -192,8 +208,9 @@ int rsp_batched_nms(const float* boxes, const float* scores, const int32_t* ids,
 int rsp_hyper_mask(const float* up, const float* hyper, float* out, int32_t R, int32_t npix,
                    int32_t C, rsp_stream_t stream);
 /* models.py:1746-1784: sigmoid, bilinear (h,w)->(Hb,Wb), crop (crop_h,crop_w),  */
-/* bilinear -> (out_h,out_w), >= thr.  out_prob optional.                        */
-int rsp_mask_post(const float* low_res, int32_t k, int32_t h, int32_t w, int32_t Hb, int32_t Wb,
+/* bilinear -> (out_h,out_w), >= thr.  out_prob optional.  sig_ws: [k*h*w] scratch  */
+/* (sigmoid of the logits, computed once instead of per output tap).               */
+int rsp_mask_post(const float* low_res, float* sig_ws, int32_t k, int32_t h, int32_t w, int32_t Hb, int32_t Wb,
                   int32_t crop_h, int32_t crop_w, int32_t out_h, int32_t out_w, float thr,
                   uint8_t* out_mask, float* out_prob, rsp_stream_t stream);
 

@@ -28,6 +28,7 @@ class RspGemmDesc(ctypes.Structure):
         ("conv_Ho", c_int), ("conv_Wo", c_int),
         ("ct_W", c_int), ("ct_dy", c_int),
         ("res_bmap", c_void_p), ("res_brows", c_int),
+        ("Ahi", c_void_p), ("Alo", c_void_p), ("Chi", c_void_p), ("Clo", c_void_p), ("c_scale_log2", c_int),
     ]
 
 
@@ -67,6 +68,10 @@ PROTOTYPES = {
     "rsp_split_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rsp_gemm": (c_int, [ctypes.POINTER(RspGemmDesc), c_void_p]),
     "rsp_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
+    "rsp_layernorm_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,
+                                 c_float, c_int, c_void_p]),
+    "rsp_vit_attention_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_int, c_float, c_void_p]),
     "rsp_vit_relpos": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rsp_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rsp_preprocess": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
@@ -84,7 +89,7 @@ PROTOTYPES = {
     "rsp_batched_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsp_hyper_mask": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "rsp_mask_post": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+    "rsp_mask_post": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                               c_void_p, c_void_p, c_void_p]),
     "rsp_pool2": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rsp_add_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),

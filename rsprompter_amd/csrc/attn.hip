@@ -38,6 +38,7 @@ struct AttnP {
   const float* q; const float* k; const float* v; const float* rel; float* out;
   const int32_t* kv_batch_map;  // optional: batch b reads K/V of batch kv_batch_map[b]
   const int32_t* q_batch_map;   // optional: batch b reads Q of batch q_batch_map[b]
+  half_t* out_hi; half_t* out_lo; float out_pscale;  // optional fp16-plane copy of `out` (same strides)
   int64_t q_bs, q_ts, q_hs;     // element strides: batch, token, head
   int64_t k_bs, k_ts, k_hs;
   int64_t v_bs, v_ts, v_hs;
@@ -306,7 +307,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
           f32x4 o;
 #pragma unroll
           for (int c = 0; c < 4; ++c) o[c] = acc_o[db][4 * g + c] * inv;
-          *reinterpret_cast<f32x4*>(dst + d0) = o;
+          if (out) *reinterpret_cast<f32x4*>(dst + d0) = o;
+          if (p.out_hi) {
+            half4_t h4, l4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { half_t a, b; rsp_split1(o[c] * p.out_pscale, a, b); h4[c] = a; l4[c] = b; }
+            const int64_t eo = (int64_t)bp * p.o_bs + (int64_t)q * p.o_ts + (int64_t)h * p.o_hs + d0;
+            *reinterpret_cast<half4_t*>(p.out_hi + eo) = h4;
+            *reinterpret_cast<half4_t*>(p.out_lo + eo) = l4;
+          }
         }
       }
   }
@@ -389,15 +398,29 @@ static int launch_attn(const AttnP& p, int B, hipStream_t s) {
   return RSP_OK;
 }
 
+extern "C" int rsp_vit_attention_ex(const float* qkv, const float* rel, float* out, uint16_t* out_hi,
+                                    uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t S,
+                                    int32_t nh, int32_t dh, float scale, rsp_stream_t stream);
+
 extern "C" int rsp_vit_attention(const float* qkv, const float* rel, float* out, int32_t Bp,
                                  int32_t S, int32_t nh, int32_t dh, float scale,
                                  rsp_stream_t stream) {
-  if (!qkv || !rel || !out || Bp <= 0 || S <= 0 || nh <= 0) return RSP_EINVAL;
+  if (!out) return RSP_EINVAL;
+  return rsp_vit_attention_ex(qkv, rel, out, nullptr, nullptr, 0, Bp, S, nh, dh, scale, stream);
+}
+
+extern "C" int rsp_vit_attention_ex(const float* qkv, const float* rel, float* out, uint16_t* out_hi,
+                                    uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t S,
+                                    int32_t nh, int32_t dh, float scale, rsp_stream_t stream) {
+  if (!qkv || !rel || Bp <= 0 || S <= 0 || nh <= 0) return RSP_EINVAL;
+  if (!out && !(out_hi && out_lo)) return RSP_EINVAL;
   if (!(S == 64 || S <= 32)) return RSP_EINVAL;
   const int T = S * S;
   const int64_t D = (int64_t)nh * dh;
   AttnP p;
   p.q = qkv; p.k = qkv + D; p.v = qkv + 2 * D; p.rel = rel; p.out = out; p.kv_batch_map = nullptr; p.q_batch_map = nullptr;
+  p.out_hi = reinterpret_cast<half_t*>(out_hi); p.out_lo = reinterpret_cast<half_t*>(out_lo);
+  p.out_pscale = ldexpf(1.0f, out_scale_log2);
   p.q_bs = p.k_bs = p.v_bs = (int64_t)T * 3 * D;
   p.q_ts = p.k_ts = p.v_ts = 3 * D;
   p.q_hs = p.k_hs = p.v_hs = dh;
@@ -418,6 +441,7 @@ extern "C" int rsp_attention(const RspAttnDesc* d, rsp_stream_t stream) {
   AttnP p;
   p.q = d->q; p.k = d->k; p.v = d->v; p.rel = nullptr; p.out = d->out;
   p.kv_batch_map = d->kv_batch_map; p.q_batch_map = d->q_batch_map;
+  p.out_hi = nullptr; p.out_lo = nullptr; p.out_pscale = 1.0f;
   p.q_bs = d->q_bs; p.q_ts = d->q_ts; p.q_hs = d->q_hs;
   p.k_bs = d->k_bs; p.k_ts = d->k_ts; p.k_hs = d->k_hs;
   p.v_bs = d->v_bs; p.v_ts = d->v_ts; p.v_hs = d->v_hs;

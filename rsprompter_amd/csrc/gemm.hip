@@ -47,8 +47,9 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const GemmP p) {
   const int wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int hh = lane >> 5, l31 = lane & 31;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int M = d.M, N = d.N, K = d.K;
+  const int nbn = (N + BN - 1) / BN;          // 1-D grid, N-blocks fastest: neighbours share the A panel
+  const int m0 = (int)(blockIdx.x / nbn) * BM, n0 = (int)(blockIdx.x % nbn) * BN;
   const float a_scale = ldexpf(1.0f, d.a_scale_log2);
 
   // ---- per-thread A row bookkeeping (fixed across K tiles) ----
@@ -226,7 +227,13 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const GemmP p) {
         if (d.bias) v += d.bias[col];
         v = rsp_act(v, d.act);
         if (d.res) v += d.res[rrow * d.ldr + col];
-        d.C[(int64_t)crow * d.ldc + col] = v;
+        if (d.C) d.C[(int64_t)crow * d.ldc + col] = v;
+        if (d.Chi) {
+          half_t h, l;
+          rsp_split1(v * ldexpf(1.0f, d.c_scale_log2), h, l);
+          reinterpret_cast<half_t*>(d.Chi)[(int64_t)crow * d.ldc + col] = h;
+          reinterpret_cast<half_t*>(d.Clo)[(int64_t)crow * d.ldc + col] = l;
+        }
       }
     }
   }
@@ -246,8 +253,9 @@ __global__ void split_f16_kernel(const float* __restrict__ w, half_t* __restrict
 template <int BM, int BN, int WGM, int WGN>
 int launch_gemm(const RspGemmDesc& d, hipStream_t s) {
   GemmP p; p.d = d;
-  dim3 grid((d.N + BN - 1) / BN, (d.M + BM - 1) / BM);
-  if (grid.y > 65535) return RSP_EINVAL;
+  const long long nblk = (long long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
+  if (nblk > 0x7fffffffLL) return RSP_EINVAL;
+  dim3 grid((unsigned)nblk);
   hipLaunchKernelGGL((gemm_f16x3_kernel<BM, BN, WGM, WGN>), grid, dim3(256), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
@@ -268,10 +276,15 @@ extern "C" int rsp_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t
   return RSP_OK;
 }
 
+int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s);  // gemm_dma.hip
+
 extern "C" int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream) {
   if (!desc) return RSP_EINVAL;
   const RspGemmDesc& d = *desc;
-  if (!d.A || !d.Bhi || !d.Blo || !d.C) return RSP_EINVAL;
+  if (!d.Bhi || !d.Blo) return RSP_EINVAL;
+  if (!d.A && !(d.Ahi && d.Alo)) return RSP_EINVAL;
+  if (!d.C && !(d.Chi && d.Clo)) return RSP_EINVAL;
+  if ((d.Chi == nullptr) != (d.Clo == nullptr)) return RSP_EINVAL;
   if (d.M < 0 || d.N <= 0 || d.K <= 0 || (d.K % BK) != 0) return RSP_EINVAL;
   if (d.M == 0) return RSP_OK;
   if (d.conv_k != 0) {
@@ -281,8 +294,10 @@ extern "C" int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream) {
   } else {
     if ((d.lda & 3) != 0) return RSP_EINVAL;
   }
+  if (d.M == 0) return RSP_OK;
   if (d.res && d.ldr <= 0) return RSP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
+  if (d.Ahi && d.Alo) return rsp_gemm_dma_dispatch(d, s);
   if (d.N > 64) return launch_gemm<128, 128, 2, 2>(d, s);
   if (d.N > 32) return launch_gemm<128, 64, 2, 2>(d, s);
   return launch_gemm<128, 32, 4, 1>(d, s);

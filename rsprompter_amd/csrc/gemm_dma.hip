@@ -1,0 +1,250 @@
+// fp16x3 GEMM, "plane" fast path: BOTH operands arrive as pre-split fp16 planes (hi, lo) and are
+// streamed HBM -> LDS by the DMA engine (`global_load_lds_dwordx4`, 16 B per lane), bypassing the
+// register file: no staging VGPRs, no conversion VALU in the main loop.  Same arithmetic as
+// gemm.hip (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate in v_mfma_f32_32x32x16_f16).
+//
+// LDS image (per buffer): [A_hi | A_lo | B_hi | B_lo], each plane [rows][32 halves] = 64-B rows,
+// written lane-linearly by the DMA (wave-uniform base + lane*16).  A row-major 64-B-row tile would
+// be a 4-way bank conflict for the ds_read_b128 fragment reads (rows r and r+4 share a 16-B slot
+// column), so the 16-B chunk index is XOR-swizzled with (row >> 2) & 3 -- applied on the per-lane
+// GLOBAL source address (the DMA destination must stay linear) and again on the read.
+//
+// Pipeline: 2 LDS buffers; the DMA for tile k+1 is issued before the MFMA block of tile k and is
+// drained by the __syncthreads() that ends the iteration (one barrier per K step).
+#include "rsp_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int ROWB = BK * 2;  // bytes per LDS row
+
+__device__ uint4 g_zero_page[16];  // zeros: source of padded rows / out-of-image conv taps
+
+struct GemmP {
+  RspGemmDesc d;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256) void gemm_f16x3_dma_kernel(const GemmP p) {
+  static_assert(WGM * WGN == 4, "4 waves per block");
+  constexpr int WTM = BM / WGM, WTN = BN / WGN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_UNITS = 2 * BM * 4, B_UNITS = 2 * BN * 4;   // 16-byte units per buffer
+  constexpr int NA = A_UNITS / 256, NB = (B_UNITS + 255) / 256;
+  constexpr int BUF_BYTES = (A_UNITS + B_UNITS) * 16;
+  constexpr int OFF_ALO = BM * ROWB, OFF_BHI = 2 * BM * ROWB, OFF_BLO = 2 * BM * ROWB + BN * ROWB;
+
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2][BUF_BYTES];
+
+  const RspGemmDesc& d = p.d;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int M = d.M, N = d.N, K = d.K;
+  const int nbn = (N + BN - 1) / BN;
+  const int m0 = (int)(blockIdx.x / nbn) * BM, n0 = (int)(blockIdx.x % nbn) * BN;
+  const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
+
+  // ---- per-thread DMA slots.  A unit u = i*256 + tid: plane = u / (BM*4), row = (u % (BM*4)) / 4,
+  //      physical 16-B position pos = u & 3 holds logical chunk pos ^ ((row >> 2) & 3).
+  const unsigned char* a_src[NA];  // plain mode: row base (bytes) incl. chunk offset; conv: plane base
+  bool a_ok[NA];
+  int a_chunkb[NA];                // byte offset of the logical chunk inside the K tile
+  int64_t a_pix[NA];               // conv: batch pixel base
+  int a_y[NA], a_x[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int u = i * 256 + tid;
+    const int plane = u / (BM * 4);
+    const int row = (u % (BM * 4)) >> 2;
+    const int chunk = (u & 3) ^ ((row >> 2) & 3);
+    const uint16_t* base = plane == 0 ? d.Ahi : d.Alo;
+    const int gm = m0 + row;
+    a_ok[i] = gm < M;
+    a_chunkb[i] = chunk * 16;
+    a_src[i] = reinterpret_cast<const unsigned char*>(base);
+    a_pix[i] = 0; a_y[i] = 0; a_x[i] = 0;
+    if (a_ok[i]) {
+      if (d.conv_k == 0) {
+        const int srow = d.a_rowmap ? d.a_rowmap[gm] : gm;
+        if (srow < 0) a_ok[i] = false;
+        a_src[i] += ((int64_t)srow * d.lda) * 2 + chunk * 16;
+      } else {
+        const int hw = d.conv_Ho * d.conv_Wo;
+        const int b = gm / hw;
+        const int rem = gm - b * hw;
+        const int yo = rem / d.conv_Wo;
+        const int xo = rem - yo * d.conv_Wo;
+        a_pix[i] = (int64_t)b * d.conv_H * d.conv_W;
+        a_y[i] = yo * d.conv_stride - d.conv_pad;
+        a_x[i] = xo * d.conv_stride - d.conv_pad;
+      }
+    }
+  }
+  const unsigned char* b_src[NB];
+  bool b_ok[NB], b_in[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int u = i * 256 + tid;
+    b_in[i] = u < B_UNITS;
+    const int plane = u / (BN * 4);
+    const int row = (u % (BN * 4)) >> 2;
+    const int chunk = (u & 3) ^ ((row >> 2) & 3);
+    const uint16_t* base = plane == 0 ? d.Bhi : d.Blo;
+    b_ok[i] = b_in[i] && (n0 + row < N);
+    b_src[i] = reinterpret_cast<const unsigned char*>(base) + ((int64_t)(n0 + row) * K) * 2 + chunk * 16;
+  }
+
+  auto issue_tile = [&](int k0, int buf) {
+    int ky = 0, kx = 0, c0 = 0;
+    if (d.conv_k != 0) {
+      const int tap = k0 / d.conv_C;
+      c0 = k0 - tap * d.conv_C;
+      ky = tap / d.conv_k;
+      kx = tap - ky * d.conv_k;
+    }
+    unsigned char* lbase = &smem[buf][0];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const unsigned char* src = zero;
+      if (a_ok[i]) {
+        if (d.conv_k == 0) {
+          src = a_src[i] + (int64_t)k0 * 2;
+        } else {
+          const int y = a_y[i] + ky, x = a_x[i] + kx;
+          if (y >= 0 && y < d.conv_H && x >= 0 && x < d.conv_W)
+            src = a_src[i] + ((a_pix[i] + (int64_t)y * d.conv_W + x) * d.conv_C + c0) * 2 + a_chunkb[i];
+        }
+      }
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      if (B_UNITS >= 256 * (i + 1) || (i * 256 + wave * 64) < B_UNITS) {   // wave-uniform guard
+        const unsigned char* src = b_ok[i] ? b_src[i] + (int64_t)k0 * 2 : zero;
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (A_UNITS + i * 256 + wave * 64) * 16), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane fragment byte offsets (row * 64 + swizzled chunk), fixed across K tiles
+  int a_off[TM][2], b_off[TN][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int r = wm * WTM + i * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) a_off[i][s] = r * ROWB + (((s * 2 + hh) ^ ((r >> 2) & 3)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int r = wn * WTN + j * 32 + l31;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) b_off[j][s] = r * ROWB + (((s * 2 + hh) ^ ((r >> 2) & 3)) << 4);
+  }
+
+  const int nk = K / BK;
+  issue_tile(0, 0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) issue_tile((kt + 1) * BK, buf ^ 1);
+    const unsigned char* sb = &smem[buf][0];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      half8_t ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i][s]);
+        al[i] = *reinterpret_cast<const half8_t*>(sb + OFF_ALO + a_off[i][s]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const half8_t*>(sb + OFF_BHI + b_off[j][s]);
+        bl[j] = *reinterpret_cast<const half8_t*>(sb + OFF_BLO + b_off[j][s]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();   // drains this wave's DMA (vmcnt(0)) and separates buffer reuse
+  }
+
+  // ---- epilogue (same contract as gemm.hip) + optional fp16-plane output for the next GEMM ----
+  const float alpha = d.alpha;
+  const float cs = d.Chi ? ldexpf(1.0f, d.c_scale_log2) : 1.0f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (row >= M) continue;
+      int crow = d.c_rowmap ? d.c_rowmap[row] : row;
+      if (crow < 0) continue;
+      if (d.ct_W > 0) {
+        const int yy = crow / d.ct_W;
+        crow = (yy * 2 + d.ct_dy) * d.ct_W + (crow - yy * d.ct_W);
+      }
+      int64_t rrow = d.res_mod > 0 ? crow % d.res_mod : crow;
+      if (d.res_bmap) {
+        const int rb = crow / d.res_brows;
+        rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (crow - rb * d.res_brows);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * WTN + j * 32 + l31;
+        if (col >= N) continue;
+        float v = acc[i][j][r] * alpha;
+        if (d.bias) v += d.bias[col];
+        v = rsp_act(v, d.act);
+        if (d.res) v += d.res[rrow * d.ldr + col];
+        if (d.C) d.C[(int64_t)crow * d.ldc + col] = v;
+        if (d.Chi) {
+          half_t h, l;
+          rsp_split1(v * cs, h, l);
+          reinterpret_cast<half_t*>(d.Chi)[(int64_t)crow * d.ldc + col] = h;
+          reinterpret_cast<half_t*>(d.Clo)[(int64_t)crow * d.ldc + col] = l;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_dma(const RspGemmDesc& d, hipStream_t s) {
+  GemmP p; p.d = d;
+  const long long nblk = (long long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
+  if (nblk > 0x7fffffffLL) return RSP_EINVAL;
+  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+}  // namespace
+
+// called from rsp_gemm (gemm.hip) when the descriptor carries A planes
+int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
+  if ((d.lda & 7) != 0) return RSP_EINVAL;   // 16-byte aligned fp16 rows
+  if (d.conv_k != 0 && (d.conv_C & 7) != 0) return RSP_EINVAL;
+  if (d.N > 64) return launch_dma<128, 128, 2, 2>(d, s);
+  if (d.N > 32) return launch_dma<128, 64, 2, 2>(d, s);
+  return launch_dma<128, 32, 4, 1>(d, s);
+}

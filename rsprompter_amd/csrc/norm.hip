@@ -11,7 +11,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         float* __restrict__ y, int64_t rows, int C,
-                                                        float eps, int act) {
+                                                        float eps, int act, half_t* __restrict__ yhi,
+                                                        half_t* __restrict__ ylo, float pscale) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -58,29 +59,104 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         if (act == RSP_ACT_GELU) t = rsp_gelu(t);
         o[j] = t;
       }
-      *reinterpret_cast<f32x4*>(yr + c) = o;
+      if (y) *reinterpret_cast<f32x4*>(yr + c) = o;
+      if (yhi) {
+        half4_t h4, l4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          half_t a, b;
+          rsp_split1(o[j] * pscale, a, b);
+          h4[j] = a; l4[j] = b;
+        }
+        *reinterpret_cast<half4_t*>(yhi + row * C + c) = h4;
+        *reinterpret_cast<half4_t*>(ylo + row * C + c) = l4;
+      }
     }
+  }
+}
+
+// C <= 64: a 16-lane group per row (4 rows per wave) so that no lane idles
+__global__ __launch_bounds__(256) void layernorm_small_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              float* __restrict__ y, int64_t rows, int C,
+                                                              float eps, int act, half_t* __restrict__ yhi,
+                                                              half_t* __restrict__ ylo, float pscale) {
+  const int sub = threadIdx.x & 15;
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const bool rv = row < rows;
+  const int c = sub * 4;
+  const bool ok = rv && c < C;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (ok) v = *reinterpret_cast<const f32x4*>(x + row * C + c);
+  float sum = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+  if (ok) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float dlt = v[j] - mean; sq += dlt * dlt; }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  if (!ok) return;
+  const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c);
+  const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c);
+  f32x4 o4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float t = (v[j] - mean) * rstd * g[j] + b[j];
+    if (act == RSP_ACT_GELU) t = rsp_gelu(t);
+    o4[j] = t;
+  }
+  if (y) *reinterpret_cast<f32x4*>(y + row * C + c) = o4;
+  if (yhi) {
+    half4_t h4, l4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { half_t a, bb; rsp_split1(o4[j] * pscale, a, bb); h4[j] = a; l4[j] = bb; }
+    *reinterpret_cast<half4_t*>(yhi + row * C + c) = h4;
+    *reinterpret_cast<half4_t*>(ylo + row * C + c) = l4;
   }
 }
 
 }  // namespace
 
-extern "C" int rsp_layernorm(const float* x, const float* gamma, const float* beta, float* y,
-                             int64_t rows, int32_t C, float eps, int32_t act,
-                             rsp_stream_t stream) {
-  if (!x || !gamma || !beta || !y || rows < 0 || C <= 0 || (C & 3) || C > 2048) return RSP_EINVAL;
+extern "C" int rsp_layernorm_ex(const float* x, const float* gamma, const float* beta, float* y,
+                                uint16_t* yhi, uint16_t* ylo, int32_t scale_log2, int64_t rows, int32_t C,
+                                float eps, int32_t act, rsp_stream_t stream) {
+  if (!x || !gamma || !beta || rows < 0 || C <= 0 || (C & 3) || C > 2048) return RSP_EINVAL;
+  if (!y && !(yhi && ylo)) return RSP_EINVAL;
+  if ((yhi == nullptr) != (ylo == nullptr)) return RSP_EINVAL;
   if (act != RSP_ACT_NONE && act != RSP_ACT_GELU) return RSP_EINVAL;
   if (rows == 0) return RSP_OK;
+  hipStream_t s = (hipStream_t)stream;
+  half_t* hi = reinterpret_cast<half_t*>(yhi);
+  half_t* lo = reinterpret_cast<half_t*>(ylo);
+  const float ps = ldexpf(1.0f, scale_log2);
+  if (C <= 64) {
+    const int64_t blocks = (rows + 15) / 16;
+    if (blocks > 0x7fffffffLL) return RSP_EINVAL;
+    hipLaunchKernelGGL(layernorm_small_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act, hi, lo, ps);
+    RSP_CHECK_LAUNCH();
+    return RSP_OK;
+  }
   const int64_t blocks = (rows + 3) / 4;
   if (blocks > 0x7fffffffLL) return RSP_EINVAL;
-  hipStream_t s = (hipStream_t)stream;
   if (C <= 256) {
-    hipLaunchKernelGGL((layernorm_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act);
+    hipLaunchKernelGGL((layernorm_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act, hi, lo, ps);
   } else if (C <= 1024) {
-    hipLaunchKernelGGL((layernorm_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act);
+    hipLaunchKernelGGL((layernorm_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act, hi, lo, ps);
   } else {
-    hipLaunchKernelGGL((layernorm_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act);
+    hipLaunchKernelGGL((layernorm_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act, hi, lo, ps);
   }
   RSP_CHECK_LAUNCH();
   return RSP_OK;
+}
+
+extern "C" int rsp_layernorm(const float* x, const float* gamma, const float* beta, float* y,
+                             int64_t rows, int32_t C, float eps, int32_t act, rsp_stream_t stream) {
+  if (!y) return RSP_EINVAL;
+  return rsp_layernorm_ex(x, gamma, beta, y, nullptr, nullptr, 0, rows, C, eps, act, stream);
 }

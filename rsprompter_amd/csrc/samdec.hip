@@ -51,33 +51,39 @@ struct MaskPostP {
   float thr;
 };
 
+__global__ __launch_bounds__(256) void sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+
+// `sig` = sigmoid(low-res logits) (models.py:1758); IDENT: crop == output size, so the second
+// interpolation is the identity (src index == dst index, weight 1) and only stage 1 is evaluated.
+template <bool IDENT>
 __global__ __launch_bounds__(256) void mask_post_kernel(const MaskPostP p) {
   const int m = blockIdx.y;
   const float* low = p.low + (int64_t)m * p.h * p.w;
   const float s1h = (float)p.h / (float)p.Hb, s1w = (float)p.w / (float)p.Wb;
   const float s2h = (float)p.ch / (float)p.oh, s2w = (float)p.cw / (float)p.ow;
   const int64_t total = (int64_t)p.oh * p.ow;
+  auto stage1 = [&](int Y, int X) -> float {
+    const Lin ay = lin_coef(Y, s1h, p.h);
+    const Lin ax = lin_coef(X, s1w, p.w);
+    const float v00 = low[ay.i0 * p.w + ax.i0], v01 = low[ay.i0 * p.w + ax.i1];
+    const float v10 = low[ay.i1 * p.w + ax.i0], v11 = low[ay.i1 * p.w + ax.i1];
+    return ay.l0 * (ax.l0 * v00 + ax.l1 * v01) + ay.l1 * (ax.l0 * v10 + ax.l1 * v11);
+  };
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int oy = (int)(i / p.ow), ox = (int)(i - (int64_t)oy * p.ow);
-    const Lin cy = lin_coef(oy, s2h, p.ch), cx = lin_coef(ox, s2w, p.cw);
-    float v[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int Y = a == 0 ? cy.i0 : cy.i1;
-      const Lin ay = lin_coef(Y, s1h, p.h);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const int X = b == 0 ? cx.i0 : cx.i1;
-        const Lin ax = lin_coef(X, s1w, p.w);
-        const float v00 = 1.0f / (1.0f + expf(-low[ay.i0 * p.w + ax.i0]));
-        const float v01 = 1.0f / (1.0f + expf(-low[ay.i0 * p.w + ax.i1]));
-        const float v10 = 1.0f / (1.0f + expf(-low[ay.i1 * p.w + ax.i0]));
-        const float v11 = 1.0f / (1.0f + expf(-low[ay.i1 * p.w + ax.i1]));
-        v[a][b] = ay.l0 * (ax.l0 * v00 + ax.l1 * v01) + ay.l1 * (ax.l0 * v10 + ax.l1 * v11);
-      }
+    float val;
+    if (IDENT) {
+      val = stage1(oy, ox);
+    } else {
+      const Lin cy = lin_coef(oy, s2h, p.ch), cx = lin_coef(ox, s2w, p.cw);
+      const float a00 = stage1(cy.i0, cx.i0), a01 = stage1(cy.i0, cx.i1);
+      const float a10 = stage1(cy.i1, cx.i0), a11 = stage1(cy.i1, cx.i1);
+      val = cy.l0 * (cx.l0 * a00 + cx.l1 * a01) + cy.l1 * (cx.l0 * a10 + cx.l1 * a11);
     }
-    const float val = cy.l0 * (cx.l0 * v[0][0] + cx.l1 * v[0][1]) + cy.l1 * (cx.l0 * v[1][0] + cx.l1 * v[1][1]);
     p.out[(int64_t)m * total + i] = val >= p.thr ? 1 : 0;
     if (p.prob) p.prob[(int64_t)m * total + i] = val;
   }
@@ -96,19 +102,28 @@ extern "C" int rsp_hyper_mask(const float* up, const float* hyper, float* out, i
   return RSP_OK;
 }
 
-extern "C" int rsp_mask_post(const float* low_res, int32_t k, int32_t h, int32_t w, int32_t Hb, int32_t Wb,
-                             int32_t crop_h, int32_t crop_w, int32_t out_h, int32_t out_w, float thr,
+extern "C" int rsp_mask_post(const float* low_res, float* sig_ws, int32_t k, int32_t h, int32_t w, int32_t Hb,
+                             int32_t Wb, int32_t crop_h, int32_t crop_w, int32_t out_h, int32_t out_w, float thr,
                              uint8_t* out_mask, float* out_prob, rsp_stream_t stream) {
-  if (!low_res || !out_mask || k < 0 || h <= 0 || w <= 0 || Hb <= 0 || Wb <= 0 || crop_h <= 0 || crop_w <= 0 ||
+  if (!low_res || !sig_ws || !out_mask || k < 0 || h <= 0 || w <= 0 || Hb <= 0 || Wb <= 0 || crop_h <= 0 || crop_w <= 0 ||
       crop_h > Hb || crop_w > Wb || out_h <= 0 || out_w <= 0)
     return RSP_EINVAL;
   if (k == 0) return RSP_OK;
+  {
+    const int64_t n = (int64_t)k * h * w;
+    int64_t gs = (n + 255) / 256;
+    if (gs > 4096) gs = 4096;
+    hipLaunchKernelGGL(sigmoid_kernel, dim3((unsigned)gs), dim3(256), 0, (hipStream_t)stream, low_res, sig_ws, n);
+  }
   MaskPostP p;
-  p.low = low_res; p.out = out_mask; p.prob = out_prob; p.k = k; p.h = h; p.w = w; p.Hb = Hb; p.Wb = Wb;
+  p.low = sig_ws; p.out = out_mask; p.prob = out_prob; p.k = k; p.h = h; p.w = w; p.Hb = Hb; p.Wb = Wb;
   p.ch = crop_h; p.cw = crop_w; p.oh = out_h; p.ow = out_w; p.thr = thr;
   int64_t gx = ((int64_t)out_h * out_w + 255) / 256;
   if (gx > 4096) gx = 4096;
-  hipLaunchKernelGGL(mask_post_kernel, dim3((unsigned)gx, k), dim3(256), 0, (hipStream_t)stream, p);
+  if (crop_h == out_h && crop_w == out_w)
+    hipLaunchKernelGGL((mask_post_kernel<true>), dim3((unsigned)gx, k), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL((mask_post_kernel<false>), dim3((unsigned)gx, k), dim3(256), 0, (hipStream_t)stream, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }

@@ -101,20 +101,69 @@ class PackedWeight:
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
 
 
+class Planes:
+    """An fp32 matrix x held as two fp16 tensors: hi = f16(x * 2^e), lo = f16(x * 2^e - hi).
+    Same bytes as fp32; lets the GEMM stream its A operand HBM -> LDS with the DMA engine."""
+
+    def __init__(self, hi, lo, scale_log2=DEFAULT_A_SCALE_LOG2):
+        self.hi, self.lo, self.scale_log2 = hi, lo, scale_log2
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    @property
+    def device(self):
+        return self.hi.device
+
+    def view(self, *shape):
+        return Planes(self.hi.view(*shape), self.lo.view(*shape), self.scale_log2)
+
+    def reshape(self, *shape):
+        return Planes(self.hi.reshape(*shape), self.lo.reshape(*shape), self.scale_log2)
+
+
+def empty_planes(shape, device, scale_log2=DEFAULT_A_SCALE_LOG2):
+    return Planes(torch.empty(shape, dtype=torch.float16, device=device),
+                  torch.empty(shape, dtype=torch.float16, device=device), scale_log2)
+
+
+def to_planes(x, scale_log2=DEFAULT_A_SCALE_LOG2):
+    """fp32 tensor -> Planes (one extra HBM pass; producers that can emit planes directly avoid it)."""
+    lib = _lib.load()
+    _chk_f32(x, "x")
+    x = x if x.is_contiguous() else x.contiguous()
+    p = empty_planes(x.shape, x.device, scale_log2)
+    _timed('split_f16_kernel', 0, 8.0 * x.numel(),
+           lambda: _lib.check(lib.rsp_split_f16(x.data_ptr(), p.hi.data_ptr(), p.lo.data_ptr(), x.numel(),
+                                                scale_log2, _stream()), "rsp_split_f16"))
+    return p
+
+
 def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, c_rowmap=None,
          M=None, out_rows=None, res_mod=0, a_scale_log2=DEFAULT_A_SCALE_LOG2, conv=None,
-         res_bmap=None, res_brows=0):
+         res_bmap=None, res_brows=0, out_planes=False, out_f32=True, dma="auto"):
     """C = act(A @ W^T + bias) + res   (see RspGemmDesc in include/rsp_hip.h).
 
     a: [rows, K] fp32 (row stride = a.stride(0)) or, with conv=(k, stride, pad),
        an NHWC tensor [B, H, W, C].
     """
     lib = _lib.load()
-    _chk_f32(a, "a")
+    if not isinstance(a, Planes):
+        _chk_f32(a, "a")
+        # the DMA fast path wants fp16 planes: convert once when the GEMM is big enough to amortise it
+        if dma is True or (dma == "auto" and w.N > 64 and w.K >= 128 and (a.is_contiguous() or a.dim() == 2)):
+            if a.dim() == 2 and a.stride(0) != a.shape[1]:
+                pass
+            else:
+                a = to_planes(a, a_scale_log2)
+    is_planes = isinstance(a, Planes)
+    if is_planes:
+        a_scale_log2 = a.scale_log2
     d = _lib.RspGemmDesc()
     if conv is not None:
         k, stride, pad = conv
-        if a.dim() != 4 or not a.is_contiguous():
+        if len(a.shape) != 4 or not (a.hi if is_planes else a).is_contiguous():
             raise ValueError("conv gemm expects a contiguous NHWC tensor")
         B, H, W, C = a.shape
         Ho = (H + 2 * pad - k) // stride + 1
@@ -126,45 +175,67 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
         if w.K != k * k * C:
             raise ValueError(f"conv weight K={w.K} != {k}*{k}*{C}")
     else:
-        if a.dim() != 2 or a.stride(1) != 1:
+        a0 = a.hi if is_planes else a
+        if a0.dim() != 2 or a0.stride(1) != 1:
             raise ValueError("gemm expects a 2-D row-major A")
-        m = a.shape[0] if M is None else M
-        if a.shape[1] != w.K:
-            raise ValueError(f"A has K={a.shape[1]}, weight has K={w.K}")
-        d.lda = a.stride(0)
+        m = a0.shape[0] if M is None else M
+        if a0.shape[1] != w.K:
+            raise ValueError(f"A has K={a0.shape[1]}, weight has K={w.K}")
+        d.lda = a0.stride(0)
     n = w.N
-    if out is None:
-        rows = m if out_rows is None else out_rows
+    rows = m if out_rows is None else out_rows
+    pl = None
+    if out_planes:
+        pl = empty_planes((rows, n), a.device)
+        d.Chi, d.Clo, d.c_scale_log2 = pl.hi.data_ptr(), pl.lo.data_ptr(), pl.scale_log2
+    if out is None and out_f32:
         out = torch.empty((rows, n), dtype=torch.float32, device=a.device)
-    _chk_f32(out, "out")
+    if out is not None:
+        _chk_f32(out, "out")
     if bias == "auto":
         bias = w.bias
     if res is not None:
         _chk_f32(res, "res")
         d.ldr = res.stride(0)
-    d.A, d.Bhi, d.Blo, d.C = a.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), out.data_ptr()
+    if is_planes:
+        d.Ahi, d.Alo = a.hi.data_ptr(), a.lo.data_ptr()
+    else:
+        d.A = a.data_ptr()
+    d.Bhi, d.Blo, d.C = w.hi.data_ptr(), w.lo.data_ptr(), _ptr(out)
     d.bias, d.res = _ptr(bias), _ptr(res)
     d.a_rowmap, d.c_rowmap = _ptr(a_rowmap), _ptr(c_rowmap)
     d.M, d.N, d.K = m, n, w.K
-    d.ldc = out.stride(0)
+    d.ldc = out.stride(0) if out is not None else n
     d.res_mod = res_mod
     d.res_bmap, d.res_brows = _ptr(res_bmap), res_brows
     d.act = act
     d.a_scale_log2 = a_scale_log2
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
     tile = '128x128' if n > 64 else ('128x64' if n > 32 else '128x32')
-    _timed(f'gemm_f16x3_kernel<{tile}>', 2.0 * m * n * w.K, 4.0 * (m * w.K + m * n) + 4.0 * n * w.K,
+    kname = 'gemm_f16x3_dma_kernel' if is_planes else 'gemm_f16x3_kernel'
+    _timed(f'{kname}<{tile}>', 2.0 * m * n * w.K, 4.0 * (m * w.K + m * n) + 4.0 * n * w.K,
            lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm"))
+    if out_planes:
+        return (out, pl) if out_f32 else pl
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-6, act=ACT_NONE, out=None):
+def layernorm(x, gamma, beta, eps=1e-6, act=ACT_NONE, out=None, planes=False, f32=True):
+    """planes=True additionally returns the result as fp16 Planes (f32=False: planes only)."""
     lib = _lib.load()
     _chk_f32(x, "x")
     if not x.is_contiguous():
         raise ValueError("layernorm expects a contiguous tensor")
     C = x.shape[-1]
     rows = x.numel() // C
+    if planes:
+        pl = empty_planes(x.shape, x.device)
+        y = torch.empty_like(x) if f32 else None
+        _timed('layernorm_kernel', 0, 8.0 * x.numel() + (4.0 * x.numel() if f32 else 0),
+               lambda: _lib.check(lib.rsp_layernorm_ex(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(y),
+                                                       pl.hi.data_ptr(), pl.lo.data_ptr(), pl.scale_log2, rows, C,
+                                                       eps, act, _stream()), "rsp_layernorm_ex"))
+        return (y, pl) if f32 else pl
     if out is None:
         out = torch.empty_like(x)
     _timed('layernorm_kernel', 0, 8.0 * x.numel(),
@@ -182,11 +253,20 @@ def vit_relpos(qkv, rel_pos_h, rel_pos_w, Bp, S, nh, dh):
     return rel
 
 
-def vit_attention(qkv, rel, Bp, S, nh, dh, scale):
+def vit_attention(qkv, rel, Bp, S, nh, dh, scale, planes=False):
+    """planes=True: return the output only as fp16 Planes (it feeds the proj GEMM's DMA path)."""
     lib = _lib.load()
-    out = torch.empty((Bp * S * S, nh * dh), dtype=torch.float32, device=qkv.device)
     kind = 'global' if S * S > 1024 else 'window'
-    _timed(f'attn_kernel<vit,{kind}>', 4.0 * Bp * nh * (S * S) ** 2 * dh, 0,
+    fl = 4.0 * Bp * nh * (S * S) ** 2 * dh
+    if planes:
+        pl = empty_planes((Bp * S * S, nh * dh), qkv.device)
+        _timed(f'attn_kernel<vit,{kind}>', fl, 0,
+               lambda: _lib.check(lib.rsp_vit_attention_ex(qkv.data_ptr(), rel.data_ptr(), 0, pl.hi.data_ptr(),
+                                                           pl.lo.data_ptr(), pl.scale_log2, Bp, S, nh, dh, scale,
+                                                           _stream()), "rsp_vit_attention_ex"))
+        return pl
+    out = torch.empty((Bp * S * S, nh * dh), dtype=torch.float32, device=qkv.device)
+    _timed(f'attn_kernel<vit,{kind}>', fl, 0,
            lambda: _lib.check(lib.rsp_vit_attention(qkv.data_ptr(), rel.data_ptr(), out.data_ptr(), Bp, S, nh, dh,
                                                     scale, _stream()), "rsp_vit_attention"))
     return out
@@ -356,7 +436,8 @@ def mask_post(low_res, batch_input_shape, crop_hw, out_hw, thr, want_prob=False)
     k, h, w = low_res.shape
     out = torch.empty((k, out_hw[0], out_hw[1]), dtype=torch.bool, device=low_res.device)
     prob = torch.empty((k, out_hw[0], out_hw[1]), dtype=torch.float32, device=low_res.device) if want_prob else None
-    _lib.check(lib.rsp_mask_post(low_res.data_ptr(), k, h, w, batch_input_shape[0], batch_input_shape[1],
+    ws = torch.empty_like(low_res)
+    _lib.check(lib.rsp_mask_post(low_res.data_ptr(), ws.data_ptr(), k, h, w, batch_input_shape[0], batch_input_shape[1],
                                  crop_hw[0], crop_hw[1], out_hw[0], out_hw[1], thr, out.data_ptr(), _ptr(prob),
                                  _stream()), "rsp_mask_post")
     return (out, prob) if want_prob else out

@@ -166,7 +166,8 @@ class SamVisionEncoderHIP(HIPModule):
         for i in range(self.depth):
             L = P['layers'][i]
             S = L['S']
-            xn = ops.layernorm(x, L['ln1'][0], L['ln1'][1], self.eps)
+            # GEMM A operands travel as fp16 (hi, lo) planes: LN / attention / GELU epilogues emit them
+            xn = ops.layernorm(x, L['ln1'][0], L['ln1'][1], self.eps, planes=True, f32=False)
             if S == g:  # global attention layer
                 qkv = ops.gemm(xn, L['qkv'])
                 Bp, rowmap = B, None
@@ -175,12 +176,12 @@ class SamVisionEncoderHIP(HIPModule):
                 Bp = B * nw * nw
                 qkv = ops.gemm(xn, L['qkv'], a_rowmap=rowmap, M=Bp * S * S)
             rel = ops.vit_relpos(qkv, L['rph'], L['rpw'], Bp, S, nh, dh)
-            att = ops.vit_attention(qkv, rel, Bp, S, nh, dh, scale)
+            att = ops.vit_attention(qkv, rel, Bp, S, nh, dh, scale, planes=True)
             # proj + window_unpartition + crop + residual (HF:830, 924-952, 969)
             x1 = ops.gemm(att, L['proj'], res=x, c_rowmap=rowmap, out_rows=B * T)
             del qkv, rel, att, xn
-            xn2 = ops.layernorm(x1, L['ln2'][0], L['ln2'][1], self.eps)
-            hmid = ops.gemm(xn2, L['lin1'], act=ops.ACT_GELU)
+            xn2 = ops.layernorm(x1, L['ln2'][0], L['ln2'][1], self.eps, planes=True, f32=False)
+            hmid = ops.gemm(xn2, L['lin1'], act=ops.ACT_GELU, out_planes=True, out_f32=False)
             x = ops.gemm(hmid, L['lin2'], res=x1)
             del hmid, xn2, x1
             if want_hidden:

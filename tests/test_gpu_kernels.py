@@ -353,3 +353,65 @@ def test_hyper_mask(dev):
     hy = torch.randn(3, 32, generator=g)
     ref = torch.einsum('rpc,rc->rp', up.double(), hy.double())
     assert float((ops.hyper_mask(up.to(dev), hy.to(dev)).cpu().double() - ref).abs().max()) < 1e-4
+
+
+def _planes_to_f32(p):
+    return (p.hi.float() + p.lo.float()).cpu().double() / 2.0 ** p.scale_log2
+
+
+def test_plane_path_gemm_layernorm_attention(dev):
+    """fp16 (hi, lo) planes: DMA GEMM (plain / gather / implicit conv / plane output), LN and attention emitters."""
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for (M, N, K) in [(300, 200, 96), (1000, 768, 768), (130, 40, 64), (257, 30, 256)]:
+        a = torch.randn(M, K, generator=g) * 2
+        w = torch.randn(N, K, generator=g) * 0.05
+        b = torch.randn(N, generator=g)
+        r = torch.randn(M, N, generator=g)
+        pw = ops.PackedWeight(w, b, device=dev)
+        ref = F.gelu(a.double() @ w.double().t() + b.double()) + r.double()
+        ap = ops.to_planes(a.to(dev))
+        assert float((_planes_to_f32(ap) - a.double()).abs().max()) < 1e-6
+        out, pl = ops.gemm(ap, pw, act=ops.ACT_GELU, res=r.to(dev), out_planes=True)
+        assert _rel_err(out, ref) < 2e-6
+        assert float((_planes_to_f32(pl) - ref).abs().max() / ref.abs().max()) < 2e-6
+    # gather + scatter maps on the DMA path
+    R, M, N, K = 300, 500, 160, 128
+    a = torch.randn(R, K, generator=g)
+    w = torch.randn(N, K, generator=g) * 0.1
+    pw = ops.PackedWeight(w, None, device=dev)
+    amap = torch.randint(-1, R, (M,), generator=g, dtype=torch.int32)
+    ref = torch.zeros(M, N, dtype=torch.float64)
+    sel = amap >= 0
+    ref[sel] = a[amap[sel].long()].double() @ w.double().t()
+    got = ops.gemm(ops.to_planes(a.to(dev)), pw, a_rowmap=amap.to(dev), M=M)
+    assert _rel_err(got, ref) < 2e-6
+    # implicit 3x3 conv from planes
+    for stride in (1, 2):
+        x = torch.randn(2, 64, 14, 18, generator=g)
+        cw = torch.randn(140, 64, 3, 3, generator=g) * 0.05
+        ref = F.conv2d(x.double(), cw.double(), None, stride=stride, padding=1)
+        pw = ops.PackedWeight(cw.permute(0, 2, 3, 1).reshape(140, -1), None, device=dev)
+        xp = ops.to_planes(x.permute(0, 2, 3, 1).contiguous().to(dev))
+        got = ops.gemm(xp, pw, conv=(3, stride, 1))
+        Ho, Wo = ref.shape[-2:]
+        assert _rel_err(got.view(2, Ho, Wo, 140).permute(0, 3, 1, 2), ref) < 2e-6
+    # LayerNorm emitting planes (all C classes incl. the small-C kernel)
+    for C in (32, 64, 256, 768):
+        x = torch.randn(777, C, generator=g) * 3 + 1
+        wt = torch.randn(C, generator=g); bs = torch.randn(C, generator=g)
+        ref = F.layer_norm(x.double(), (C,), wt.double(), bs.double(), 1e-6)
+        y, pl = ops.layernorm(x.to(dev), wt.to(dev), bs.to(dev), 1e-6, planes=True)
+        assert float((y.cpu().double() - ref).abs().max()) < 2e-5
+        assert float((_planes_to_f32(pl) - ref).abs().max()) < 2e-5
+    # attention emitting planes
+    S, nh, dh, Bp = 14, 2, 64, 3
+    T = S * S
+    qkv = torch.randn(Bp, T, 3, nh, dh, generator=g)
+    rph = torch.randn(2 * S - 1, dh, generator=g) * 0.2
+    rpw = torch.randn(2 * S - 1, dh, generator=g) * 0.2
+    ref, _ = _ref_vit_attention(qkv, rph, rpw, S, nh, dh, dh ** -0.5)
+    d = qkv.to(dev).contiguous()
+    rel = ops.vit_relpos(d, rph.to(dev), rpw.to(dev), Bp, S, nh, dh)
+    pl = ops.vit_attention(d, rel, Bp, S, nh, dh, dh ** -0.5, planes=True)
+    assert float((_planes_to_f32(pl).view(Bp, T, nh * dh) - ref).abs().max()) < 2e-5

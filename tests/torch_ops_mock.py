@@ -30,7 +30,8 @@ class PackedWeight:
 
 
 def gemm(a, w, *, out=None, bias='auto', res=None, act=0, a_rowmap=None, c_rowmap=None, M=None, out_rows=None,
-         res_mod=0, a_scale_log2=6, conv=None, res_bmap=None, res_brows=0):
+         res_mod=0, a_scale_log2=6, conv=None, res_bmap=None, res_brows=0, out_planes=False, out_f32=True,
+         dma='auto'):
     if conv is not None:
         k, s, p = conv
         B, H, W, C = a.shape
@@ -62,11 +63,13 @@ def gemm(a, w, *, out=None, bias='auto', res=None, act=0, a_rowmap=None, c_rowma
             rr = res_bmap.long()[rr // res_brows] * res_brows + rr % res_brows
         y = y + res[rr]
     out[crow[keep]] = y[keep]
-    return out
+    return (out, out) if (out_planes and out_f32) else out
 
 
-def layernorm(x, gamma, beta, eps=1e-6, act=0, out=None):
-    return _act(F.layer_norm(x, (x.shape[-1],), gamma, beta, eps), act)
+def layernorm(x, gamma, beta, eps=1e-6, act=0, out=None, planes=False, f32=True):
+    # the mock keeps "planes" as plain fp32 tensors: only the host wiring is under test
+    y = _act(F.layer_norm(x, (x.shape[-1],), gamma, beta, eps), act)
+    return (y, y) if (planes and f32) else y
 
 
 def vit_relpos(qkv, rph, rpw, Bp, S, nh, dh):
@@ -78,7 +81,7 @@ def vit_relpos(qkv, rph, rpw, Bp, S, nh, dh):
     return torch.cat([rh, rw], -1).reshape(Bp * nh, T, 2 * S)
 
 
-def vit_attention(qkv, rel, Bp, S, nh, dh, scale):
+def vit_attention(qkv, rel, Bp, S, nh, dh, scale, planes=False):
     T = S * S
     q, k, v = qkv.view(Bp, T, 3, nh, dh).permute(2, 0, 3, 1, 4).reshape(3, Bp * nh, T, dh).unbind(0)
     attn = (q * scale) @ k.transpose(-2, -1)
