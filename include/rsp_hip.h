@@ -90,6 +90,7 @@ typedef struct RspGemmDesc {
   const uint16_t* Ahi; const uint16_t* Alo;
   uint16_t* Chi; uint16_t* Clo;
   int32_t c_scale_log2;
+  int32_t tile_hint;  /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile (plane path; benchmarking) */
 } RspGemmDesc;
 
 int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream);

@@ -29,6 +29,7 @@ class RspGemmDesc(ctypes.Structure):
         ("ct_W", c_int), ("ct_dy", c_int),
         ("res_bmap", c_void_p), ("res_brows", c_int),
         ("Ahi", c_void_p), ("Alo", c_void_p), ("Chi", c_void_p), ("Clo", c_void_p), ("c_scale_log2", c_int),
+        ("tile_hint", c_int),
     ]
 
 

@@ -27,13 +27,23 @@ struct GemmP {
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// XCD-aware block remap (8 XCDs, block b runs on XCD b % 8): give every XCD a contiguous range of
+// the logical block order so that blocks sharing an A panel / neighbouring B panels hit the SAME L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u;
+  const unsigned xcd = bid & 7u, idx = bid >> 3;
+  const unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
 template <int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(256) void gemm_f16x3_dma_kernel(const GemmP p) {
-  static_assert(WGM * WGN == 4, "4 waves per block");
+__global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const GemmP p) {
+  constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int A_UNITS = 2 * BM * 4, B_UNITS = 2 * BN * 4;   // 16-byte units per buffer
-  constexpr int NA = A_UNITS / 256, NB = (B_UNITS + 255) / 256;
+  constexpr int NA = A_UNITS / NT, NB = (B_UNITS + NT - 1) / NT;
+  static_assert(A_UNITS % NT == 0 && B_UNITS % NT == 0, "tile/threads mismatch");
   constexpr int BUF_BYTES = (A_UNITS + B_UNITS) * 16;
   constexpr int OFF_ALO = BM * ROWB, OFF_BHI = 2 * BM * ROWB, OFF_BLO = 2 * BM * ROWB + BN * ROWB;
 
@@ -47,7 +57,8 @@ __global__ __launch_bounds__(256) void gemm_f16x3_dma_kernel(const GemmP p) {
   const int hh = lane >> 5, l31 = lane & 31;
   const int M = d.M, N = d.N, K = d.K;
   const int nbn = (N + BN - 1) / BN;
-  const int m0 = (int)(blockIdx.x / nbn) * BM, n0 = (int)(blockIdx.x % nbn) * BN;
+  const unsigned lbid = xcd_remap(blockIdx.x, gridDim.x);
+  const int m0 = (int)(lbid / nbn) * BM, n0 = (int)(lbid % nbn) * BN;
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
 
   // ---- per-thread DMA slots.  A unit u = i*256 + tid: plane = u / (BM*4), row = (u % (BM*4)) / 4,
@@ -59,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_dma_kernel(const GemmP p) {
   int a_y[NA], a_x[NA];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
-    const int u = i * 256 + tid;
+    const int u = i * NT + tid;
     const int plane = u / (BM * 4);
     const int row = (u % (BM * 4)) >> 2;
     const int chunk = (u & 3) ^ ((row >> 2) & 3);
@@ -90,7 +101,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_dma_kernel(const GemmP p) {
   bool b_ok[NB], b_in[NB];
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int u = i * 256 + tid;
+    const int u = i * NT + tid;
     b_in[i] = u < B_UNITS;
     const int plane = u / (BN * 4);
     const int row = (u % (BN * 4)) >> 2;
@@ -121,14 +132,12 @@ __global__ __launch_bounds__(256) void gemm_f16x3_dma_kernel(const GemmP p) {
             src = a_src[i] + ((a_pix[i] + (int64_t)y * d.conv_W + x) * d.conv_C + c0) * 2 + a_chunkb[i];
         }
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (i * NT + wave * 64) * 16), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      if (B_UNITS >= 256 * (i + 1) || (i * 256 + wave * 64) < B_UNITS) {   // wave-uniform guard
-        const unsigned char* src = b_ok[i] ? b_src[i] + (int64_t)k0 * 2 : zero;
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (A_UNITS + i * 256 + wave * 64) * 16), 16, 0, 0);
-      }
+      const unsigned char* src = b_ok[i] ? b_src[i] + (int64_t)k0 * 2 : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (A_UNITS + i * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
 
@@ -233,7 +242,7 @@ int launch_dma(const RspGemmDesc& d, hipStream_t s) {
   GemmP p; p.d = d;
   const long long nblk = (long long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
   if (nblk > 0x7fffffffLL) return RSP_EINVAL;
-  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
@@ -244,6 +253,15 @@ int launch_dma(const RspGemmDesc& d, hipStream_t s) {
 int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if ((d.lda & 7) != 0) return RSP_EINVAL;   // 16-byte aligned fp16 rows
   if (d.conv_k != 0 && (d.conv_C & 7) != 0) return RSP_EINVAL;
+  auto nblk = [&](int bm, int bn) { return (long long)((d.N + bn - 1) / bn) * ((d.M + bm - 1) / bm); };
+  int tile = d.tile_hint;
+  if (tile == 0) {   // pick the largest tile that still fills the 256 CUs reasonably
+    if (d.N > 128 && nblk(256, 256) >= 384) tile = 3;
+    else if (d.N > 64 && nblk(256, 128) >= 384) tile = 2;
+    else tile = 1;
+  }
+  if (tile == 3 && d.N > 128) return launch_dma<256, 256, 2, 4>(d, s);
+  if (tile >= 2 && d.N > 64) return launch_dma<256, 128, 4, 2>(d, s);
   if (d.N > 64) return launch_dma<128, 128, 2, 2>(d, s);
   if (d.N > 32) return launch_dma<128, 64, 2, 2>(d, s);
   return launch_dma<128, 32, 4, 1>(d, s);

@@ -142,7 +142,7 @@ def to_planes(x, scale_log2=DEFAULT_A_SCALE_LOG2):
 
 def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, c_rowmap=None,
          M=None, out_rows=None, res_mod=0, a_scale_log2=DEFAULT_A_SCALE_LOG2, conv=None,
-         res_bmap=None, res_brows=0, out_planes=False, out_f32=True, dma="auto"):
+         res_bmap=None, res_brows=0, out_planes=False, out_f32=True, dma="auto", tile_hint=0):
     """C = act(A @ W^T + bias) + res   (see RspGemmDesc in include/rsp_hip.h).
 
     a: [rows, K] fp32 (row stride = a.stride(0)) or, with conv=(k, stride, pad),
@@ -208,6 +208,7 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.ldc = out.stride(0) if out is not None else n
     d.res_mod = res_mod
     d.res_bmap, d.res_brows = _ptr(res_bmap), res_brows
+    d.tile_hint = tile_hint
     d.act = act
     d.a_scale_log2 = a_scale_log2
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))

@@ -415,3 +415,23 @@ def test_plane_path_gemm_layernorm_attention(dev):
     rel = ops.vit_relpos(d, rph.to(dev), rpw.to(dev), Bp, S, nh, dh)
     pl = ops.vit_attention(d, rel, Bp, S, nh, dh, dh ** -0.5, planes=True)
     assert float((_planes_to_f32(pl).view(Bp, T, nh * dh) - ref).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize('hint', [1, 2, 3])
+def test_plane_gemm_tile_variants(dev, hint):
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(30 + hint)
+    for (M, N, K) in [(1000, 700, 256), (513, 257, 96), (300, 3072, 64)]:
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) * 0.05
+        b = torch.randn(N, generator=g)
+        pw = ops.PackedWeight(w, b, device=dev)
+        ref = a.double() @ w.double().t() + b.double()
+        got = ops.gemm(ops.to_planes(a.to(dev)), pw, tile_hint=hint)
+        assert _rel_err(got, ref) < 2e-6, (hint, M, N, K)
+    x = torch.randn(2, 64, 20, 24, generator=g)
+    cw = torch.randn(300, 64, 3, 3, generator=g) * 0.05
+    ref = F.conv2d(x.double(), cw.double(), None, stride=1, padding=1)
+    pw = ops.PackedWeight(cw.permute(0, 2, 3, 1).reshape(300, -1), None, device=dev)
+    got = ops.gemm(ops.to_planes(x.permute(0, 2, 3, 1).contiguous().to(dev)), pw, conv=(3, 1, 1), tile_hint=hint)
+    assert _rel_err(got.view(2, 20, 24, 300).permute(0, 3, 1, 2), ref) < 2e-6
