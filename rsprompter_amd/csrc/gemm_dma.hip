@@ -36,7 +36,16 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nblk) {
   return base + idx;
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NBUF-deep LDS ring: the DMA of tile k+NBUF-1 is issued while tile k is computed and is only waited
+// for NBUF-1 iterations later with a COUNTED s_waitcnt vmcnt (never 0 in steady state) + a raw
+// s_barrier, so HBM/L2 latency is covered by several K steps instead of one
+// (cdna_hip_programming.md §5 "Pipelining across barriers", T3+T4).
+template <int BM, int BN, int WGM, int WGN, int NBUF>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const GemmP p) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -47,7 +56,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   constexpr int BUF_BYTES = (A_UNITS + B_UNITS) * 16;
   constexpr int OFF_ALO = BM * ROWB, OFF_BHI = 2 * BM * ROWB, OFF_BLO = 2 * BM * ROWB + BN * ROWB;
 
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2][BUF_BYTES];
+  constexpr int LPT = NA + NB;   // DMA instructions per wave per tile
+  static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * LPT < 64, "ring depth / vmcnt range");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF][BUF_BYTES];
 
   const RspGemmDesc& d = p.d;
   const int tid = threadIdx.x;
@@ -165,12 +176,23 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   }
 
   const int nk = K / BK;
-  issue_tile(0, 0);
-  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < NBUF - 1; ++t)
+    if (t < nk) issue_tile(t * BK, t);
 
+  int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) issue_tile((kt + 1) * BK, buf ^ 1);
+    // tile kt must have landed (this wave's part), newer tiles may stay in flight
+    const int ahead = min(NBUF - 2, nk - 1 - kt);
+    if (ahead >= 2) wait_vmcnt<2 * LPT>();
+    else if (ahead == 1) wait_vmcnt<LPT>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();          // ... and everybody else's part; also: all reads of tile kt-1 are done
+    if (kt + NBUF - 1 < nk) {
+      int nb = buf + NBUF - 1;
+      if (nb >= NBUF) nb -= NBUF;
+      issue_tile((kt + NBUF - 1) * BK, nb);
+    }
     const unsigned char* sb = &smem[buf][0];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -194,7 +216,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
         }
     }
-    __syncthreads();   // drains this wave's DMA (vmcnt(0)) and separates buffer reuse
+    if (++buf == NBUF) buf = 0;
   }
 
   // ---- epilogue (same contract as gemm.hip) + optional fp16-plane output for the next GEMM ----
@@ -203,28 +225,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (row >= M) continue;
-      int crow = d.c_rowmap ? d.c_rowmap[row] : row;
-      if (crow < 0) continue;
-      if (d.ct_W > 0) {
-        const int yy = crow / d.ct_W;
-        crow = (yy * 2 + d.ct_dy) * d.ct_W + (crow - yy * d.ct_W);
-      }
-      int64_t rrow = d.res_mod > 0 ? crow % d.res_mod : crow;
-      if (d.res_bmap) {
-        const int rb = crow / d.res_brows;
-        rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (crow - rb * d.res_brows);
-      }
+    for (int j = 0; j < TN; ++j) {
+      const f32x16 t = acc[i][j];      // keep the accumulator indices compile-time (no scratch)
+      const int col = n0 + wn * WTN + j * 32 + l31;
+      const bool col_ok = col < N;
+      const float bv = (d.bias && col_ok) ? d.bias[col] : 0.f;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * WTN + j * 32 + l31;
-        if (col >= N) continue;
-        float v = acc[i][j][r] * alpha;
-        if (d.bias) v += d.bias[col];
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row >= M || !col_ok) continue;
+        int crow = d.c_rowmap ? d.c_rowmap[row] : row;
+        if (crow < 0) continue;
+        if (d.ct_W > 0) {
+          const int yy = crow / d.ct_W;
+          crow = (yy * 2 + d.ct_dy) * d.ct_W + (crow - yy * d.ct_W);
+        }
+        float v = t[r] * alpha + bv;
         v = rsp_act(v, d.act);
-        if (d.res) v += d.res[rrow * d.ldr + col];
+        if (d.res) {
+          int64_t rrow = d.res_mod > 0 ? crow % d.res_mod : crow;
+          if (d.res_bmap) {
+            const int rb = crow / d.res_brows;
+            rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (crow - rb * d.res_brows);
+          }
+          v += d.res[rrow * d.ldr + col];
+        }
         if (d.C) d.C[(int64_t)crow * d.ldc + col] = v;
         if (d.Chi) {
           half_t h, l;
@@ -237,12 +262,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   }
 }
 
-template <int BM, int BN, int WGM, int WGN>
+template <int BM, int BN, int WGM, int WGN, int NBUF>
 int launch_dma(const RspGemmDesc& d, hipStream_t s) {
   GemmP p; p.d = d;
   const long long nblk = (long long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
   if (nblk > 0x7fffffffLL) return RSP_EINVAL;
-  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
+  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
@@ -260,9 +285,15 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
     else if (d.N > 64 && nblk(256, 128) >= 384) tile = 2;
     else tile = 1;
   }
-  if (tile == 3 && d.N > 128) return launch_dma<256, 256, 2, 4>(d, s);
-  if (tile >= 2 && d.N > 64) return launch_dma<256, 128, 4, 2>(d, s);
-  if (d.N > 64) return launch_dma<128, 128, 2, 2>(d, s);
-  if (d.N > 32) return launch_dma<128, 64, 2, 2>(d, s);
-  return launch_dma<128, 32, 4, 1>(d, s);
+  switch (tile) {   // hints >= 4 are benchmarking variants of the same arithmetic
+    case 3: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2>(d, s); break;
+    case 2: if (d.N > 64) return launch_dma<256, 128, 4, 2, 3>(d, s); break;
+    case 4: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2>(d, s); break;
+    case 5: if (d.N > 64) return launch_dma<128, 128, 2, 2, 4>(d, s); break;
+    case 6: if (d.N > 64) return launch_dma<128, 128, 2, 2, 3>(d, s); break;
+    default: break;
+  }
+  if (d.N > 64) return launch_dma<128, 128, 2, 2, 2>(d, s);
+  if (d.N > 32) return launch_dma<128, 64, 2, 2, 3>(d, s);
+  return launch_dma<128, 32, 4, 1, 3>(d, s);
 }

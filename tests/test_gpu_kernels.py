@@ -417,7 +417,7 @@ def test_plane_path_gemm_layernorm_attention(dev):
     assert float((_planes_to_f32(pl).view(Bp, T, nh * dh) - ref).abs().max()) < 2e-5
 
 
-@pytest.mark.parametrize('hint', [1, 2, 3])
+@pytest.mark.parametrize('hint', [1, 2, 3, 4, 5, 6])
 def test_plane_gemm_tile_variants(dev, hint):
     from rsprompter_amd import ops
     g = torch.Generator().manual_seed(30 + hint)

@@ -32,7 +32,7 @@ def main():
         w = ops.PackedWeight(torch.randn(N, K) * 0.02, torch.zeros(N), device=dev)
         out = torch.empty(M, N, device=dev)
         row = {}
-        for hint in (1, 2, 3):
+        for hint in (1, 2, 3, 4, 5, 6):
             try:
                 t = timeit(lambda: ops.gemm(ap, w, out=out, tile_hint=hint))
                 row[f'dma_tile{hint}'] = round(2.0 * M * N * K / t / 1e12, 1)
