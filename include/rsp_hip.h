@@ -45,6 +45,10 @@ const char* rsp_build_info(void);
 /* hi = f16(w * 2^e), lo = f16(w * 2^e - hi).  n elements.                   */
 int rsp_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t n,
                   int scale_log2, rsp_stream_t stream);
+/* same for a row-major [rows, K] matrix (K % 32 == 0), written in the KB32     */
+/* plane layout [K/32][rows][32] that the DMA GEMM path consumes.               */
+int rsp_split_f16_kb32(const float* w, uint16_t* hi, uint16_t* lo, int64_t rows, int32_t K,
+                       int scale_log2, rsp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* GEMM with fused prologue/epilogue: the workhorse.                          */
@@ -83,13 +87,16 @@ typedef struct RspGemmDesc {
   /* + crow % res_brows  (per-RoI rows adding their image's rows). NULL disables. */
   const int32_t* res_bmap;
   int32_t res_brows;
-  /* fp16 "plane" operands/results: A given as two fp16 matrices (hi, lo) of     */
-  /* x * 2^a_scale_log2, same [*, lda] layout (lda in elements, multiple of 8) -> the DMA fast   */
-  /* path (global_load_lds, no register staging).  Chi/Clo: additionally (or, with C == NULL,    */
-  /* only) write the result pre-split with scale 2^c_scale_log2 for the next GEMM.               */
+  /* fp16 "plane" operands/results: A given as two fp16 tensors (hi, lo) of      */
+  /* x * 2^a_scale_log2 in the K-BLOCKED layout [K/32][a_rows][32] ("KB32": every 128x32 K tile   */
+  /* of a plane is one contiguous 8 KiB run of full cache lines) -> the DMA fast path             */
+  /* (global_load_lds, no register staging).  Weights (Bhi/Blo) use the same layout [K/32][N][32] */
+  /* when A is given as planes.  Chi/Clo: additionally (or, with C == NULL, only) write the       */
+  /* result pre-split, scale 2^c_scale_log2, KB32 layout [N/32][c_rows][32], for the next GEMM.   */
   const uint16_t* Ahi; const uint16_t* Alo;
   uint16_t* Chi; uint16_t* Clo;
   int32_t c_scale_log2;
+  int32_t a_rows, c_rows;
   int32_t tile_hint;  /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile (plane path; benchmarking) */
 } RspGemmDesc;
 
@@ -104,8 +111,8 @@ int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream);
 /* ------------------------------------------------------------------------ */
 int rsp_layernorm(const float* x, const float* gamma, const float* beta, float* y,
                   int64_t rows, int32_t C, float eps, int32_t act, rsp_stream_t stream);
-/* same, optionally writing the result as fp16 planes (hi, lo of y * 2^scale_log2) for a       */
-/* following plane-mode GEMM; y may then be NULL.                                              */
+/* same, optionally writing the result as fp16 planes (hi, lo of y * 2^scale_log2; KB32 layout  */
+/* [C/32][rows][32], C % 32 == 0) for a following plane-mode GEMM; y may then be NULL.          */
 int rsp_layernorm_ex(const float* x, const float* gamma, const float* beta, float* y,
                      uint16_t* yhi, uint16_t* ylo, int32_t scale_log2, int64_t rows, int32_t C,
                      float eps, int32_t act, rsp_stream_t stream);
@@ -126,7 +133,8 @@ int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const float* rel_po
 int rsp_vit_attention(const float* qkv, const float* rel, float* out,
                       int32_t Bp, int32_t S, int32_t nh, int32_t dh, float scale,
                       rsp_stream_t stream);
-/* same with an optional fp16-plane copy of the output (feeds the proj GEMM's DMA path)        */
+/* same with an optional fp16-plane copy of the output (KB32 layout [D/32][Bp*T][32]; feeds the  */
+/* proj GEMM's DMA path)                                                                         */
 int rsp_vit_attention_ex(const float* qkv, const float* rel, float* out, uint16_t* out_hi,
                          uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t S,
                          int32_t nh, int32_t dh, float scale, rsp_stream_t stream);

@@ -29,6 +29,7 @@ class RspGemmDesc(ctypes.Structure):
         ("ct_W", c_int), ("ct_dy", c_int),
         ("res_bmap", c_void_p), ("res_brows", c_int),
         ("Ahi", c_void_p), ("Alo", c_void_p), ("Chi", c_void_p), ("Clo", c_void_p), ("c_scale_log2", c_int),
+        ("a_rows", c_int), ("c_rows", c_int),
         ("tile_hint", c_int),
     ]
 
@@ -67,6 +68,7 @@ PROTOTYPES = {
     "rsp_abi_version": (c_int, []),
     "rsp_build_info": (ctypes.c_char_p, []),
     "rsp_split_f16": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "rsp_split_f16_kb32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "rsp_gemm": (c_int, [ctypes.POINTER(RspGemmDesc), c_void_p]),
     "rsp_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
     "rsp_layernorm_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int,

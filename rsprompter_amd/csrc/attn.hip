@@ -38,7 +38,8 @@ struct AttnP {
   const float* q; const float* k; const float* v; const float* rel; float* out;
   const int32_t* kv_batch_map;  // optional: batch b reads K/V of batch kv_batch_map[b]
   const int32_t* q_batch_map;   // optional: batch b reads Q of batch q_batch_map[b]
-  half_t* out_hi; half_t* out_lo; float out_pscale;  // optional fp16-plane copy of `out` (same strides)
+  half_t* out_hi; half_t* out_lo; float out_pscale;  // optional fp16-plane copy of `out`, KB32 layout
+  int64_t out_rows;                                  // rows (= B * Tq) of that [rows, nh*dh] matrix
   int64_t q_bs, q_ts, q_hs;     // element strides: batch, token, head
   int64_t k_bs, k_ts, k_hs;
   int64_t v_bs, v_ts, v_hs;
@@ -312,7 +313,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
             half4_t h4, l4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) { half_t a, b; rsp_split1(o[c] * p.out_pscale, a, b); h4[c] = a; l4[c] = b; }
-            const int64_t eo = (int64_t)bp * p.o_bs + (int64_t)q * p.o_ts + (int64_t)h * p.o_hs + d0;
+            const int col = h * DH + d0;
+            const int64_t eo = ((int64_t)(col >> 5) * p.out_rows + ((int64_t)bp * T + q)) * 32 + (col & 31);
             *reinterpret_cast<half4_t*>(p.out_hi + eo) = h4;
             *reinterpret_cast<half4_t*>(p.out_lo + eo) = l4;
           }
@@ -421,6 +423,8 @@ extern "C" int rsp_vit_attention_ex(const float* qkv, const float* rel, float* o
   p.q = qkv; p.k = qkv + D; p.v = qkv + 2 * D; p.rel = rel; p.out = out; p.kv_batch_map = nullptr; p.q_batch_map = nullptr;
   p.out_hi = reinterpret_cast<half_t*>(out_hi); p.out_lo = reinterpret_cast<half_t*>(out_lo);
   p.out_pscale = ldexpf(1.0f, out_scale_log2);
+  p.out_rows = (int64_t)Bp * T;
+  if (out_hi && ((nh * dh) & 31)) return RSP_EINVAL;
   p.q_bs = p.k_bs = p.v_bs = (int64_t)T * 3 * D;
   p.q_ts = p.k_ts = p.v_ts = 3 * D;
   p.q_hs = p.k_hs = p.v_hs = dh;
@@ -441,7 +445,7 @@ extern "C" int rsp_attention(const RspAttnDesc* d, rsp_stream_t stream) {
   AttnP p;
   p.q = d->q; p.k = d->k; p.v = d->v; p.rel = nullptr; p.out = d->out;
   p.kv_batch_map = d->kv_batch_map; p.q_batch_map = d->q_batch_map;
-  p.out_hi = nullptr; p.out_lo = nullptr; p.out_pscale = 1.0f;
+  p.out_hi = nullptr; p.out_lo = nullptr; p.out_pscale = 1.0f; p.out_rows = 0;
   p.q_bs = d->q_bs; p.q_ts = d->q_ts; p.q_hs = d->q_hs;
   p.k_bs = d->k_bs; p.k_ts = d->k_ts; p.k_hs = d->k_hs;
   p.v_bs = d->v_bs; p.v_ts = d->v_ts; p.v_hs = d->v_hs;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const GemmP p) {
     for (int i = 0; i < B_PER_THREAD; ++i) {
       uint4 zh = {0u, 0u, 0u, 0u}, zl = {0u, 0u, 0u, 0u};
       if (b_ok[i]) {
-        const int64_t off = (int64_t)(n0 + b_row[i]) * K + k0 + b_kc[i];
+        const int64_t off = ((int64_t)(k0 / BK) * N + n0 + b_row[i]) * BK + b_kc[i];   // KB32 weight layout
         zh = *reinterpret_cast<const uint4*>(d.Bhi + off);
         zl = *reinterpret_cast<const uint4*>(d.Blo + off);
       }
@@ -231,8 +231,9 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const GemmP p) {
         if (d.Chi) {
           half_t h, l;
           rsp_split1(v * ldexpf(1.0f, d.c_scale_log2), h, l);
-          reinterpret_cast<half_t*>(d.Chi)[(int64_t)crow * d.ldc + col] = h;
-          reinterpret_cast<half_t*>(d.Clo)[(int64_t)crow * d.ldc + col] = l;
+          const int64_t po = ((int64_t)(col >> 5) * d.c_rows + crow) * 32 + (col & 31);   // KB32 layout
+          reinterpret_cast<half_t*>(d.Chi)[po] = h;
+          reinterpret_cast<half_t*>(d.Clo)[po] = l;
         }
       }
     }
@@ -247,6 +248,25 @@ __global__ void split_f16_kernel(const float* __restrict__ w, half_t* __restrict
     half_t h, l;
     rsp_split1(w[i] * scale, h, l);
     hi[i] = h; lo[i] = l;
+  }
+}
+
+// row-major [rows, K] fp32 -> KB32 planes [K/32][rows][32]; a thread handles 4 consecutive k
+__global__ void split_f16_kb32_kernel(const float* __restrict__ w, half_t* __restrict__ hi,
+                                      half_t* __restrict__ lo, int64_t rows, int K, float scale) {
+  const int k4n = K / 4;
+  const int64_t total = rows * k4n;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / k4n;
+    const int k = (int)(i - r * k4n) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(w + r * K + k);
+    half4_t h4, l4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { half_t a, b; rsp_split1(v[j] * scale, a, b); h4[j] = a; l4[j] = b; }
+    const int64_t o = ((int64_t)(k >> 5) * rows + r) * 32 + (k & 31);
+    *reinterpret_cast<half4_t*>(hi + o) = h4;
+    *reinterpret_cast<half4_t*>(lo + o) = l4;
   }
 }
 
@@ -276,6 +296,19 @@ extern "C" int rsp_split_f16(const float* w, uint16_t* hi, uint16_t* lo, int64_t
   return RSP_OK;
 }
 
+extern "C" int rsp_split_f16_kb32(const float* w, uint16_t* hi, uint16_t* lo, int64_t rows, int32_t K,
+                                  int scale_log2, rsp_stream_t stream) {
+  if (!w || !hi || !lo || rows < 0 || K <= 0 || (K & 31)) return RSP_EINVAL;
+  if (rows == 0) return RSP_OK;
+  int64_t blocks = (rows * (K / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(split_f16_kb32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
+                     reinterpret_cast<half_t*>(hi), reinterpret_cast<half_t*>(lo), rows, K,
+                     ldexpf(1.0f, scale_log2));
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
 int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s);  // gemm_dma.hip
 
 extern "C" int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream) {
@@ -285,6 +318,7 @@ extern "C" int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream) {
   if (!d.A && !(d.Ahi && d.Alo)) return RSP_EINVAL;
   if (!d.C && !(d.Chi && d.Clo)) return RSP_EINVAL;
   if ((d.Chi == nullptr) != (d.Clo == nullptr)) return RSP_EINVAL;
+  if (d.Chi && (d.c_rows <= 0 || (d.N & 31))) return RSP_EINVAL;
   if (d.M < 0 || d.N <= 0 || d.K <= 0 || (d.K % BK) != 0) return RSP_EINVAL;
   if (d.M == 0) return RSP_OK;
   if (d.conv_k != 0) {

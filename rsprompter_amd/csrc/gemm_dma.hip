@@ -3,6 +3,11 @@
 // register file: no staging VGPRs, no conversion VALU in the main loop.  Same arithmetic as
 // gemm.hip (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulate in v_mfma_f32_32x32x16_f16).
 //
+// HBM layout ("KB32"): a plane of a [rows, K] matrix is stored K-blocked as [K/32][rows][32 halves],
+// so the 128x32 (or 256x32) slice a K step needs is ONE contiguous run of full 128-B cache lines and
+// a wave-wide DMA instruction reads 1 KiB contiguously (no 64-B half-line gathers, no power-of-two
+// row stride hammering a single L2 channel).
+//
 // LDS image (per buffer): [A_hi | A_lo | B_hi | B_lo], each plane [rows][32 halves] = 64-B rows,
 // written lane-linearly by the DMA (wave-uniform base + lane*16).  A row-major 64-B-row tile would
 // be a 4-way bank conflict for the ds_read_b128 fragment reads (rows r and r+4 share a 16-B slot
@@ -45,7 +50,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // for NBUF-1 iterations later with a COUNTED s_waitcnt vmcnt (never 0 in steady state) + a raw
 // s_barrier, so HBM/L2 latency is covered by several K steps instead of one
 // (cdna_hip_programming.md §5 "Pipelining across barriers", T3+T4).
-template <int BM, int BN, int WGM, int WGN, int NBUF>
+// ABL: ablation switch for the tuning probe (0 = product kernel, 1 = skip the DMA inside the K loop,
+// 2 = skip the MFMAs); results are garbage for ABL != 0.
+template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const GemmP p) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -95,7 +102,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
       if (d.conv_k == 0) {
         const int srow = d.a_rowmap ? d.a_rowmap[gm] : gm;
         if (srow < 0) a_ok[i] = false;
-        a_src[i] += ((int64_t)srow * d.lda) * 2 + chunk * 16;
+        a_src[i] += (int64_t)srow * ROWB + chunk * 16;
       } else {
         const int hw = d.conv_Ho * d.conv_Wo;
         const int b = gm / hw;
@@ -119,9 +126,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
     const int chunk = (u & 3) ^ ((row >> 2) & 3);
     const uint16_t* base = plane == 0 ? d.Bhi : d.Blo;
     b_ok[i] = b_in[i] && (n0 + row < N);
-    b_src[i] = reinterpret_cast<const unsigned char*>(base) + ((int64_t)(n0 + row) * K) * 2 + chunk * 16;
+    b_src[i] = reinterpret_cast<const unsigned char*>(base) + (int64_t)(n0 + row) * ROWB + chunk * 16;
   }
 
+  const int64_t a_kstride = (int64_t)d.a_rows * ROWB;   // bytes between consecutive K blocks of an A plane
+  const int64_t b_kstride = (int64_t)N * ROWB;
   auto issue_tile = [&](int k0, int buf) {
     int ky = 0, kx = 0, c0 = 0;
     if (d.conv_k != 0) {
@@ -130,24 +139,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
       ky = tap / d.conv_k;
       kx = tap - ky * d.conv_k;
     }
+    const int kb = k0 / BK;
     unsigned char* lbase = &smem[buf][0];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const unsigned char* src = zero;
       if (a_ok[i]) {
         if (d.conv_k == 0) {
-          src = a_src[i] + (int64_t)k0 * 2;
+          src = a_src[i] + kb * a_kstride;
         } else {
           const int y = a_y[i] + ky, x = a_x[i] + kx;
           if (y >= 0 && y < d.conv_H && x >= 0 && x < d.conv_W)
-            src = a_src[i] + ((a_pix[i] + (int64_t)y * d.conv_W + x) * d.conv_C + c0) * 2 + a_chunkb[i];
+            src = a_src[i] + (c0 / BK) * a_kstride + (a_pix[i] + (int64_t)y * d.conv_W + x) * ROWB + a_chunkb[i];
         }
       }
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (i * NT + wave * 64) * 16), 16, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const unsigned char* src = b_ok[i] ? b_src[i] + (int64_t)k0 * 2 : zero;
+      const unsigned char* src = b_ok[i] ? b_src[i] + kb * b_kstride : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (A_UNITS + i * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
     else if (ahead == 1) wait_vmcnt<LPT>();
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();          // ... and everybody else's part; also: all reads of tile kt-1 are done
-    if (kt + NBUF - 1 < nk) {
+    if (ABL != 1 && kt + NBUF - 1 < nk) {
       int nb = buf + NBUF - 1;
       if (nb >= NBUF) nb -= NBUF;
       issue_tile((kt + NBUF - 1) * BK, nb);
@@ -211,9 +221,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          if (ABL == 2) {   // keep the fragments live without the matrix work
+            asm volatile("" ::"v"(al[i]), "v"(ah[i]), "v"(bl[j]), "v"(bh[j]));
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          }
         }
     }
     if (++buf == NBUF) buf = 0;
@@ -254,20 +268,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
         if (d.Chi) {
           half_t h, l;
           rsp_split1(v * cs, h, l);
-          reinterpret_cast<half_t*>(d.Chi)[(int64_t)crow * d.ldc + col] = h;
-          reinterpret_cast<half_t*>(d.Clo)[(int64_t)crow * d.ldc + col] = l;
+          const int64_t po = ((int64_t)(col >> 5) * d.c_rows + crow) * 32 + (col & 31);   // KB32 layout
+          reinterpret_cast<half_t*>(d.Chi)[po] = h;
+          reinterpret_cast<half_t*>(d.Clo)[po] = l;
         }
       }
     }
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NBUF>
+template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0>
 int launch_dma(const RspGemmDesc& d, hipStream_t s) {
   GemmP p; p.d = d;
   const long long nblk = (long long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
   if (nblk > 0x7fffffffLL) return RSP_EINVAL;
-  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
+  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF, ABL>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
@@ -276,8 +291,8 @@ int launch_dma(const RspGemmDesc& d, hipStream_t s) {
 
 // called from rsp_gemm (gemm.hip) when the descriptor carries A planes
 int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
-  if ((d.lda & 7) != 0) return RSP_EINVAL;   // 16-byte aligned fp16 rows
-  if (d.conv_k != 0 && (d.conv_C & 7) != 0) return RSP_EINVAL;
+  if (d.a_rows <= 0) return RSP_EINVAL;
+  if (d.conv_k != 0 && (d.conv_C % BK) != 0) return RSP_EINVAL;
   auto nblk = [&](int bm, int bn) { return (long long)((d.N + bn - 1) / bn) * ((d.M + bm - 1) / bm); };
   int tile = d.tile_hint;
   if (tile == 0) {   // pick the largest tile that still fills the 256 CUs reasonably
@@ -291,6 +306,10 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
     case 4: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2>(d, s); break;
     case 5: if (d.N > 64) return launch_dma<128, 128, 2, 2, 4>(d, s); break;
     case 6: if (d.N > 64) return launch_dma<128, 128, 2, 2, 3>(d, s); break;
+    case 7: if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 1>(d, s); break;   // ablation: no DMA
+    case 8: if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 2>(d, s); break;   // ablation: no MFMA
+    case 9: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 1>(d, s); break;
+    case 10: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 2>(d, s); break;
     default: break;
   }
   if (d.N > 64) return launch_dma<128, 128, 2, 2, 2>(d, s);

@@ -68,8 +68,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
           rsp_split1(o[j] * pscale, a, b);
           h4[j] = a; l4[j] = b;
         }
-        *reinterpret_cast<half4_t*>(yhi + row * C + c) = h4;
-        *reinterpret_cast<half4_t*>(ylo + row * C + c) = l4;
+        const int64_t po = ((int64_t)(c >> 5) * rows + row) * 32 + (c & 31);   // KB32 layout
+        *reinterpret_cast<half4_t*>(yhi + po) = h4;
+        *reinterpret_cast<half4_t*>(ylo + po) = l4;
       }
     }
   }
@@ -116,8 +117,9 @@ __global__ __launch_bounds__(256) void layernorm_small_kernel(const float* __res
     half4_t h4, l4;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { half_t a, bb; rsp_split1(o4[j] * pscale, a, bb); h4[j] = a; l4[j] = bb; }
-    *reinterpret_cast<half4_t*>(yhi + row * C + c) = h4;
-    *reinterpret_cast<half4_t*>(ylo + row * C + c) = l4;
+    const int64_t po = ((int64_t)(c >> 5) * rows + row) * 32 + (c & 31);   // KB32 layout
+    *reinterpret_cast<half4_t*>(yhi + po) = h4;
+    *reinterpret_cast<half4_t*>(ylo + po) = l4;
   }
 }
 
@@ -128,6 +130,7 @@ extern "C" int rsp_layernorm_ex(const float* x, const float* gamma, const float*
                                 float eps, int32_t act, rsp_stream_t stream) {
   if (!x || !gamma || !beta || rows < 0 || C <= 0 || (C & 3) || C > 2048) return RSP_EINVAL;
   if (!y && !(yhi && ylo)) return RSP_EINVAL;
+  if (yhi && (C & 31)) return RSP_EINVAL;
   if ((yhi == nullptr) != (ylo == nullptr)) return RSP_EINVAL;
   if (act != RSP_ACT_NONE && act != RSP_ACT_GELU) return RSP_EINVAL;
   if (rows == 0) return RSP_OK;

@@ -93,39 +93,54 @@ class PackedWeight:
         wd = w.contiguous().to(device)
         self.N, self.K = n, kpad
         self.scale_log2 = e
-        self.hi = torch.empty((n, kpad), dtype=torch.float16, device=device)
-        self.lo = torch.empty((n, kpad), dtype=torch.float16, device=device)
+        # KB32 layout [K/32][N][32]: every 32-wide K slice of the weight is one contiguous run
+        self.hi = torch.empty((kpad // 32, n, 32), dtype=torch.float16, device=device)
+        self.lo = torch.empty((kpad // 32, n, 32), dtype=torch.float16, device=device)
         lib = _lib.load()
-        _lib.check(lib.rsp_split_f16(wd.data_ptr(), self.hi.data_ptr(), self.lo.data_ptr(),
-                                     wd.numel(), e, _stream()), "rsp_split_f16")
+        _lib.check(lib.rsp_split_f16_kb32(wd.data_ptr(), self.hi.data_ptr(), self.lo.data_ptr(),
+                                          n, kpad, e, _stream()), "rsp_split_f16_kb32")
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
 
 
 class Planes:
-    """An fp32 matrix x held as two fp16 tensors: hi = f16(x * 2^e), lo = f16(x * 2^e - hi).
-    Same bytes as fp32; lets the GEMM stream its A operand HBM -> LDS with the DMA engine."""
+    """An fp32 matrix x [rows, K] held as two fp16 tensors hi = f16(x * 2^e), lo = f16(x * 2^e - hi) in the
+    K-blocked "KB32" layout [K/32][rows][32].  Same bytes as fp32; lets the GEMM stream its A operand
+    HBM -> LDS with the DMA engine in contiguous 1-KiB bursts.  `shape` is the LOGICAL shape
+    (leading dims are free to re-factor: rows = prod(shape[:-1]))."""
 
-    def __init__(self, hi, lo, scale_log2=DEFAULT_A_SCALE_LOG2):
-        self.hi, self.lo, self.scale_log2 = hi, lo, scale_log2
-
-    @property
-    def shape(self):
-        return self.hi.shape
+    def __init__(self, hi, lo, shape, scale_log2=DEFAULT_A_SCALE_LOG2):
+        self.hi, self.lo, self.shape, self.scale_log2 = hi, lo, tuple(shape), scale_log2
 
     @property
     def device(self):
         return self.hi.device
 
-    def view(self, *shape):
-        return Planes(self.hi.view(*shape), self.lo.view(*shape), self.scale_log2)
+    @property
+    def rows(self):
+        return self.hi.shape[1]
 
-    def reshape(self, *shape):
-        return Planes(self.hi.reshape(*shape), self.lo.reshape(*shape), self.scale_log2)
+    def view(self, *shape):
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else tuple(shape)
+        n = 1
+        for v in shape[:-1]:
+            n *= v
+        if shape[-1] != self.shape[-1] or n != self.rows:
+            raise ValueError(f'cannot view planes {self.shape} as {shape}')
+        return Planes(self.hi, self.lo, shape, self.scale_log2)
+
+    reshape = view
 
 
 def empty_planes(shape, device, scale_log2=DEFAULT_A_SCALE_LOG2):
-    return Planes(torch.empty(shape, dtype=torch.float16, device=device),
-                  torch.empty(shape, dtype=torch.float16, device=device), scale_log2)
+    shape = tuple(shape)
+    K = shape[-1]
+    if K % 32:
+        raise ValueError('planes need K % 32 == 0')
+    rows = 1
+    for v in shape[:-1]:
+        rows *= v
+    return Planes(torch.empty((K // 32, rows, 32), dtype=torch.float16, device=device),
+                  torch.empty((K // 32, rows, 32), dtype=torch.float16, device=device), shape, scale_log2)
 
 
 def to_planes(x, scale_log2=DEFAULT_A_SCALE_LOG2):
@@ -135,8 +150,8 @@ def to_planes(x, scale_log2=DEFAULT_A_SCALE_LOG2):
     x = x if x.is_contiguous() else x.contiguous()
     p = empty_planes(x.shape, x.device, scale_log2)
     _timed('split_f16_kernel', 0, 8.0 * x.numel(),
-           lambda: _lib.check(lib.rsp_split_f16(x.data_ptr(), p.hi.data_ptr(), p.lo.data_ptr(), x.numel(),
-                                                scale_log2, _stream()), "rsp_split_f16"))
+           lambda: _lib.check(lib.rsp_split_f16_kb32(x.data_ptr(), p.hi.data_ptr(), p.lo.data_ptr(), p.rows,
+                                                     x.shape[-1], scale_log2, _stream()), "rsp_split_f16_kb32"))
     return p
 
 
@@ -152,18 +167,16 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     if not isinstance(a, Planes):
         _chk_f32(a, "a")
         # the DMA fast path wants fp16 planes: convert once when the GEMM is big enough to amortise it
-        if dma is True or (dma == "auto" and w.N > 64 and w.K >= 128 and (a.is_contiguous() or a.dim() == 2)):
-            if a.dim() == 2 and a.stride(0) != a.shape[1]:
-                pass
-            else:
-                a = to_planes(a, a_scale_log2)
+        if (dma is True or (dma == "auto" and w.N > 64 and w.K >= 128)) and a.is_contiguous() \
+                and a.shape[-1] % 32 == 0:
+            a = to_planes(a, a_scale_log2)
     is_planes = isinstance(a, Planes)
     if is_planes:
         a_scale_log2 = a.scale_log2
     d = _lib.RspGemmDesc()
     if conv is not None:
         k, stride, pad = conv
-        if len(a.shape) != 4 or not (a.hi if is_planes else a).is_contiguous():
+        if len(a.shape) != 4 or not (is_planes or a.is_contiguous()):
             raise ValueError("conv gemm expects a contiguous NHWC tensor")
         B, H, W, C = a.shape
         Ho = (H + 2 * pad - k) // stride + 1
@@ -175,19 +188,18 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
         if w.K != k * k * C:
             raise ValueError(f"conv weight K={w.K} != {k}*{k}*{C}")
     else:
-        a0 = a.hi if is_planes else a
-        if a0.dim() != 2 or a0.stride(1) != 1:
+        if len(a.shape) != 2 or (not is_planes and a.stride(1) != 1):
             raise ValueError("gemm expects a 2-D row-major A")
-        m = a0.shape[0] if M is None else M
-        if a0.shape[1] != w.K:
-            raise ValueError(f"A has K={a0.shape[1]}, weight has K={w.K}")
-        d.lda = a0.stride(0)
+        m = a.shape[0] if M is None else M
+        if a.shape[1] != w.K:
+            raise ValueError(f"A has K={a.shape[1]}, weight has K={w.K}")
+        d.lda = a.shape[1] if is_planes else a.stride(0)
     n = w.N
     rows = m if out_rows is None else out_rows
     pl = None
     if out_planes:
         pl = empty_planes((rows, n), a.device)
-        d.Chi, d.Clo, d.c_scale_log2 = pl.hi.data_ptr(), pl.lo.data_ptr(), pl.scale_log2
+        d.Chi, d.Clo, d.c_scale_log2, d.c_rows = pl.hi.data_ptr(), pl.lo.data_ptr(), pl.scale_log2, rows
     if out is None and out_f32:
         out = torch.empty((rows, n), dtype=torch.float32, device=a.device)
     if out is not None:
@@ -198,7 +210,7 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
         _chk_f32(res, "res")
         d.ldr = res.stride(0)
     if is_planes:
-        d.Ahi, d.Alo = a.hi.data_ptr(), a.lo.data_ptr()
+        d.Ahi, d.Alo, d.a_rows = a.hi.data_ptr(), a.lo.data_ptr(), a.rows
     else:
         d.A = a.data_ptr()
     d.Bhi, d.Blo, d.C = w.hi.data_ptr(), w.lo.data_ptr(), _ptr(out)

@@ -25,14 +25,14 @@ def main():
     dev = torch.device('cuda:0')
     res = {}
     shapes = [(32768, 3072, 768), (32768, 768, 3072), (39200, 2304, 768), (32768, 768, 768), (8192, 8192, 8192),
-              (32768, 256, 768), (524288, 256, 2304), (3276800, 128, 256)]
+              (524288, 256, 2304)]
     for (M, N, K) in shapes:
         a = torch.randn(M, K, device=dev)
         ap = ops.to_planes(a)
         w = ops.PackedWeight(torch.randn(N, K) * 0.02, torch.zeros(N), device=dev)
         out = torch.empty(M, N, device=dev)
         row = {}
-        for hint in (1, 2, 3, 4, 5, 6):
+        for hint in (1, 2, 3, 8, 10):
             try:
                 t = timeit(lambda: ops.gemm(ap, w, out=out, tile_hint=hint))
                 row[f'dma_tile{hint}'] = round(2.0 * M * N * K / t / 1e12, 1)
