@@ -1,0 +1,56 @@
+"""CPU: the C-ABI shared library loads without a GPU and exports every entry point that
+include/rsp_hip.h declares (no compute calls); argument validation paths return RSP_EINVAL."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, 'include', 'rsp_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(rsp_[a-z0-9_]+)\s*\(', src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from rsprompter_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f'{n} declared in include/rsp_hip.h but not exported'
+    assert set(_lib.PROTOTYPES) <= set(names)
+    assert lib.rsp_abi_version() == 1
+    assert b'gfx950' in lib.rsp_build_info()
+
+
+def test_argument_validation_without_gpu():
+    from rsprompter_amd import _lib
+    lib = _lib.load()
+    EINVAL = -1
+    assert lib.rsp_gemm(None, None) == EINVAL
+    d = _lib.RspGemmDesc()
+    assert lib.rsp_gemm(ctypes.byref(d), None) == EINVAL          # null operands
+    assert lib.rsp_layernorm(None, None, None, None, 4, 64, 1e-6, 0, None) == EINVAL
+    assert lib.rsp_roi_align(None, None) == EINVAL
+    assert lib.rsp_attention(None, None) == EINVAL
+    assert lib.rsp_pack_bits(None, None, 64, None) == EINVAL
+    assert lib.rsp_nms_workspace_bytes(2, 5000) > 2 * 5000 * 79 * 8
+
+
+def test_ctypes_struct_matches_header_field_order():
+    """RspGemmDesc in _lib.py mirrors the C struct (same field names, same order)."""
+    from rsprompter_amd import _lib
+    src = open(os.path.join(ROOT, 'include', 'rsp_hip.h')).read()
+    body = re.search(r'typedef struct RspGemmDesc \{(.*?)\} RspGemmDesc;', src, re.S).group(1)
+    body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+    fields = []
+    for decl in body.split(';'):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(None, 2 if decl.startswith('const') else 1)[-1]
+        for n in names.split(','):
+            fields.append(n.strip().lstrip('*').strip())
+    assert fields == [f[0] for f in _lib.RspGemmDesc._fields_]
