@@ -154,6 +154,8 @@ typedef struct RspAttnDesc {
   int64_t o_bs, o_ts, o_hs;
   int32_t B, nh, dh, Tq, Tk;
   float scale;
+  /* optional fp16-plane (KB32) copy of a dense [B*Tq, nh*dh] output; `out` may then be NULL */
+  uint16_t* out_hi; uint16_t* out_lo; int32_t out_scale_log2;
 } RspAttnDesc;
 int rsp_attention(const RspAttnDesc* desc, rsp_stream_t stream);
 

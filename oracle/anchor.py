@@ -74,6 +74,22 @@ class FeatureAggregator(nn.Module):
         return self.fusion_conv(x)
 
 
+class PseudoAggregator(nn.Module):
+    """models.py:943-984."""
+
+    def __init__(self, cin=256, hidden=512, cout=256):
+        super().__init__()
+        from .vitsam import _LN2d
+        self.channel_fusion = nn.Sequential(
+            nn.Conv2d(cin, hidden, 1, bias=False), _LN2d(hidden, eps=1e-6),
+            nn.Conv2d(hidden, hidden, 3, padding=1, bias=False), _LN2d(hidden, eps=1e-6),
+            nn.Conv2d(hidden, cout, 3, padding=1, bias=False), _LN2d(cout, eps=1e-6))
+
+    def forward(self, inputs):
+        assert len(inputs) == 1
+        return self.channel_fusion(inputs[0])
+
+
 class SimpleFPN(nn.Module):
     """models.py:1278-1363 with norm_cfg=LN2d, act_cfg=None, num_outs=5."""
 
@@ -187,15 +203,22 @@ class AnchorOracle(nn.Module):
     """RSPrompterAnchor (MaskRCNN) predict path, configs/rsprompter/_base_/rsprompter_anchor.py."""
 
     def __init__(self, arch='base', num_classes=10, select_layers=None, hidden_channels=32,
-                 test_cfg=None):
+                 test_cfg=None, peft512=False):
+        """peft512=True: the rsprompter_anchor-*-peft-512.py tree (MMPretrainSamVisionEncoder at 512 px with
+        LoRA on qkv + PseudoFeatureAggregator(hidden 512)), models.py:812-878,943-984."""
         super().__init__()
         depth = hf_sam.ARCH[arch]['num_hidden_layers']
         select_layers = list(select_layers) if select_layers is not None else list(range(1, depth + 1, 2))
-        self.arch, self.num_classes = arch, num_classes
-        self.backbone = _Wrap('vision_encoder', hf_sam.build_vision_encoder(arch))
+        self.arch, self.num_classes, self.peft512 = arch, num_classes, peft512
         self.shared_image_embedding = _Wrap('shared_image_embedding', hf_sam.build_positional_embedding(arch))
         self.neck = nn.Module()
-        self.neck.feature_aggregator = FeatureAggregator(arch, hidden_channels, 256, select_layers)
+        if peft512:
+            from .vitsam import PeftWrapped, ViTSAM
+            self.backbone = _Wrap('vision_encoder', PeftWrapped(ViTSAM(arch, 512, lora=True)))
+            self.neck.feature_aggregator = PseudoAggregator(256, 512, 256)
+        else:
+            self.backbone = _Wrap('vision_encoder', hf_sam.build_vision_encoder(arch))
+            self.neck.feature_aggregator = FeatureAggregator(arch, hidden_channels, 256, select_layers)
         self.neck.feature_spliter = SimpleFPN()
         self.rpn_head = RPNHead()
         self.roi_head = RoIHead(num_classes)
@@ -210,7 +233,11 @@ class AnchorOracle(nn.Module):
     @torch.no_grad()
     def extract_feat(self, batch_inputs):
         """models.py:97-114."""
-        emb, hidden = hf_sam.run_vision_encoder(self.backbone.vision_encoder, batch_inputs)
+        if self.peft512:
+            hidden = self.backbone.vision_encoder(batch_inputs)      # 1-tuple (models.py:102-104)
+            emb = hidden[0]
+        else:
+            emb, hidden = hf_sam.run_vision_encoder(self.backbone.vision_encoder, batch_inputs)
         G = self.shared_image_embedding.shared_image_embedding.positional_embedding
         ipe = glue.image_wide_positional_embeddings(G, emb.shape[-1]).repeat(emb.shape[0], 1, 1, 1)
         agg = self.neck.feature_aggregator(hidden)

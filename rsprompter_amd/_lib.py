@@ -44,6 +44,7 @@ class RspAttnDesc(ctypes.Structure):
         ("o_bs", c_int64), ("o_ts", c_int64), ("o_hs", c_int64),
         ("B", c_int), ("nh", c_int), ("dh", c_int), ("Tq", c_int), ("Tk", c_int),
         ("scale", c_float),
+        ("out_hi", c_void_p), ("out_lo", c_void_p), ("out_scale_log2", c_int),
     ]
 
 

@@ -437,7 +437,7 @@ extern "C" int rsp_vit_attention_ex(const float* qkv, const float* rel, float* o
 }
 
 extern "C" int rsp_attention(const RspAttnDesc* d, rsp_stream_t stream) {
-  if (!d || !d->q || !d->k || !d->v || !d->out) return RSP_EINVAL;
+  if (!d || !d->q || !d->k || !d->v || (!d->out && !d->out_hi)) return RSP_EINVAL;
   if (d->B <= 0 || d->nh <= 0 || d->Tq <= 0 || d->Tk <= 0) return RSP_EINVAL;
   if ((d->q_ts & 3) || (d->k_ts & 3) || (d->v_ts & 3) || (d->o_ts & 3) || (d->q_hs & 3) ||
       (d->k_hs & 3) || (d->v_hs & 3) || (d->o_hs & 3))
@@ -445,7 +445,13 @@ extern "C" int rsp_attention(const RspAttnDesc* d, rsp_stream_t stream) {
   AttnP p;
   p.q = d->q; p.k = d->k; p.v = d->v; p.rel = nullptr; p.out = d->out;
   p.kv_batch_map = d->kv_batch_map; p.q_batch_map = d->q_batch_map;
-  p.out_hi = nullptr; p.out_lo = nullptr; p.out_pscale = 1.0f; p.out_rows = 0;
+  p.out_hi = reinterpret_cast<half_t*>(d->out_hi); p.out_lo = reinterpret_cast<half_t*>(d->out_lo);
+  p.out_pscale = ldexpf(1.0f, d->out_scale_log2); p.out_rows = (int64_t)d->B * d->Tq;
+  if (p.out_hi) {   // plane copy assumes a dense [B*Tq, nh*dh] output matrix
+    if (!p.out_lo || d->o_hs != d->dh || d->o_ts != (int64_t)d->nh * d->dh || d->o_bs != d->o_ts * d->Tq ||
+        ((d->nh * d->dh) & 31))
+      return RSP_EINVAL;
+  }
   p.q_bs = d->q_bs; p.q_ts = d->q_ts; p.q_hs = d->q_hs;
   p.k_bs = d->k_bs; p.k_ts = d->k_ts; p.k_hs = d->k_hs;
   p.v_bs = d->v_bs; p.v_ts = d->v_ts; p.v_hs = d->v_hs;

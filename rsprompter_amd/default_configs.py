@@ -72,3 +72,20 @@ def rsprompter_anchor(arch='base', num_classes=10, prompt_shape=(70, 5), pretrai
                                min_bbox_size=0),
                       rcnn=dict(score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100,
                                 mask_thr_binary=0.5)))
+
+
+def rsprompter_anchor_peft512(arch='base', num_classes=10, prompt_shape=(60, 5), pretrain_name=None, ckpt=None):
+    """configs/rsprompter/rsprompter_anchor-nwpu-peft-512.py: ViTSAM at 512 px + LoRA(qkv) + PseudoFeatureAggregator."""
+    m = rsprompter_anchor(arch, num_classes, prompt_shape, pretrain_name, ckpt)
+    name = pretrain_name or f'work_dirs/sam_cache/sam_vit_{arch}'
+    init = dict(type='Pretrained', checkpoint=ckpt or f'{name}/pytorch_model.bin')
+    crop = (512, 512)
+    m['data_preprocessor']['batch_augments'][0]['size'] = crop
+    m['backbone'] = dict(type='MMPretrainSamVisionEncoder', hf_pretrain_name=name, img_size=crop[0],
+                         init_cfg=init,
+                         peft_config=dict(peft_type='LORA', r=16, target_modules=['qkv'], lora_alpha=32,
+                                          lora_dropout=0.05, bias='none'))
+    m['neck']['feature_aggregator'] = dict(type='PseudoFeatureAggregator', in_channels=256, hidden_channels=512,
+                                           out_channels=256)
+    m['train_cfg']['rcnn']['mask_size'] = crop
+    return m

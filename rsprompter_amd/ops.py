@@ -355,11 +355,14 @@ def _gemm_ct(a, w, out, bias, act, ct_W, ct_dy, a_scale_log2):
 
 
 def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v_strides, o_strides,
-              kv_batch_map=None, q_batch_map=None):
-    """Generic strided multi-head attention (RspAttnDesc). strides = (batch, token, head) in elements."""
+              kv_batch_map=None, q_batch_map=None, out_planes=None):
+    """Generic strided multi-head attention (RspAttnDesc). strides = (batch, token, head) in elements.
+    out_planes: optional Planes receiving a KB32 copy of the dense [B*Tq, nh*dh] output (out may be None)."""
     lib = _lib.load()
     d = _lib.RspAttnDesc()
-    d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr()
+    d.q, d.k, d.v, d.out = q.data_ptr(), k.data_ptr(), v.data_ptr(), _ptr(out)
+    if out_planes is not None:
+        d.out_hi, d.out_lo, d.out_scale_log2 = out_planes.hi.data_ptr(), out_planes.lo.data_ptr(), out_planes.scale_log2
     d.kv_batch_map = _ptr(kv_batch_map)
     d.q_batch_map = _ptr(q_batch_map)
     d.q_bs, d.q_ts, d.q_hs = q_strides
@@ -369,7 +372,7 @@ def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v
     d.B, d.nh, d.dh, d.Tq, d.Tk, d.scale = B, nh, dh, Tq, Tk, scale
     _timed('attn_kernel<sam_decoder>', 4.0 * B * nh * Tq * Tk * dh, 0,
            lambda: _lib.check(lib.rsp_attention(d, _stream()), "rsp_attention"))
-    return out
+    return out if out_planes is None else out_planes
 
 
 def roi_align(feats_nhwc, pes, rois, P, strides, finest_scale=56):

@@ -123,9 +123,9 @@ class SamMaskDecoderHIP(HIPModule):
         return self._pe_cache[key]
 
     # ------------------------------------------------------------------ pieces
-    def _ln(self, x, name, eps=1e-6):
+    def _ln(self, x, name, eps=1e-6, planes=False):
         m = _g(self, name)
-        return ops.layernorm(x, m.weight, m.bias, eps)
+        return ops.layernorm(x, m.weight, m.bias, eps, planes=planes)
 
     def _token_attn(self, q_in, k_in, v_in, pfx, R, T, res=None):
         """SamAttention among the T prompt tokens of each RoI (self attention, internal dim 256)."""
@@ -164,6 +164,7 @@ class SamMaskDecoderHIP(HIPModule):
         tokens0 = tokens0.reshape(R * T, HID).contiguous()
         # keys of layer 0: image embedding + dense prompt, ONE copy per image (HF:499)
         src = ops.add_rows(emb.reshape(B * N, C), dense_vec.reshape(1, C), vmod=1)
+        src_pl = ops.to_planes(src)
 
         # ---------------- layer 0 (HF:306-348 with skip_first_layer_pe) ----------------
         q = self._token_attn(tokens0, tokens0, tokens0, '0.self_attn', R, T)          # replaces queries
@@ -171,9 +172,9 @@ class SamMaskDecoderHIP(HIPModule):
         # tokens -> image
         qpe = ops.add_rows(q, tokens0)
         tq = ops.gemm(qpe, P['0.cross_attn_token_to_image.q_proj'])
-        k_img = ops.gemm(src, P['0.cross_attn_token_to_image.k_proj'], bias=None,
+        k_img = ops.gemm(src_pl, P['0.cross_attn_token_to_image.k_proj'], bias=None,
                          res=pe_t['0.cross_attn_token_to_image.k_proj'], res_mod=N)      # per image
-        v_img = ops.gemm(src, P['0.cross_attn_token_to_image.v_proj'])
+        v_img = ops.gemm(src_pl, P['0.cross_attn_token_to_image.v_proj'])
         ao = torch.empty_like(tq)
         ops.attention(tq, k_img, v_img, ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
                       q_strides=(T * d2, d2, dh2), k_strides=(N * d2, d2, dh2), v_strides=(N * d2, d2, dh2),
@@ -185,17 +186,17 @@ class SamMaskDecoderHIP(HIPModule):
         q = self._ln(q, 'transformer.layers.0.layer_norm3')
         # image -> tokens: image-side queries are per image, keys/values per RoI
         qpe = ops.add_rows(q, tokens0)
-        qi = ops.gemm(src, P['0.cross_attn_image_to_token.q_proj'], bias=None,
+        qi = ops.gemm(src_pl, P['0.cross_attn_image_to_token.q_proj'], bias=None,
                       res=pe_t['0.cross_attn_image_to_token.q_proj'], res_mod=N)
         kt = ops.gemm(qpe, P['0.cross_attn_image_to_token.k_proj'])
         vt = ops.gemm(q, P['0.cross_attn_image_to_token.v_proj'])
-        ai = torch.empty((R * N, d2), dtype=torch.float32, device=dev)
-        ops.attention(qi, kt, vt, ai, B=R, nh=HEADS, dh=dh2, Tq=N, Tk=T, scale=dh2 ** -0.5,
+        ai = ops.empty_planes((R * N, d2), dev)      # attention output goes straight to the out_proj GEMM as planes
+        ops.attention(qi, kt, vt, None, B=R, nh=HEADS, dh=dh2, Tq=N, Tk=T, scale=dh2 ** -0.5,
                       q_strides=(N * d2, d2, dh2), k_strides=(T * d2, d2, dh2), v_strides=(T * d2, d2, dh2),
-                      o_strides=(N * d2, d2, dh2), q_batch_map=roi_img)
+                      o_strides=(N * d2, d2, dh2), q_batch_map=roi_img, out_planes=ai)
         keys = ops.gemm(ai, P['0.cross_attn_image_to_token.out_proj'], res=src, res_bmap=roi_img, res_brows=N)
-        keys = self._ln(keys, 'transformer.layers.0.layer_norm4')                        # [R*N, 256]
-        del ai, qi, k_img, v_img
+        keys, keys_pl = self._ln(keys, 'transformer.layers.0.layer_norm4', planes=True)   # [R*N, 256] f32 + planes
+        del qi, k_img, v_img
 
         # ---------------- layer 1 ----------------
         qpe = ops.add_rows(q, tokens0)
@@ -203,9 +204,9 @@ class SamMaskDecoderHIP(HIPModule):
         q = self._ln(q, 'transformer.layers.1.layer_norm1')
         qpe = ops.add_rows(q, tokens0)
         tq = ops.gemm(qpe, P['1.cross_attn_token_to_image.q_proj'])
-        kk = ops.gemm(keys, P['1.cross_attn_token_to_image.k_proj'], bias=None,
+        kk = ops.gemm(keys_pl, P['1.cross_attn_token_to_image.k_proj'], bias=None,
                       res=pe_t['1.cross_attn_token_to_image.k_proj'], res_mod=N)
-        vv = ops.gemm(keys, P['1.cross_attn_token_to_image.v_proj'])
+        vv = ops.gemm(keys_pl, P['1.cross_attn_token_to_image.v_proj'])
         ops.attention(tq, kk, vv, ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
                       q_strides=(T * d2, d2, dh2), k_strides=(N * d2, d2, dh2), v_strides=(N * d2, d2, dh2),
                       o_strides=(T * d2, d2, dh2))
@@ -215,28 +216,27 @@ class SamMaskDecoderHIP(HIPModule):
         q = ops.gemm(hmid, P['1.lin2'], res=q)
         q = self._ln(q, 'transformer.layers.1.layer_norm3')
         qpe = ops.add_rows(q, tokens0)
-        qi = ops.gemm(keys, P['1.cross_attn_image_to_token.q_proj'], bias=None,
+        qi = ops.gemm(keys_pl, P['1.cross_attn_image_to_token.q_proj'], bias=None,
                       res=pe_t['1.cross_attn_image_to_token.q_proj'], res_mod=N)
         kt = ops.gemm(qpe, P['1.cross_attn_image_to_token.k_proj'])
         vt = ops.gemm(q, P['1.cross_attn_image_to_token.v_proj'])
-        ai = kk  # reuse the [R*N, 128] buffer
-        ops.attention(qi, kt, vt, ai, B=R, nh=HEADS, dh=dh2, Tq=N, Tk=T, scale=dh2 ** -0.5,
+        ops.attention(qi, kt, vt, None, B=R, nh=HEADS, dh=dh2, Tq=N, Tk=T, scale=dh2 ** -0.5,
                       q_strides=(N * d2, d2, dh2), k_strides=(T * d2, d2, dh2), v_strides=(T * d2, d2, dh2),
-                      o_strides=(N * d2, d2, dh2))
+                      o_strides=(N * d2, d2, dh2), out_planes=ai)
         keys = ops.gemm(ai, P['1.cross_attn_image_to_token.out_proj'], res=keys)
-        keys = self._ln(keys, 'transformer.layers.1.layer_norm4')
+        keys, keys_pl = self._ln(keys, 'transformer.layers.1.layer_norm4', planes=True)
 
         # ---------------- final token -> image attention (HF:396-404; LayerNorm default eps 1e-5) ----
         qpe = ops.add_rows(q, tokens0)
         tq = ops.gemm(qpe, P['final.q_proj'])
-        kk = ops.gemm(keys, P['final.k_proj'], bias=None, res=pe_t['final.k_proj'], res_mod=N, out=kk)
-        vv = ops.gemm(keys, P['final.v_proj'], out=vv)
+        kk = ops.gemm(keys_pl, P['final.k_proj'], bias=None, res=pe_t['final.k_proj'], res_mod=N, out=kk)
+        vv = ops.gemm(keys_pl, P['final.v_proj'], out=vv)
         ops.attention(tq, kk, vv, ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
                       q_strides=(T * d2, d2, dh2), k_strides=(N * d2, d2, dh2), v_strides=(N * d2, d2, dh2),
                       o_strides=(T * d2, d2, dh2))
         q = ops.gemm(ao, P['final.out_proj'], res=q)
         q = self._ln(q, 'transformer.layer_norm_final_attn', eps=1e-5)
-        del kk, vv, qi
+        del kk, vv, qi, ai, keys_pl
         q3 = q.view(R, T, HID)
 
         # ---------------- upscaling + hyper-network (HF:513-531) ----------------

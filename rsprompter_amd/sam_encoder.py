@@ -44,10 +44,29 @@ def resize_rel_pos(rel_pos, size):
     return r.reshape(-1, n).permute(1, 0).contiguous()
 
 
+NAMES = {
+    # HuggingFace SamVisionEncoder attribute paths (HF:1013-1072) ...
+    'hf': dict(ln1='layer_norm1', ln2='layer_norm2', lin1='mlp.lin1', lin2='mlp.lin2', conv1='neck.conv1',
+               nln1='neck.layer_norm1', conv2='neck.conv2', nln2='neck.layer_norm2'),
+    # ... and the in-repo mmpretrain ViTSAM's (vit_sam.py:224-313,514-530; key renames models.py:840-851)
+    'mmpretrain': dict(ln1='ln1', ln2='ln2', lin1='ffn.layers.0.0', lin2='ffn.layers.1',
+                       conv1='channel_reduction.0', nln1='channel_reduction.1', conv2='channel_reduction.2',
+                       nln2='channel_reduction.3'),
+}
+
+
+def _get(root, dotted):
+    for part in dotted.split('.'):
+        root = getattr(root, part)
+    return root
+
+
 class SamVisionEncoderHIP(HIPModule):
     def __init__(self, arch='base', image_size=1024, patch_size=16, window_size=14,
-                 out_channels=256, output_hidden_states=False, layer_norm_eps=1e-6):
+                 out_channels=256, output_hidden_states=False, layer_norm_eps=1e-6, naming='hf'):
         super().__init__()
+        self.nm = NAMES[naming]
+        nm = self.nm
         a = SAM_ARCH[arch]
         self.arch = arch
         self.D, self.depth, self.heads = a['hidden'], a['depth'], a['heads']
@@ -65,26 +84,26 @@ class SamVisionEncoderHIP(HIPModule):
         for i in range(self.depth):
             s = g if i in self.global_idx else window_size
             p = f'layers.{i}.'
-            add_param(self, p + 'layer_norm1.weight', (D,), 1.0)
-            add_param(self, p + 'layer_norm1.bias', (D,))
+            add_param(self, p + nm['ln1'] + '.weight', (D,), 1.0)
+            add_param(self, p + nm['ln1'] + '.bias', (D,))
             add_param(self, p + 'attn.qkv.weight', (3 * D, D))
             add_param(self, p + 'attn.qkv.bias', (3 * D,))
             add_param(self, p + 'attn.proj.weight', (D, D))
             add_param(self, p + 'attn.proj.bias', (D,))
             add_param(self, p + 'attn.rel_pos_h', (2 * s - 1, self.dh))
             add_param(self, p + 'attn.rel_pos_w', (2 * s - 1, self.dh))
-            add_param(self, p + 'layer_norm2.weight', (D,), 1.0)
-            add_param(self, p + 'layer_norm2.bias', (D,))
-            add_param(self, p + 'mlp.lin1.weight', (self.mlp_dim, D))
-            add_param(self, p + 'mlp.lin1.bias', (self.mlp_dim,))
-            add_param(self, p + 'mlp.lin2.weight', (D, self.mlp_dim))
-            add_param(self, p + 'mlp.lin2.bias', (D,))
-        add_param(self, 'neck.conv1.weight', (out_channels, D, 1, 1))
-        add_param(self, 'neck.layer_norm1.weight', (out_channels,), 1.0)
-        add_param(self, 'neck.layer_norm1.bias', (out_channels,))
-        add_param(self, 'neck.conv2.weight', (out_channels, out_channels, 3, 3))
-        add_param(self, 'neck.layer_norm2.weight', (out_channels,), 1.0)
-        add_param(self, 'neck.layer_norm2.bias', (out_channels,))
+            add_param(self, p + nm['ln2'] + '.weight', (D,), 1.0)
+            add_param(self, p + nm['ln2'] + '.bias', (D,))
+            add_param(self, p + nm['lin1'] + '.weight', (self.mlp_dim, D))
+            add_param(self, p + nm['lin1'] + '.bias', (self.mlp_dim,))
+            add_param(self, p + nm['lin2'] + '.weight', (D, self.mlp_dim))
+            add_param(self, p + nm['lin2'] + '.bias', (D,))
+        add_param(self, nm['conv1'] + '.weight', (out_channels, D, 1, 1))
+        add_param(self, nm['nln1'] + '.weight', (out_channels,), 1.0)
+        add_param(self, nm['nln1'] + '.bias', (out_channels,))
+        add_param(self, nm['conv2'] + '.weight', (out_channels, out_channels, 3, 3))
+        add_param(self, nm['nln2'] + '.weight', (out_channels,), 1.0)
+        add_param(self, nm['nln2'] + '.bias', (out_channels,))
         self.lora = None  # optional dict name -> (A [r,D], B [3D,r], scale), merged at pack time
         self._maps = {}
 
@@ -99,6 +118,9 @@ class SamVisionEncoderHIP(HIPModule):
         P['layers'] = []
         for i in range(self.depth):
             L = getattr(self.layers, str(i))
+            nm = self.nm
+            ln1, ln2 = _get(L, nm['ln1']), _get(L, nm['ln2'])
+            lin1, lin2 = _get(L, nm['lin1']), _get(L, nm['lin2'])
             s = self.grid if i in self.global_idx else self.window_size
             wq = L.attn.qkv.weight.detach()
             if self.lora is not None and i in self.lora:
@@ -106,20 +128,22 @@ class SamVisionEncoderHIP(HIPModule):
                 wq = wq + sc * (Bm.to(wq) @ A.to(wq))   # load-time merge W += (alpha/r) B A (models.py:785-797)
             P['layers'].append(dict(
                 S=s,
-                ln1=(L.layer_norm1.weight.detach(), L.layer_norm1.bias.detach()),
-                ln2=(L.layer_norm2.weight.detach(), L.layer_norm2.bias.detach()),
+                ln1=(ln1.weight.detach(), ln1.bias.detach()),
+                ln2=(ln2.weight.detach(), ln2.bias.detach()),
                 qkv=ops.PackedWeight(wq, L.attn.qkv.bias),
                 proj=ops.PackedWeight(L.attn.proj.weight, L.attn.proj.bias),
-                lin1=ops.PackedWeight(L.mlp.lin1.weight, L.mlp.lin1.bias),
-                lin2=ops.PackedWeight(L.mlp.lin2.weight, L.mlp.lin2.bias),
+                lin1=ops.PackedWeight(lin1.weight, lin1.bias),
+                lin2=ops.PackedWeight(lin2.weight, lin2.bias),
                 rph=resize_rel_pos(L.attn.rel_pos_h.detach(), s).contiguous(),
                 rpw=resize_rel_pos(L.attn.rel_pos_w.detach(), s).contiguous(),
             ))
-        P['neck1'] = ops.PackedWeight(self.neck.conv1.weight.reshape(self.out_channels, self.D))
+        nm = self.nm
+        c1, c2, n1, n2 = (_get(self, nm[k]) for k in ('conv1', 'conv2', 'nln1', 'nln2'))
+        P['neck1'] = ops.PackedWeight(c1.weight.reshape(self.out_channels, self.D))
         # 3x3 conv weight [O, I, ky, kx] -> [O, (ky, kx, I)] to match the NHWC implicit-GEMM K order
-        P['neck2'] = ops.PackedWeight(self.neck.conv2.weight.permute(0, 2, 3, 1).reshape(self.out_channels, -1))
-        P['nln1'] = (self.neck.layer_norm1.weight.detach(), self.neck.layer_norm1.bias.detach())
-        P['nln2'] = (self.neck.layer_norm2.weight.detach(), self.neck.layer_norm2.bias.detach())
+        P['neck2'] = ops.PackedWeight(c2.weight.permute(0, 2, 3, 1).reshape(self.out_channels, -1))
+        P['nln1'] = (n1.weight.detach(), n1.bias.detach())
+        P['nln2'] = (n2.weight.detach(), n2.bias.detach())
         self._packed = P
         self._maps = {}
 
@@ -196,8 +220,68 @@ class SamVisionEncoderHIP(HIPModule):
         return SamVisionEncoderOutput(emb, hs)
 
 
+def _lora_defaults(peft_config):
+    """the reference's LoRA defaults (models.py:786-795 / 855-864): r=16, alpha=32, target qkv."""
+    cfg = dict(r=16, lora_alpha=32, target_modules=['qkv'])
+    cfg.update(peft_config or {})
+    if list(cfg.get('target_modules', ['qkv'])) != ['qkv']:
+        raise NotImplementedError('only LoRA on `qkv` (the reference configuration) is implemented')
+    return cfg
+
+
+class _PeftKeyLayout:
+    """state_dict key translation between this module and the peft 0.8.2 wrapper layout the reference
+    checkpoints use: `<prefix>base_model.model.<path>` and `qkv.base_layer.*`."""
+
+    def _install_peft_hooks(self):
+        self._register_load_state_dict_pre_hook(self._peft_load_hook)
+        self._register_state_dict_hook(self._peft_save_hook)
+
+    def _peft_load_hook(self, state_dict, prefix, *args):
+        root = prefix + 'vision_encoder.'
+        for k in [k for k in state_dict if k.startswith(root + 'base_model.model.')]:
+            nk = root + k[len(root + 'base_model.model.'):].replace('.qkv.base_layer.', '.qkv.')
+            state_dict[nk] = state_dict.pop(k)
+
+    @staticmethod
+    def _peft_save_hook(module, state_dict, prefix, local_metadata):
+        root = prefix + 'vision_encoder.'
+        for k in [k for k in state_dict if k.startswith(root)]:
+            tail = k[len(root):]
+            if tail.startswith('base_model.model.'):
+                continue
+            if '.attn.qkv.weight' in tail or '.attn.qkv.bias' in tail:
+                tail = tail.replace('.attn.qkv.', '.attn.qkv.base_layer.')
+            state_dict[root + 'base_model.model.' + tail] = state_dict.pop(k)
+        return state_dict
+
+
+def _attach_lora(enc, peft_config):
+    cfg = _lora_defaults(peft_config)
+    r = cfg['r']
+    enc.lora_scale = cfg['lora_alpha'] / r
+    for i in range(enc.depth):
+        add_param(enc, f'layers.{i}.attn.qkv.lora_A.default.weight', (r, enc.D))
+        add_param(enc, f'layers.{i}.attn.qkv.lora_B.default.weight', (3 * enc.D, r))
+    enc.lora = _LoraView(enc)
+
+
+def _resize_on_load(enc, state_dict, prefix):
+    """load-time interpolation of pos_embed (bicubic) and rel_pos_* (linear) when the checkpoint was
+    trained at another resolution (vit_sam.py:612-662, mmpretrain/models/utils/embed.py:16-59)."""
+    name = prefix + 'pos_embed'
+    if name in state_dict and tuple(state_dict[name].shape) != tuple(enc.pos_embed.shape):
+        src = state_dict[name].float().permute(0, 3, 1, 2)
+        dst = torch.nn.functional.interpolate(src, size=enc.pos_embed.shape[1:3], align_corners=False, mode='bicubic')
+        state_dict[name] = dst.permute(0, 2, 3, 1).contiguous()
+    own = enc.state_dict()
+    for k, cur in own.items():
+        if 'rel_pos_' in k and prefix + k in state_dict and state_dict[prefix + k].shape[0] != cur.shape[0]:
+            state_dict[prefix + k] = resize_rel_pos(state_dict[prefix + k].float(), (cur.shape[0] + 1) // 2)
+
+
 @MODELS.register_module()
-class RSSamVisionEncoder(HIPModule):
+class RSSamVisionEncoder(HIPModule, _PeftKeyLayout):
     """Registry-compatible wrapper (reference models.py:762-809)."""
 
     def __init__(self, hf_pretrain_name, extra_config=None, peft_config=None, init_cfg=None):
@@ -211,22 +295,42 @@ class RSSamVisionEncoder(HIPModule):
                                  revise_keys=[(r'^module\.', ''), (r'^vision_encoder\.', '')])
         self.peft_config = peft_config
         if peft_config is not None and isinstance(peft_config, dict):
-            self._add_lora(peft_config)
+            _attach_lora(self.vision_encoder, peft_config)
+            self._install_peft_hooks()
         self.vision_encoder.is_init = True
-
-    def _add_lora(self, peft_config):
-        cfg = dict(r=16, lora_alpha=32)
-        cfg.update(peft_config)
-        r = cfg['r']
-        enc = self.vision_encoder
-        enc.lora_scale = cfg['lora_alpha'] / r
-        for i in range(enc.depth):
-            add_param(enc, f'layers.{i}.attn.qkv.lora_A.default.weight', (r, enc.D))
-            add_param(enc, f'layers.{i}.attn.qkv.lora_B.default.weight', (3 * enc.D, r))
-        enc.lora = _LoraView(enc)
 
     def forward(self, *args, **kwargs):
         return self.vision_encoder(*args, **kwargs)
+
+
+@MODELS.register_module()
+class MMPretrainSamVisionEncoder(HIPModule, _PeftKeyLayout):
+    """models.py:812-878: the in-repo mmpretrain `ViTSAM` (vit_sam.py:317-602) at `img_size` (512 in the
+    *-peft-512 configs: 32x32 grid, 3x3 windows of 14 on the padded 42x42 grid, global S=32), LoRA on qkv,
+    returning the 1-tuple (channel_reduction output,) that extract_feat expects (models.py:102-104)."""
+
+    def __init__(self, hf_pretrain_name, img_size=1024, peft_config=None, init_cfg=None):
+        super().__init__()
+        arch = str(hf_pretrain_name).split('-')[-1].split('_')[-1]      # models.py:824
+        if arch not in SAM_ARCH:
+            arch = infer_sam_arch(hf_pretrain_name)
+        self.vision_encoder = SamVisionEncoderHIP(arch=arch, image_size=img_size, naming='mmpretrain')
+        enc = self.vision_encoder
+        enc._register_load_state_dict_pre_hook(lambda sd, prefix, *a: _resize_on_load(enc, sd, prefix))
+        if init_cfg is not None:
+            load_checkpoint_into(enc, init_cfg.get('checkpoint'), revise_keys=[
+                (r'^module\.', ''), (r'^vision_encoder\.', ''), (r'.layer_norm1.', '.ln1.'),
+                (r'.layer_norm2.', '.ln2.'), (r'.mlp.lin1.', '.ffn.layers.0.0.'), (r'.mlp.lin2.', '.ffn.layers.1.'),
+                (r'neck.conv1.', 'channel_reduction.0.'), (r'neck.ln1.', 'channel_reduction.1.'),
+                (r'neck.conv2.', 'channel_reduction.2.'), (r'neck.ln2.', 'channel_reduction.3.')])
+        if peft_config is not None and isinstance(peft_config, dict):
+            _attach_lora(enc, peft_config)
+            self._install_peft_hooks()
+        enc.is_init = True
+
+    def forward(self, x):
+        out = self.vision_encoder(x, output_hidden_states=False)
+        return (out[0],)
 
 
 class _LoraView:

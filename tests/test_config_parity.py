@@ -44,6 +44,30 @@ def test_reference_anchor_configs_build(fname, arch, nc, ps):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
+def test_reference_peft512_config_builds_with_peft_key_layout():
+    import rsprompter_amd as ra
+    from rsprompter_amd.default_configs import rsprompter_anchor_peft512
+    cfg = ra.Config.fromfile(os.path.join(REF, 'rsprompter_anchor-nwpu-peft-512.py'))
+    assert _norm(cfg.model) == _norm(rsprompter_anchor_peft512('base', 10, (70, 5)))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = ra.build_model(cfg)
+    keys = set(m.state_dict())
+    p = 'backbone.vision_encoder.base_model.model.'          # peft 0.8.2 wrapper layout
+    for k in [p + 'layers.0.attn.qkv.base_layer.weight', p + 'layers.0.attn.qkv.lora_A.default.weight',
+              p + 'layers.3.attn.qkv.lora_B.default.weight', p + 'layers.0.ffn.layers.0.0.weight',
+              p + 'channel_reduction.3.bias', p + 'pos_embed', 'neck.feature_aggregator.channel_fusion.4.weight']:
+        assert k in keys, k
+    assert tuple(m.state_dict()[p + 'pos_embed'].shape) == (1, 32, 32, 768)
+    assert tuple(m.state_dict()[p + 'layers.2.attn.rel_pos_h'].shape) == (63, 64)      # global layer at 512 px
+    # load-time interpolation of a 1024-px checkpoint (vit_sam.py:612-662)
+    import torch
+    sd = {p + 'pos_embed': torch.randn(1, 64, 64, 768), p + 'layers.2.attn.rel_pos_h': torch.randn(127, 64)}
+    m.backbone.load_state_dict({k[len('backbone.'):]: v for k, v in sd.items()}, strict=False)
+    assert tuple(m.backbone.vision_encoder.pos_embed.shape) == (1, 32, 32, 768)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
 def test_config_loader_base_and_delete():
     import rsprompter_amd as ra
     cfg = ra.Config.fromfile(os.path.join(REF, 'rsprompter_anchor-nwpu-peft-512.py'))

@@ -195,3 +195,41 @@ def test_end_to_end_predict(setup, dev):
               f'score err {sc_err:.2e}, mask mismatch {mism:.2e}')
         assert pi.labels.shape[0] == k
         assert lab_eq == 1.0 and sc_err < 1e-4 and box_err < 1e-2 and mism < 1e-3
+
+
+def test_peft512_variant_end_to_end(dev):
+    """BASELINE.json configs[0] tree: rsprompter_anchor, ViT-B at 512 px (mmpretrain ViTSAM) + LoRA(qkv) +
+    PseudoFeatureAggregator, one 512x512 tile; HIP vs CPU oracle on identical seeded weights (LoRA B non-zero)."""
+    import warnings
+    import rsprompter_amd as ra
+    from oracle import glue
+    from oracle.anchor import AnchorOracle
+    from rsprompter_amd.default_configs import rsprompter_anchor_peft512
+    from rsprompter_amd.structures import DetDataSample
+    from rsprompter_amd.synth import synth_images, synth_metas, synth_state_dict
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = ra.build_model(rsprompter_anchor_peft512('base', 10))
+    oracle = AnchorOracle('base', 10, peft512=True)
+    sd = synth_state_dict(oracle, seed=1)
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd, strict=True)          # peft key layout (base_model.model..., qkv.base_layer)
+    model = model.to(dev)
+    imgs, metas = synth_images(2, size=(512, 512)), synth_metas(2, size=(512, 512))
+    x = glue.data_preprocess(imgs, MEAN, STD, True, 32)
+    ref, tr = oracle.predict(x, metas)
+    feats, emb, ipe = model.extract_feat(x.to(dev))
+    e_emb = _maxerr(emb, tr['image_embeddings'])
+    e_fpn = max(_maxerr(a, b) for a, b in zip(feats, tr['fpn']))
+    print('peft512: embedding err %.2e, fpn err %.2e' % (e_emb, e_fpn))
+    assert e_emb < 1e-3 and e_fpn < 1e-3
+    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs],
+                               data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
+    for b in range(2):
+        pi, r = out[b].pred_instances, ref[b]
+        assert pi.labels.shape[0] == r['labels'].shape[0]
+        assert torch.equal(pi.labels.cpu(), r['labels'])
+        assert _maxerr(pi.scores, r['scores']) < 1e-4
+        mism = float((pi.masks.cpu() != r['masks']).float().mean())
+        print(f'peft512 img {b}: {pi.labels.shape[0]} dets, mask mismatch {mism:.2e}')
+        assert mism < 1e-3

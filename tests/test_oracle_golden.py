@@ -106,6 +106,17 @@ def test_window_and_relpos_semantics_match_vit_sam_source(gold):
     assert torch.allclose(ours, d['out'], atol=1e-5)
 
 
+def test_oracle_vitsam_helpers_match_reference_source(gold):
+    from oracle import vitsam
+    w = gold['window']
+    win, pad = vitsam.window_partition(w['x'], 14)
+    assert torch.equal(win, w['windows']) and tuple(pad) == tuple(w['pad_hw'])
+    assert torch.equal(vitsam.window_unpartition(win, 14, pad, (20, 20)), w['back'])
+    rp = gold['rel_pos']
+    assert torch.equal(vitsam.get_rel_pos(14, 14, rp['rel_pos']), rp['same'])
+    assert torch.allclose(vitsam.get_rel_pos(20, 20, rp['rel_pos']), rp['resized'], atol=1e-6)
+
+
 def test_ln2d_and_aggregator_match_reference_source(gold):
     from oracle.anchor import LN2d, FeatureAggregator
     l = gold['ln2d']

@@ -107,8 +107,18 @@ def conv_transpose2x2(x, w_dy, bias, act=0, a_scale_log2=6):
     return out
 
 
+def empty_planes(shape, device, scale_log2=6):
+    return torch.zeros(shape)
+
+
+def to_planes(x, scale_log2=6):
+    return x
+
+
 def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v_strides, o_strides,
-              kv_batch_map=None, q_batch_map=None):
+              kv_batch_map=None, q_batch_map=None, out_planes=None):
+    if out is None:
+        out = out_planes
     def view(t, st, T, bmap):
         nb = t.numel() // st[0] if st[0] else 1
         tt = torch.as_strided(t, (nb, T, nh, dh), (st[0], st[1], st[2], 1))
