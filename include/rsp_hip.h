@@ -97,6 +97,7 @@ typedef struct RspGemmDesc {
   uint16_t* Chi; uint16_t* Clo;
   int32_t c_scale_log2;
   int32_t a_rows, c_rows;
+  int32_t b_rows;   /* rows of the Bhi/Blo plane tensors when the weight is a row slice of them (0 = N) */
   int32_t tile_hint;  /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile (plane path; benchmarking) */
 } RspGemmDesc;
 
@@ -156,6 +157,9 @@ typedef struct RspAttnDesc {
   float scale;
   /* optional fp16-plane (KB32) copy of a dense [B*Tq, nh*dh] output; `out` may then be NULL */
   uint16_t* out_hi; uint16_t* out_lo; int32_t out_scale_log2;
+  /* optional attention mask [B, Tq, Tk] bytes, non-zero = blocked, shared by all heads               */
+  /* (Mask2Former masked cross-attention, mask2former_layers.py:113-121)                               */
+  const uint8_t* mask;
 } RspAttnDesc;
 int rsp_attention(const RspAttnDesc* desc, rsp_stream_t stream);
 
@@ -224,6 +228,48 @@ int rsp_hyper_mask(const float* up, const float* hyper, float* out, int32_t R, i
 int rsp_mask_post(const float* low_res, float* sig_ws, int32_t k, int32_t h, int32_t w, int32_t Hb, int32_t Wb,
                   int32_t crop_h, int32_t crop_w, int32_t out_h, int32_t out_w, float thr,
                   uint8_t* out_mask, float* out_prob, rsp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* Query prompter (RSMask2FormerHead + MSDeformAttnPixelDecoder + fusion head)  */
+/* ------------------------------------------------------------------------ */
+/* GroupNorm(G) on a channels-last map x [B, HW, C] (+ReLU, + optional `add` after the norm):          */
+/* mmcv ConvModule(norm_cfg=GN) of msdeformattn_pixel_decoder.py:73-111.  stats_ws: 2*B*G doubles.       */
+int rsp_groupnorm_nhwc(const float* x, const float* gamma, const float* beta, const float* add, float* y,
+                       double* stats_ws, int32_t B, int32_t HW, int32_t C, int32_t G, float eps,
+                       int32_t relu, rsp_stream_t stream);
+/* F.interpolate(bilinear, align_corners=False) on channels-last data                                    */
+int rsp_resize_bilinear_nhwc(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                             int32_t C, rsp_stream_t stream);
+/* mmcv MultiScaleDeformableAttention core (8 heads x 16, 3 levels, 4 points): value [B,Ntok,128];         */
+/* offs_weights [B,Ntok,ld]: 192 offsets (h,l,p,xy) then 96 attention logits (h,l*p); ref [Ntok,2];         */
+/* level_hw: HOST int32 [L,2] (h, w), levels concatenated along Ntok.  out [B,Ntok,128] (pre output_proj).   */
+int rsp_msdeform_attn(const float* value, const float* offs_weights, int32_t ld_ow, const float* ref_points,
+                      float* out, int32_t B, int32_t Ntok, int32_t num_levels, const int32_t* level_hw,
+                      rsp_stream_t stream);
+/* mask[row, k] = sigmoid(bilinear(mask_pred_plus[row], (h,w)))[k] < 0.5, fully-blocked rows cleared        */
+/* (models.py:386-391, 439-442); rows = B*Nq maps of size Hs x Ws.                                          */
+int rsp_query_attn_mask(const float* mask_pred_plus, uint8_t* mask, int64_t rows, int32_t Hs, int32_t Ws,
+                        int32_t h, int32_t w, rsp_stream_t stream);
+/* SamMaskEmbedding (HF:584-593) of mask_pred_plus [R, 4he, 4we] fused with `image_embeddings + dense`      */
+/* (HF:499): out [R, he*we, C] = emb[roi_img[r]] + conv3(gelu(ln(conv2(gelu(ln(conv1(m)))))))               */
+typedef struct RspMaskEmbedDesc {
+  const float* mask_pred_plus; const float* image_embeddings; const int32_t* roi_img;
+  const float *conv1_w, *conv1_b, *ln1_w, *ln1_b, *conv2_w, *conv2_b, *ln2_w, *ln2_b, *conv3_w, *conv3_b;
+  float* out;
+  int32_t R, he, we, C;
+  float eps;
+} RspMaskEmbedDesc;
+int rsp_sam_mask_embed(const RspMaskEmbedDesc* d, rsp_stream_t stream);
+/* maskformer_fusion_head.py:149-162: softmax(cls)[:, :-1], top-k over Nq*nc, (score desc, index asc)        */
+int rsp_query_topk(const float* cls, int32_t B, int32_t Nq, int32_t nc, int32_t k, float* out_score,
+                   int32_t* out_flat, rsp_stream_t stream);
+/* models.py:652-656,684-695 + maskformer_fusion_head.py:164-176 + mask2bbox: per selected instance,         */
+/* bilinear logits -> (Hb,Wb) -> crop -> (out_h,out_w); mask = logit > 0; det_score = cls_score * mean        */
+/* sigmoid over the mask; bbox = mask extents.  stats_ws: k * 32 bytes.                                       */
+int rsp_query_mask_post(const float* low_res, const int32_t* qidx, const float* cls_score, int32_t k, int32_t h,
+                        int32_t w, int32_t Hb, int32_t Wb, int32_t crop_h, int32_t crop_w, int32_t out_h,
+                        int32_t out_w, void* stats_ws, uint8_t* out_mask, float* out_logits, float* det_score,
+                        float* bboxes, rsp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* Data movement                                                              */

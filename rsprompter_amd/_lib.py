@@ -29,7 +29,7 @@ class RspGemmDesc(ctypes.Structure):
         ("ct_W", c_int), ("ct_dy", c_int),
         ("res_bmap", c_void_p), ("res_brows", c_int),
         ("Ahi", c_void_p), ("Alo", c_void_p), ("Chi", c_void_p), ("Clo", c_void_p), ("c_scale_log2", c_int),
-        ("a_rows", c_int), ("c_rows", c_int),
+        ("a_rows", c_int), ("c_rows", c_int), ("b_rows", c_int),
         ("tile_hint", c_int),
     ]
 
@@ -45,7 +45,15 @@ class RspAttnDesc(ctypes.Structure):
         ("B", c_int), ("nh", c_int), ("dh", c_int), ("Tq", c_int), ("Tk", c_int),
         ("scale", c_float),
         ("out_hi", c_void_p), ("out_lo", c_void_p), ("out_scale_log2", c_int),
+        ("mask", c_void_p),
     ]
+
+
+class RspMaskEmbedDesc(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in (
+        "mask_pred_plus", "image_embeddings", "roi_img", "conv1_w", "conv1_b", "ln1_w", "ln1_b", "conv2_w",
+        "conv2_b", "ln2_w", "ln2_b", "conv3_w", "conv3_b", "out")] + [
+        ("R", c_int), ("he", c_int), ("we", c_int), ("C", c_int), ("eps", c_float)]
 
 
 class RspRoiAlignDesc(ctypes.Structure):
@@ -100,6 +108,16 @@ PROTOTYPES = {
     "rsp_sincos_pairs": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rsp_div_boxes": (c_int, [c_void_p, c_void_p, c_int64, ctypes.POINTER(c_float), c_void_p]),
     "rsp_pack_bits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "rsp_groupnorm_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                   c_int, c_float, c_int, c_void_p]),
+    "rsp_resize_bilinear_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rsp_msdeform_attn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                  ctypes.POINTER(c_int), c_void_p]),
+    "rsp_query_attn_mask": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "rsp_sam_mask_embed": (c_int, [ctypes.POINTER(RspMaskEmbedDesc), c_void_p]),
+    "rsp_query_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "rsp_query_mask_post": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsp_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
 }
 

@@ -40,6 +40,7 @@ struct AttnP {
   const int32_t* q_batch_map;   // optional: batch b reads Q of batch q_batch_map[b]
   half_t* out_hi; half_t* out_lo; float out_pscale;  // optional fp16-plane copy of `out`, KB32 layout
   int64_t out_rows;                                  // rows (= B * Tq) of that [rows, nh*dh] matrix
+  const uint8_t* mask;                               // optional [B, Tq, Tk] bytes, non-zero = blocked (all heads)
   int64_t q_bs, q_ts, q_hs;     // element strides: batch, token, head
   int64_t k_bs, k_ts, k_hs;
   int64_t v_bs, v_ts, v_hs;
@@ -246,18 +247,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
           v += sRel[ql * (2 * S + 1) + (km & 0xffff)] + sRel[ql * (2 * S + 1) + S + (km >> 16)];
         }
         if (key >= TK) v = -INFINITY;
+        else if (p.mask && q < T && p.mask[((int64_t)bp * T + q) * TK + key]) v = -INFINITY;
         sc[blk][r] = v;
         tmax = fmaxf(tmax, v);
       }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
-    const float alpha = exp2f((m_run - m_new) * LOG2E);  // m_run=-inf -> 0
+    // fully masked so far (m_new == -inf): contribute nothing and keep the state (no inf - inf)
+    const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
+    const float alpha = (m_run == -INFINITY) ? 0.f : exp2f((m_run - m_safe) * LOG2E);
     float psum = 0.f;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f((sc[blk][r] - m_new) * LOG2E) * P_SCALE;
+        const float pv = exp2f((sc[blk][r] - m_safe) * LOG2E) * P_SCALE;
         sc[blk][r] = pv;
         psum += pv;
       }
@@ -423,6 +427,7 @@ extern "C" int rsp_vit_attention_ex(const float* qkv, const float* rel, float* o
   p.q = qkv; p.k = qkv + D; p.v = qkv + 2 * D; p.rel = rel; p.out = out; p.kv_batch_map = nullptr; p.q_batch_map = nullptr;
   p.out_hi = reinterpret_cast<half_t*>(out_hi); p.out_lo = reinterpret_cast<half_t*>(out_lo);
   p.out_pscale = ldexpf(1.0f, out_scale_log2);
+  p.mask = nullptr;
   p.out_rows = (int64_t)Bp * T;
   if (out_hi && ((nh * dh) & 31)) return RSP_EINVAL;
   p.q_bs = p.k_bs = p.v_bs = (int64_t)T * 3 * D;
@@ -447,6 +452,7 @@ extern "C" int rsp_attention(const RspAttnDesc* d, rsp_stream_t stream) {
   p.kv_batch_map = d->kv_batch_map; p.q_batch_map = d->q_batch_map;
   p.out_hi = reinterpret_cast<half_t*>(d->out_hi); p.out_lo = reinterpret_cast<half_t*>(d->out_lo);
   p.out_pscale = ldexpf(1.0f, d->out_scale_log2); p.out_rows = (int64_t)d->B * d->Tq;
+  p.mask = d->mask;
   if (p.out_hi) {   // plane copy assumes a dense [B*Tq, nh*dh] output matrix
     if (!p.out_lo || d->o_hs != d->dh || d->o_ts != (int64_t)d->nh * d->dh || d->o_bs != d->o_ts * d->Tq ||
         ((d->nh * d->dh) & 31))

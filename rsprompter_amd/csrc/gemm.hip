@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const GemmP p) {
     for (int i = 0; i < B_PER_THREAD; ++i) {
       uint4 zh = {0u, 0u, 0u, 0u}, zl = {0u, 0u, 0u, 0u};
       if (b_ok[i]) {
-        const int64_t off = ((int64_t)(k0 / BK) * N + n0 + b_row[i]) * BK + b_kc[i];   // KB32 weight layout
+        const int64_t off = ((int64_t)(k0 / BK) * (d.b_rows > 0 ? d.b_rows : N) + n0 + b_row[i]) * BK + b_kc[i];   // KB32 weight layout
         zh = *reinterpret_cast<const uint4*>(d.Bhi + off);
         zl = *reinterpret_cast<const uint4*>(d.Blo + off);
       }

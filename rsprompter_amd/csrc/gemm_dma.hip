@@ -130,7 +130,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   }
 
   const int64_t a_kstride = (int64_t)d.a_rows * ROWB;   // bytes between consecutive K blocks of an A plane
-  const int64_t b_kstride = (int64_t)N * ROWB;
+  const int64_t b_kstride = (int64_t)(d.b_rows > 0 ? d.b_rows : N) * ROWB;
   auto issue_tile = [&](int k0, int buf) {
     int ky = 0, kx = 0, c0 = 0;
     if (d.conv_k != 0) {

@@ -89,3 +89,56 @@ def rsprompter_anchor_peft512(arch='base', num_classes=10, prompt_shape=(60, 5),
                                            out_channels=256)
     m['train_cfg']['rcnn']['mask_size'] = crop
     return m
+
+
+def rsprompter_query(arch='base', num_classes=1, prompt_shape=(100, 5), pretrain_name=None, ckpt=None,
+                     max_per_image=None):
+    """configs/rsprompter/_base_/rsprompter_query.py:58-202 merged with rsprompter_query-<dataset>.py."""
+    name = pretrain_name or f'work_dirs/sam_cache/sam_vit_{arch}'
+    init = dict(type='Pretrained', checkpoint=ckpt or f'{name}/pytorch_model.bin')
+    a = rsprompter_anchor(arch, num_classes, prompt_shape, pretrain_name, ckpt)
+    return dict(
+        type='RSPrompterQuery', data_preprocessor=a['data_preprocessor'], decoder_freeze=False,
+        shared_image_embedding=a['shared_image_embedding'], backbone=a['backbone'], neck=a['neck'],
+        panoptic_head=dict(
+            type='RSMask2FormerHead', decoder_plus=True,
+            mask_decoder=dict(type='RSSamMaskDecoder', hf_pretrain_name=name, init_cfg=init),
+            per_pointset_point=prompt_shape[1], with_sincos=True, multimask_output=False,
+            in_channels=[256, 256, 256, 256, 256], feat_channels=128, out_channels=256,
+            num_things_classes=num_classes, num_stuff_classes=0, num_queries=prompt_shape[0],
+            num_transformer_feat_level=3,
+            pixel_decoder=dict(
+                type='MSDeformAttnPixelDecoder', strides=[4, 8, 16, 32, 64], num_outs=3,
+                norm_cfg=dict(type='GN', num_groups=32), act_cfg=dict(type='ReLU'),
+                encoder=dict(num_layers=3, layer_cfg=dict(
+                    self_attn_cfg=dict(embed_dims=128, num_heads=8, num_levels=3, num_points=4, dropout=0.0,
+                                       batch_first=True),
+                    ffn_cfg=dict(embed_dims=128, feedforward_channels=512, num_fcs=2, ffn_drop=0.0,
+                                 act_cfg=dict(type='ReLU', inplace=True)))),
+                positional_encoding=dict(num_feats=64, normalize=True)),
+            enforce_decoder_input_project=False, positional_encoding=dict(num_feats=64, normalize=True),
+            transformer_decoder=dict(
+                return_intermediate=True, num_layers=6,
+                layer_cfg=dict(
+                    self_attn_cfg=dict(embed_dims=128, num_heads=8, dropout=0.0, batch_first=True),
+                    cross_attn_cfg=dict(embed_dims=128, num_heads=8, dropout=0.0, batch_first=True),
+                    ffn_cfg=dict(embed_dims=128, feedforward_channels=512, num_fcs=2, ffn_drop=0.0,
+                                 act_cfg=dict(type='ReLU', inplace=True))),
+                init_cfg=None),
+            loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=2.0, reduction='mean',
+                          class_weight=[1.0] * num_classes + [0.1]),
+            loss_mask=dict(type='CrossEntropyLoss', use_sigmoid=True, reduction='mean', loss_weight=5.0),
+            loss_dice=dict(type='DiceLoss', use_sigmoid=True, activate=True, reduction='mean', naive_dice=True,
+                           eps=1.0, loss_weight=5.0)),
+        panoptic_fusion_head=dict(type='RSMaskFormerFusionHead', num_things_classes=num_classes,
+                                  num_stuff_classes=0, loss_panoptic=None, init_cfg=None),
+        train_cfg=dict(
+            num_points=12544, oversample_ratio=3.0, importance_sample_ratio=0.75,
+            assigner=dict(type='HungarianAssigner', match_costs=[
+                dict(type='ClassificationCost', weight=2.0),
+                dict(type='CrossEntropyLossCost', weight=5.0, use_sigmoid=True),
+                dict(type='DiceCost', weight=5.0, pred_act=True, eps=1.0)]),
+            sampler=dict(type='MaskPseudoSampler')),
+        test_cfg=dict(panoptic_on=False, semantic_on=False, instance_on=True,
+                      max_per_image=prompt_shape[0] if max_per_image is None else max_per_image, iou_thr=0.8,
+                      filter_low_score=True))

@@ -155,6 +155,20 @@ def to_planes(x, scale_log2=DEFAULT_A_SCALE_LOG2):
     return p
 
 
+class PlaneWeight:
+    """A GEMM 'weight' that is itself an activation held as Planes (rows [r0, r0+n) of a plane tensor),
+    e.g. mask_feature in `einsum('bqc,bchw->bqhw')` (models.py:357)."""
+
+    def __init__(self, planes, r0=0, n=None):
+        self.N = planes.rows - r0 if n is None else n
+        self.K = planes.shape[-1]
+        self.scale_log2 = planes.scale_log2
+        self.b_rows = planes.rows
+        self.hi = planes.hi[:, r0:, :]
+        self.lo = planes.lo[:, r0:, :]
+        self.bias = None
+
+
 def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, c_rowmap=None,
          M=None, out_rows=None, res_mod=0, a_scale_log2=DEFAULT_A_SCALE_LOG2, conv=None,
          res_bmap=None, res_brows=0, out_planes=False, out_f32=True, dma="auto", tile_hint=0):
@@ -220,6 +234,7 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.ldc = out.stride(0) if out is not None else n
     d.res_mod = res_mod
     d.res_bmap, d.res_brows = _ptr(res_bmap), res_brows
+    d.b_rows = getattr(w, 'b_rows', 0)
     d.tile_hint = tile_hint
     d.act = act
     d.a_scale_log2 = a_scale_log2
@@ -355,7 +370,7 @@ def _gemm_ct(a, w, out, bias, act, ct_W, ct_dy, a_scale_log2):
 
 
 def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v_strides, o_strides,
-              kv_batch_map=None, q_batch_map=None, out_planes=None):
+              kv_batch_map=None, q_batch_map=None, out_planes=None, mask=None):
     """Generic strided multi-head attention (RspAttnDesc). strides = (batch, token, head) in elements.
     out_planes: optional Planes receiving a KB32 copy of the dense [B*Tq, nh*dh] output (out may be None)."""
     lib = _lib.load()
@@ -365,6 +380,7 @@ def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v
         d.out_hi, d.out_lo, d.out_scale_log2 = out_planes.hi.data_ptr(), out_planes.lo.data_ptr(), out_planes.scale_log2
     d.kv_batch_map = _ptr(kv_batch_map)
     d.q_batch_map = _ptr(q_batch_map)
+    d.mask = _ptr(mask)
     d.q_bs, d.q_ts, d.q_hs = q_strides
     d.k_bs, d.k_ts, d.k_hs = k_strides
     d.v_bs, d.v_ts, d.v_hs = v_strides
@@ -562,3 +578,95 @@ def pack_masks(masks):
         m = masks.contiguous()
         _lib.check(lib.rsp_pack_bits(m.data_ptr(), out.data_ptr(), m.numel(), _stream()), "rsp_pack_bits")
     return out
+
+
+# ----------------------------------------------------------------------------- query prompter ops
+def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, add=None):
+    """GroupNorm on channels-last [B, ..., C]; `add` (same shape) is added after the norm."""
+    lib = _lib.load()
+    B, C = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    ws = torch.empty((B * groups * 2,), dtype=torch.float64, device=x.device)
+    _timed('groupnorm_kernels', 0, 12.0 * x.numel(),
+           lambda: _lib.check(lib.rsp_groupnorm_nhwc(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(add),
+                                                     y.data_ptr(), ws.data_ptr(), B, HW, C, groups, eps,
+                                                     1 if relu else 0, _stream()), "rsp_groupnorm_nhwc"))
+    return y
+
+
+def resize_bilinear(x_nhwc, size):
+    lib = _lib.load()
+    B, H, W, C = x_nhwc.shape
+    y = torch.empty((B, size[0], size[1], C), dtype=torch.float32, device=x_nhwc.device)
+    _lib.check(lib.rsp_resize_bilinear_nhwc(x_nhwc.data_ptr(), y.data_ptr(), B, H, W, size[0], size[1], C, _stream()),
+               "rsp_resize_bilinear_nhwc")
+    return y
+
+
+def msdeform_attn(value, offs_weights, ref_points, B, Ntok, level_hw):
+    import ctypes
+    lib = _lib.load()
+    out = torch.empty((B * Ntok, 128), dtype=torch.float32, device=value.device)
+    arr = (ctypes.c_int * (2 * len(level_hw)))(*[int(v) for hw in level_hw for v in hw])
+    _timed('msda_kernel', 0, 4.0 * out.numel() * 50,
+           lambda: _lib.check(lib.rsp_msdeform_attn(value.data_ptr(), offs_weights.data_ptr(), offs_weights.shape[-1],
+                                                    ref_points.data_ptr(), out.data_ptr(), B, Ntok, len(level_hw), arr,
+                                                    _stream()), "rsp_msdeform_attn"))
+    return out
+
+
+def query_attn_mask(mask_pred_plus, size):
+    """mask_pred_plus [B, Nq, Hs, Ws] -> uint8 [B, Nq, h*w] (1 = blocked), fully blocked rows cleared."""
+    lib = _lib.load()
+    B, Nq, Hs, Ws = mask_pred_plus.shape
+    m = torch.empty((B, Nq, size[0] * size[1]), dtype=torch.uint8, device=mask_pred_plus.device)
+    _lib.check(lib.rsp_query_attn_mask(mask_pred_plus.data_ptr(), m.data_ptr(), B * Nq, Hs, Ws, size[0], size[1],
+                                       _stream()), "rsp_query_attn_mask")
+    return m
+
+
+def sam_mask_embed(mask_pred_plus, emb_rows, roi_img, prm, he, we, eps=1e-6):
+    """mask_pred_plus [R, 4he, 4we]; emb_rows [B*he*we, C]; prm: dict of the SamMaskEmbedding tensors."""
+    lib = _lib.load()
+    R = mask_pred_plus.shape[0]
+    C = emb_rows.shape[-1]
+    out = torch.empty((R * he * we, C), dtype=torch.float32, device=emb_rows.device)
+    d = _lib.RspMaskEmbedDesc()
+    d.mask_pred_plus, d.image_embeddings, d.roi_img = mask_pred_plus.data_ptr(), emb_rows.data_ptr(), roi_img.data_ptr()
+    for k in ('conv1_w', 'conv1_b', 'ln1_w', 'ln1_b', 'conv2_w', 'conv2_b', 'ln2_w', 'ln2_b', 'conv3_w', 'conv3_b'):
+        setattr(d, k, prm[k].data_ptr())
+    d.out, d.R, d.he, d.we, d.C, d.eps = out.data_ptr(), R, he, we, C, eps
+    _timed('mask_embed_kernel', 0, 4.0 * out.numel(),
+           lambda: _lib.check(lib.rsp_sam_mask_embed(d, _stream()), "rsp_sam_mask_embed"))
+    return out
+
+
+def query_topk(cls, k):
+    """cls [B, Nq, nc+1] logits -> (scores [B,k], flat index [B,k] into Nq*nc), score desc / index asc."""
+    lib = _lib.load()
+    B, Nq, nc1 = cls.shape
+    sc = torch.empty((B, k), dtype=torch.float32, device=cls.device)
+    fl = torch.empty((B, k), dtype=torch.int32, device=cls.device)
+    _lib.check(lib.rsp_query_topk(cls.data_ptr(), B, Nq, nc1 - 1, k, sc.data_ptr(), fl.data_ptr(), _stream()),
+               "rsp_query_topk")
+    return sc, fl
+
+
+def query_mask_post(low_res, qidx, cls_score, batch_input_shape, crop_hw, out_hw, want_logits=False):
+    """low_res [Nq, h, w] logits of one image; qidx int32 [k]; returns (masks bool [k,oh,ow], det_scores, bboxes)."""
+    lib = _lib.load()
+    k = qidx.numel()
+    _, h, w = low_res.shape
+    dev = low_res.device
+    masks = torch.empty((k, out_hw[0], out_hw[1]), dtype=torch.bool, device=dev)
+    logits = torch.empty((k, out_hw[0], out_hw[1]), dtype=torch.float32, device=dev) if want_logits else None
+    det = torch.empty((k,), dtype=torch.float32, device=dev)
+    boxes = torch.empty((k, 4), dtype=torch.float32, device=dev)
+    ws = torch.empty((max(k, 1) * 32,), dtype=torch.uint8, device=dev)
+    _timed('query_mask_kernel', 0, 1.0 * masks.numel(),
+           lambda: _lib.check(lib.rsp_query_mask_post(low_res.data_ptr(), qidx.data_ptr(), cls_score.data_ptr(), k, h, w,
+                                                      batch_input_shape[0], batch_input_shape[1], crop_hw[0], crop_hw[1],
+                                                      out_hw[0], out_hw[1], ws.data_ptr(), masks.data_ptr(), _ptr(logits),
+                                                      det.data_ptr(), boxes.data_ptr(), _stream()), "rsp_query_mask_post"))
+    return (masks, det, boxes, logits) if want_logits else (masks, det, boxes)

@@ -140,7 +140,7 @@ class SamMaskDecoderHIP(HIPModule):
                       q_strides=st, k_strides=st, v_strides=st, o_strides=st)
         return ops.gemm(o, P[pfx + '.out_proj'], res=res)
 
-    def decode(self, image_embeddings, image_pe, sparse, dense_vec, roi_img, want_iou=True):
+    def decode(self, image_embeddings, image_pe, sparse, dense_vec, roi_img, want_iou=True, src_rows=None, hw=None):
         """image_embeddings [B,256,h,w] (logical NCHW, channels-last), image_pe [1|B,256,h,w] (input
         independent; batch entry 0 is used), sparse [R, n_pts, 256], dense_vec [256] (the broadcast
         `no_mask_embed`, models.py:1680), roi_img int32 [R] image index of every RoI (sorted).
@@ -148,12 +148,20 @@ class SamMaskDecoderHIP(HIPModule):
         if self._packed is None:
             self._pack()
         P = self._packed
-        emb = nhwc_view(image_embeddings)
-        B, h, w, C = emb.shape
+        if src_rows is None:
+            emb = nhwc_view(image_embeddings)
+            B, h, w, C = emb.shape
+            dev = emb.device
+        else:
+            # query variant: `image_embeddings + dense prompt` already formed per source (rsp_sam_mask_embed);
+            # src_rows [Bs*h*w, 256], roi_img maps every prompt set to its source
+            h, w = hw
+            C = src_rows.shape[-1]
+            B = src_rows.shape[0] // (h * w)
+            dev = src_rows.device
         N = h * w
         R, npts = sparse.shape[0], sparse.shape[1]
         T = 1 + N_MASK_TOKENS + npts
-        dev = emb.device
         pe_rows = nhwc_view(image_pe[:1]).reshape(N, C)
         pe_t = self._pe_terms(pe_rows)
         d2, dh2 = HID // 2, (HID // 2) // HEADS
@@ -163,7 +171,10 @@ class SamMaskDecoderHIP(HIPModule):
         tokens0 = torch.cat([out_tok.unsqueeze(0).expand(R, -1, -1), sparse.reshape(R, npts, HID)], 1)
         tokens0 = tokens0.reshape(R * T, HID).contiguous()
         # keys of layer 0: image embedding + dense prompt, ONE copy per image (HF:499)
-        src = ops.add_rows(emb.reshape(B * N, C), dense_vec.reshape(1, C), vmod=1)
+        if src_rows is None:
+            src = ops.add_rows(emb.reshape(B * N, C), dense_vec.reshape(1, C), vmod=1)
+        else:
+            src = src_rows
         src_pl = ops.to_planes(src)
 
         # ---------------- layer 0 (HF:306-348 with skip_first_layer_pe) ----------------

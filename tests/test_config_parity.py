@@ -68,6 +68,30 @@ def test_reference_peft512_config_builds_with_peft_key_layout():
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
+@pytest.mark.parametrize('fname,nc,ps,mpi', [('rsprompter_query-whu.py', 1, (100, 5), 100),
+                                             ('rsprompter_query-nwpu.py', 10, (70, 5), 70),
+                                             ('rsprompter_query-ssdd.py', 1, (30, 5), 30)])
+def test_reference_query_configs_build(fname, nc, ps, mpi):
+    import rsprompter_amd as ra
+    from rsprompter_amd.default_configs import rsprompter_query
+    cfg = ra.Config.fromfile(os.path.join(REF, fname))
+    assert _norm(cfg.model) == _norm(rsprompter_query('base', nc, ps, max_per_image=mpi))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = ra.build_model(cfg)
+    assert type(m).__name__ == 'RSPrompterQuery' and m.panoptic_head.num_queries == ps[0]
+    keys = set(m.state_dict())
+    for k in ['panoptic_head.pixel_decoder.encoder.layers.0.self_attn.sampling_offsets.weight',
+              'panoptic_head.pixel_decoder.input_convs.0.gn.weight', 'panoptic_head.pixel_decoder.mask_feature.bias',
+              'panoptic_head.transformer_decoder.layers.5.cross_attn.attn.in_proj_weight',
+              'panoptic_head.transformer_decoder.post_norm.weight', 'panoptic_head.query_feat.weight',
+              'panoptic_head.cls_embed.2.weight', 'panoptic_head.mask_embed.4.bias', 'panoptic_head.point_emb.4.weight',
+              'panoptic_head.sam_mask_embed.conv2.weight', 'panoptic_head.sam_mask_embed.layer_norm2.bias',
+              'panoptic_head.mask_decoder.mask_decoder.iou_token.weight']:
+        assert k in keys, k
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
 def test_config_loader_base_and_delete():
     import rsprompter_amd as ra
     cfg = ra.Config.fromfile(os.path.join(REF, 'rsprompter_anchor-nwpu-peft-512.py'))
