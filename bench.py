@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--arch', default='base')
     ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shapes', action='store_true', help='break the kernel table down by GEMM/attention shape')
     args = ap.parse_args()
 
     from rsprompter_amd import dist as rdist
@@ -116,6 +117,7 @@ def main():
     if rank == 0:
         # ---- roofline leg: one extra instrumented step, per-kernel HIP events on the launch stream ----
         prof = ops.Profiler()
+        prof.shapes = args.shapes
         ops.set_profiler(prof)
         step()
         ops.set_profiler(None)

@@ -98,6 +98,17 @@ typedef struct RspGemmDesc {
   int32_t c_scale_log2;
   int32_t a_rows, c_rows;
   int32_t b_rows;   /* rows of the Bhi/Blo plane tensors when the weight is a row slice of them (0 = N) */
+  /* hyper-network epilogue (HF:523-531 fused into the last ConvTranspose of the SAM upscaler): instead of  */
+  /* storing the [rows, N] tile, every 32-column group g of a row is reduced against hyper[row / hd_rows]:   */
+  /* hd_out[(row / hd_rows) * hd_ostride + pix(row, g)] = sum_c act(...)[row, 32g + c] * hyper[., c]          */
+  /* (pix = the sub-pixel the 32-column group writes); needs A planes, ct_W > 0 and N == 64 (ct_dy >= 0) or   */
+  /* N == 128 (ct_dy < 0: columns are (dy, dx, co), all four sub-pixels from one pass over A).                */
+  /* grouped-LayerNorm epilogue (HF:519-520 fused into the first ConvTranspose of the SAM upscaler): with  */
+  /* ct_W > 0, ct_dy < 0 and N == 256 every 64-column group (one output sub-pixel) is normalised over its  */
+  /* 64 channels (LayerNorm2d, eps ln_eps, affine ln_gamma/ln_beta [64]) BEFORE `act`; plane output only.  */
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  const float* hd_hyper; float* hd_out;
+  int32_t hd_rows;    /* GEMM rows per RoI (input pixels of the ConvTranspose)                                */
   int32_t tile_hint;  /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile (plane path; benchmarking) */
 } RspGemmDesc;
 

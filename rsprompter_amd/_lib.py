@@ -30,6 +30,8 @@ class RspGemmDesc(ctypes.Structure):
         ("res_bmap", c_void_p), ("res_brows", c_int),
         ("Ahi", c_void_p), ("Alo", c_void_p), ("Chi", c_void_p), ("Clo", c_void_p), ("c_scale_log2", c_int),
         ("a_rows", c_int), ("c_rows", c_int), ("b_rows", c_int),
+        ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
+        ("hd_hyper", c_void_p), ("hd_out", c_void_p), ("hd_rows", c_int),
         ("tile_hint", c_int),
     ]
 

@@ -49,16 +49,19 @@ struct AttnP {
   float scale;
 };
 
-// HAS_REL: decomposed rel-pos bias (ViT); requires Tq == Tk == S*S.
-template <int DH, bool HAS_REL>
+// REL: decomposed rel-pos bias (ViT; requires Tq == Tk == S*S): 0 = none, 1 = S == 64 (a key tile is one key row:
+// rel_h is one scalar per tile, rel_w lives in registers), 2 = S <= 32 (both tables in LDS).
+// MASK: honour p.mask.  Both are compile-time so that the inner loops stay branch-free.
+template <int DH, int REL, bool MASK>
 __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
+  constexpr bool HAS_REL = REL != 0;
   constexpr int DSTEPS = DH / 16;
   constexpr int DBLK = (DH + 31) / 32;
   constexpr int K_LD = DH + 8;
   constexpr int DCH = DH / 4;                          // float4 chunks per key row
   constexpr int MT_TOTAL = 16 * DCH;                   // 4key x 4d micro tiles per K/V tile
   constexpr int MT_PER_THREAD = (MT_TOTAL + 255) / 256;
-  constexpr int REL_MAX_S = HAS_REL ? 32 : 1;          // LDS rel table only for S < 64
+  constexpr int REL_MAX_S = (REL == 2) ? 32 : 1;       // LDS rel table only for S < 64
 
   __shared__ __attribute__((aligned(16))) half_t sK[2][KT * K_LD];
   __shared__ __attribute__((aligned(16))) half_t sVt[2][DBLK * 32 * VT_LD];
@@ -73,7 +76,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   const int q = q0 + ql;
   const int T = p.Tq, TK = p.Tk, S = p.S, nh = p.nh;
   const float scale = p.scale;
-  const bool aligned = HAS_REL && (S == 64);
+  constexpr bool aligned = REL == 1;
   const int kvb = p.kv_batch_map ? p.kv_batch_map[bp] : bp;
   const int qbi = p.q_batch_map ? p.q_batch_map[bp] : bp;
   const float* q_b = p.q + (int64_t)qbi * p.q_bs + (int64_t)h * p.q_hs;
@@ -105,7 +108,9 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
 
   // ---- rel-pos bias sources ----
   float bw[2][16];  // aligned path: rel_w for this lane's 32 key columns (tile invariant)
-  if (aligned) {
+  float bh_next = 0.f;   // aligned path: rel_h of the NEXT key tile, fetched a whole tile ahead of its use
+  if constexpr (aligned) {
+    bh_next = (q < T) ? rel_b[(int64_t)q * (2 * S)] : 0.f;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -113,7 +118,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
         const int kw = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hh;
         bw[blk][r] = (q < T) ? rel_b[(int64_t)q * (2 * S) + S + kw] : 0.f;
       }
-  } else if (HAS_REL) {
+  } else if constexpr (REL == 2) {
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -232,36 +237,55 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
 
     // ---- bias, mask, online softmax (per-lane query column) ----
     float bh_t = 0.f;
-    if (aligned) bh_t = (q < T) ? rel_b[(int64_t)q * (2 * S) + kt] : 0.f;
+    if constexpr (aligned) {
+      bh_t = bh_next;
+      if (kt + 1 < nt && q < T) bh_next = rel_b[(int64_t)q * (2 * S) + kt + 1];
+    }
+    const int tk_lim = TK - kt * KT;      // keys of this tile that exist (>= KT except on the last tile)
     float tmax = -INFINITY;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int key = kt * KT + blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int kl = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         float v = sc[blk][r] * s_unscale;
-        if (aligned) {
+        if constexpr (aligned) {
           v += bh_t + bw[blk][r];
-        } else if (HAS_REL && key < TK) {
-          const int km = sKmap[key];
-          v += sRel[ql * (2 * S + 1) + (km & 0xffff)] + sRel[ql * (2 * S + 1) + S + (km >> 16)];
+        } else if constexpr (REL == 2) {
+          if (kl < tk_lim) {
+            const int km = sKmap[kt * KT + kl];
+            v += sRel[ql * (2 * S + 1) + (km & 0xffff)] + sRel[ql * (2 * S + 1) + S + (km >> 16)];
+          }
         }
-        if (key >= TK) v = -INFINITY;
-        else if (p.mask && q < T && p.mask[((int64_t)bp * T + q) * TK + key]) v = -INFINITY;
+        if constexpr (MASK) {
+          if (kl < tk_lim && q < T && p.mask[((int64_t)bp * T + q) * TK + kt * KT + kl]) v = -INFINITY;
+        }
         sc[blk][r] = v;
-        tmax = fmaxf(tmax, v);
       }
+    if (tk_lim < KT) {   // wave-uniform: only the ragged last tile pays for the bounds test
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh >= tk_lim) sc[blk][r] = -INFINITY;
+    }
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, sc[blk][r]);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
     const float m_new = fmaxf(m_run, tmax);
     // fully masked so far (m_new == -inf): contribute nothing and keep the state (no inf - inf)
     const float m_safe = (m_new == -INFINITY) ? 0.f : m_new;
-    const float alpha = (m_run == -INFINITY) ? 0.f : exp2f((m_run - m_safe) * LOG2E);
+    const float alpha = (m_run == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f((m_run - m_safe) * LOG2E);
+    const float m_l2 = m_safe * LOG2E;
     float psum = 0.f;
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = exp2f((sc[blk][r] - m_safe) * LOG2E) * P_SCALE;
+        // v_exp_f32 directly: arguments are <= 0, results in [0, 1]; flushing results below 2^-126 is harmless
+        const float pv = __builtin_amdgcn_exp2f(sc[blk][r] * LOG2E - m_l2) * P_SCALE;
         sc[blk][r] = pv;
         psum += pv;
       }
@@ -396,10 +420,10 @@ extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const fl
   return RSP_OK;
 }
 
-template <int DH, bool HAS_REL>
+template <int DH, int REL, bool MASK>
 static int launch_attn(const AttnP& p, int B, hipStream_t s) {
   dim3 grid((p.Tq + QB - 1) / QB, p.nh, B);
-  hipLaunchKernelGGL((attn_kernel<DH, HAS_REL>), grid, dim3(256), 0, s, p);
+  hipLaunchKernelGGL((attn_kernel<DH, REL, MASK>), grid, dim3(256), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
@@ -436,8 +460,8 @@ extern "C" int rsp_vit_attention_ex(const float* qkv, const float* rel, float* o
   p.o_bs = (int64_t)T * D; p.o_ts = D; p.o_hs = dh;
   p.Tq = T; p.Tk = T; p.S = S; p.nh = nh; p.scale = scale;
   hipStream_t s = (hipStream_t)stream;
-  if (dh == 64) return launch_attn<64, true>(p, Bp, s);
-  if (dh == 80) return launch_attn<80, true>(p, Bp, s);
+  if (dh == 64) return S == 64 ? launch_attn<64, 1, false>(p, Bp, s) : launch_attn<64, 2, false>(p, Bp, s);
+  if (dh == 80) return S == 64 ? launch_attn<80, 1, false>(p, Bp, s) : launch_attn<80, 2, false>(p, Bp, s);
   return RSP_EINVAL;
 }
 
@@ -465,9 +489,9 @@ extern "C" int rsp_attention(const RspAttnDesc* d, rsp_stream_t stream) {
   p.Tq = d->Tq; p.Tk = d->Tk; p.S = 0; p.nh = d->nh; p.scale = d->scale;
   hipStream_t s = (hipStream_t)stream;
   switch (d->dh) {
-    case 16: return launch_attn<16, false>(p, d->B, s);
-    case 32: return launch_attn<32, false>(p, d->B, s);
-    case 64: return launch_attn<64, false>(p, d->B, s);
+    case 16: return p.mask ? launch_attn<16, 0, true>(p, d->B, s) : launch_attn<16, 0, false>(p, d->B, s);
+    case 32: return p.mask ? launch_attn<32, 0, true>(p, d->B, s) : launch_attn<32, 0, false>(p, d->B, s);
+    case 64: return p.mask ? launch_attn<64, 0, true>(p, d->B, s) : launch_attn<64, 0, false>(p, d->B, s);
     default: return RSP_EINVAL;
   }
 }

@@ -16,6 +16,7 @@
 //
 // Pipeline: 2 LDS buffers; the DMA for tile k+1 is issued before the MFMA block of tile k and is
 // drained by the __syncthreads() that ends the iteration (one barrier per K step).
+#include <type_traits>
 #include "rsp_common.h"
 
 namespace {
@@ -52,7 +53,17 @@ __device__ __forceinline__ void wait_vmcnt() {
 // (cdna_hip_programming.md §5 "Pipelining across barriers", T3+T4).
 // ABL: ablation switch for the tuning probe (0 = product kernel, 1 = skip the DMA inside the K loop,
 // 2 = skip the MFMAs); results are garbage for ABL != 0.
-template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0>
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+// EPI: 0 = generic epilogue, 1 = ConvTranspose + GELU + hyper-network dot (no tile store at all),
+// 2 = ConvTranspose + LayerNorm over each 64-channel sub-pixel + act -> planes (pairs of j tiles)
+template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const GemmP p) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -223,6 +234,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
         for (int j = 0; j < TN; ++j) {
           if (ABL == 2) {   // keep the fragments live without the matrix work
             asm volatile("" ::"v"(al[i]), "v"(ah[i]), "v"(bl[j]), "v"(bh[j]));
+          } else if constexpr (EPI != 0) {
+            // transposed tile (W A^T): every lane owns ONE output row and 16 of the 32 channels of tile j, so the
+            // channel reduction of the hyper-network epilogue is in-lane (plus one cross-half shuffle)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
           } else {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
@@ -236,14 +253,96 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   // ---- epilogue (same contract as gemm.hip) + optional fp16-plane output for the next GEMM ----
   const float alpha = d.alpha;
   const float cs = d.Chi ? ldexpf(1.0f, d.c_scale_log2) : 1.0f;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const f32x16 t = acc[i][j];      // keep the accumulator indices compile-time (no scratch)
+  // the (i, j) loops are expanded by template recursion: a #pragma unroll the optimizer declines here turns the
+  // accumulator indices dynamic and sends all of acc[][] to scratch
+  static_for<0, TM>([&](auto ic) {
+    static_for<0, TN>([&](auto jc) {
+      constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+      const f32x16 t = acc[i][j];
       const int col = n0 + wn * WTN + j * 32 + l31;
       const bool col_ok = col < N;
       const float bv = (d.bias && col_ok) ? d.bias[col] : 0.f;
+      // ConvTranspose(k2,s2) column decode: ct_dy >= 0 -> columns are (dx, co) of one output-row parity;
+      // ct_dy < 0 -> columns are (dy, dx, co), all four sub-pixels in one GEMM (A is read once)
+      int ct_dyv = d.ct_dy, ccol = col, ct_c = N >> 1;
+      if (d.ct_W > 0 && d.ct_dy < 0) { ct_dyv = col / (N >> 1); ccol = col - ct_dyv * (N >> 1); ct_c = N >> 2; }
+      if constexpr (EPI == 1) {
+        // last ConvTranspose of the SAM upscaler + GELU + <., hyper_in> (HF:519-531).  acc holds the TRANSPOSED
+        // tile: lane l31 <-> GEMM row (input pixel), register r <-> channel (r&3) + 8(r>>2) + 4hh of the
+        // sub-pixel this 32-column group stands for.  Nothing of the [R, 4h, 4w, 32] tensor is ever stored.
+        const int row = m0 + wm * WTM + i * 32 + l31;
+        const int cbase = n0 + wn * WTN + j * 32;
+        const bool ok = row < M && cbase < N;
+        const int roi = ok ? row / d.hd_rows : 0;
+        const float* hy = d.hd_hyper + (int64_t)roi * 32;
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const float b = d.bias ? d.bias[cbase + c] : 0.f;
+          sum += rsp_act(t[r] * alpha + b, d.act) * hy[c];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        if (ok && hh == 0) {
+          const int pix = row - roi * d.hd_rows;            // input pixel (y, x) of the ConvTranspose
+          const int y = pix / d.ct_W, x = pix - y * d.ct_W;
+          const int sp = cbase >> 5;                        // sub-pixel: (dy, dx) when ct_dy < 0, else dx
+          const int dy = d.ct_dy < 0 ? (sp >> 1) : d.ct_dy, dx = sp & 1;
+          d.hd_out[(int64_t)roi * (4 * d.hd_rows) + (int64_t)(2 * y + dy) * (2 * d.ct_W) + 2 * x + dx] = sum;
+        }
+      } else if constexpr (EPI == 2) {
+        // first ConvTranspose of the SAM upscaler + LayerNorm2d(64) + GELU (HF:517-520), written as planes of the
+        // NHWC result.  Transposed tile: the lane owns one GEMM row, tiles (j, j+1) are the 64 channels of one
+        // sub-pixel (WTN % 64 == 0), half of them in this lane and half in lane ^ 32.
+        static_assert(TN % 2 == 0, "LayerNorm epilogue needs whole 64-channel groups per wave");
+        if constexpr ((j & 1) == 0) {
+          const f32x16 t1 = acc[i][j + 1];
+          const int row = m0 + wm * WTM + i * 32 + l31;
+          const int cbase = n0 + wn * WTN + j * 32;          // first column of the sub-pixel group
+          float v0[16], v1[16];
+          float sum = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+            v0[r] = t[r] * alpha + (d.bias ? d.bias[cbase + c] : 0.f);
+            v1[r] = t1[r] * alpha + (d.bias ? d.bias[cbase + 32 + c] : 0.f);
+            sum += v0[r] + v1[r];
+          }
+          sum += __shfl_xor(sum, 32, 64);
+          const float mean = sum * (1.0f / 64.0f);
+          float sq = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float a0 = v0[r] - mean, a1 = v1[r] - mean;
+            sq += a0 * a0 + a1 * a1;
+          }
+          sq += __shfl_xor(sq, 32, 64);
+          const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + d.ln_eps);
+          if (row < M && cbase < N) {
+            const int sp = cbase >> 6;                       // sub-pixel (dy, dx)
+            const int yy = row / d.ct_W;
+            const int64_t prow = ((int64_t)(yy * 2 + (sp >> 1)) * d.ct_W + (row - yy * d.ct_W)) * 2 + (sp & 1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              half4_t h0, l0, h1, l1;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int c = e + 8 * g + 4 * hh;
+                const float y0 = rsp_act((v0[4 * g + e] - mean) * rstd * d.ln_gamma[c] + d.ln_beta[c], d.act);
+                const float y1 = rsp_act((v1[4 * g + e] - mean) * rstd * d.ln_gamma[32 + c] + d.ln_beta[32 + c], d.act);
+                half_t a, b;
+                rsp_split1(y0 * cs, a, b); h0[e] = a; l0[e] = b;
+                rsp_split1(y1 * cs, a, b); h1[e] = a; l1[e] = b;
+              }
+              const int64_t po = prow * 32 + 8 * g + 4 * hh;          // channel block 0 of KB32 [2][c_rows][32]
+              *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(d.Chi) + po) = h0;
+              *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(d.Clo) + po) = l0;
+              *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(d.Chi) + (int64_t)d.c_rows * 32 + po) = h1;
+              *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(d.Clo) + (int64_t)d.c_rows * 32 + po) = l1;
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -252,7 +351,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
         if (crow < 0) continue;
         if (d.ct_W > 0) {
           const int yy = crow / d.ct_W;
-          crow = (yy * 2 + d.ct_dy) * d.ct_W + (crow - yy * d.ct_W);
+          crow = (yy * 2 + ct_dyv) * d.ct_W + (crow - yy * d.ct_W);
         }
         float v = t[r] * alpha + bv;
         v = rsp_act(v, d.act);
@@ -264,25 +363,31 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
           }
           v += d.res[rrow * d.ldr + col];
         }
-        if (d.C) d.C[(int64_t)crow * d.ldc + col] = v;
+        if (d.C) d.C[(int64_t)crow * d.ldc + ccol] = v;
         if (d.Chi) {
+          // KB32 planes of the [c_rows, N] result; for a ConvTranspose the planes are those of the NHWC output
+          // [.., ct_c]: the sub-pixel dx folds into the row index
+          int64_t prow = crow;
+          int pch = col;
+          if (d.ct_W > 0) { const int dx = ccol / ct_c; pch = ccol - dx * ct_c; prow = (int64_t)crow * 2 + dx; }
           half_t h, l;
           rsp_split1(v * cs, h, l);
-          const int64_t po = ((int64_t)(col >> 5) * d.c_rows + crow) * 32 + (col & 31);   // KB32 layout
+          const int64_t po = ((int64_t)(pch >> 5) * d.c_rows + prow) * 32 + (pch & 31);
           reinterpret_cast<half_t*>(d.Chi)[po] = h;
           reinterpret_cast<half_t*>(d.Clo)[po] = l;
         }
       }
-    }
-  }
+      }
+    });
+  });
 }
 
-template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0>
+template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0>
 int launch_dma(const RspGemmDesc& d, hipStream_t s) {
   GemmP p; p.d = d;
   const long long nblk = (long long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
   if (nblk > 0x7fffffffLL) return RSP_EINVAL;
-  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF, ABL>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
+  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF, ABL, EPI>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
@@ -292,7 +397,17 @@ int launch_dma(const RspGemmDesc& d, hipStream_t s) {
 // called from rsp_gemm (gemm.hip) when the descriptor carries A planes
 int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (d.a_rows <= 0) return RSP_EINVAL;
+  if (d.hd_out && (!d.hd_hyper || d.ct_W <= 0 || d.N != (d.ct_dy < 0 ? 128 : 64) || d.hd_rows <= 0)) return RSP_EINVAL;
+  if (d.ct_W > 0 && d.ct_dy < 0 && (d.N & 127)) return RSP_EINVAL;
+  if (d.ct_W > 0 && d.Chi && ((d.N >> (d.ct_dy < 0 ? 2 : 1)) & 31)) return RSP_EINVAL;
   if (d.conv_k != 0 && (d.conv_C % BK) != 0) return RSP_EINVAL;
+  if (d.ln_gamma) {
+    if (!d.ln_beta || !(d.Chi && d.Clo) || d.C || d.ct_W <= 0 || d.ct_dy >= 0 || d.N != 256 || d.res || d.c_rowmap)
+      return RSP_EINVAL;
+    return launch_dma<128, 128, 2, 2, 2, 0, 2>(d, s);
+  }
+  if (d.hd_out)
+    return d.N == 128 ? launch_dma<128, 128, 2, 2, 2, 0, 1>(d, s) : launch_dma<128, 64, 2, 2, 3, 0, 1>(d, s);
   auto nblk = [&](int bm, int bn) { return (long long)((d.N + bn - 1) / bn) * ((d.M + bm - 1) / bm); };
   int tile = d.tile_hint;
   if (tile == 0) {   // pick the largest tile that still fills the 256 CUs reasonably

@@ -183,6 +183,14 @@ def convt_weights(w, b):
     return packed, bias2
 
 
+def convt_weights4(w, b):
+    """ConvTranspose2d(k2,s2) weight [Cin, Cout, 2, 2] -> ONE GEMM weight [(dy, dx, co), Cin] + bias tiled x4."""
+    cin = w.shape[0]
+    packed = ops.PackedWeight(w.detach().permute(2, 3, 1, 0).reshape(-1, cin))
+    bias4 = None if b is None else b.detach().repeat(4).contiguous()
+    return packed, bias4
+
+
 @MODELS.register_module()
 class RSSimpleFPN(HIPModule):
     def __init__(self, backbone_channel, in_channels, out_channels, num_outs, conv_cfg=None, norm_cfg=None,

@@ -37,9 +37,11 @@ def set_profiler(p):
     _prof = p
 
 
-def _timed(name, flops, nbytes, fn):
+def _timed(name, flops, nbytes, fn, detail=None):
     if _prof is None:
         return fn()
+    if detail is not None and getattr(_prof, 'shapes', False):
+        name = f'{name} {detail}'
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -169,6 +171,16 @@ class PlaneWeight:
         self.bias = None
 
 
+def _dma_tile_name(m, n, hint=0):
+    """Mirror of the tile choice in rsp_gemm_dma_dispatch (gemm_dma.hip) - profiler labels only."""
+    nblk = lambda bm, bn: -(-n // bn) * -(-m // bm)
+    if hint in (3, 9, 10) or (hint == 0 and n > 128 and nblk(256, 256) >= 384):
+        return '256x256'
+    if hint in (2, 4) or (hint == 0 and n > 64 and nblk(256, 128) >= 384):
+        return '256x128'
+    return '128x128' if n > 64 else ('128x64' if n > 32 else '128x32')
+
+
 def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, c_rowmap=None,
          M=None, out_rows=None, res_mod=0, a_scale_log2=DEFAULT_A_SCALE_LOG2, conv=None,
          res_bmap=None, res_brows=0, out_planes=False, out_f32=True, dma="auto", tile_hint=0):
@@ -239,10 +251,11 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.act = act
     d.a_scale_log2 = a_scale_log2
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
-    tile = '128x128' if n > 64 else ('128x64' if n > 32 else '128x32')
+    tile = _dma_tile_name(m, n, tile_hint) if is_planes else ('128x128' if n > 64 else ('128x64' if n > 32 else '128x32'))
     kname = 'gemm_f16x3_dma_kernel' if is_planes else 'gemm_f16x3_kernel'
     _timed(f'{kname}<{tile}>', 2.0 * m * n * w.K, 4.0 * (m * w.K + m * n) + 4.0 * n * w.K,
-           lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm"))
+           lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm"),
+           detail=f'M={m} N={n} K={w.K}' + (' conv' if conv is not None else ''))
     if out_planes:
         return (out, pl) if out_f32 else pl
     return out
@@ -337,36 +350,79 @@ def preprocess(imgs, mean, std, swap_rb, pad_divisor=1, pad_value=0.0, device=No
     return out
 
 
-def conv_transpose2x2(x_nhwc, w_dy, bias, act=ACT_NONE, a_scale_log2=DEFAULT_A_SCALE_LOG2):
-    """ConvTranspose2d(k=2, s=2) on NHWC as two GEMMs (one per output-row parity).
+def conv_transpose2x2(x_nhwc, w_dy, bias, act=ACT_NONE, a_scale_log2=DEFAULT_A_SCALE_LOG2, out_planes=False,
+                      hyper=None, ln=None):
+    """ConvTranspose2d(k=2, s=2) on NHWC as GEMMs.
 
-    x_nhwc: [B, H, W, Cin]; w_dy: (PackedWeight, PackedWeight) each [(dx, co), Cin] for dy=0/1;
-    bias: [2*Cout] = bias tiled over dx.  returns [B, 2H, 2W, Cout].
-    """
+    x_nhwc: fp32 [B, H, W, Cin] or Planes of that logical shape.
+    w_dy: a pair of PackedWeights [(dx, co), Cin] (one GEMM per output-row parity, bias tiled x2), or ONE
+    PackedWeight [(dy, dx, co), Cin] (all four sub-pixels in one pass over A, bias tiled x4; plane path only).
+    Returns [B, 2H, 2W, Cout] (fp32, or Planes when out_planes).  hyper [B, Cout=32]: fuse
+    `sum_c act(.)[.., c] * hyper[b, c]` into the epilogue and return [B, 2H, 2W] (the SAM decoder's
+    hyper-network product, HF:523-531).  ln=(gamma, beta, eps): LayerNorm2d over the Cout=64 channels of every
+    output pixel before `act` (HF:519-520), one-weight form only, returns Planes."""
     B, H, W, Cin = x_nhwc.shape
-    n2 = w_dy[0].N
-    cout = n2 // 2
-    out = torch.empty((B, 2 * H, 2 * W, cout), dtype=torch.float32, device=x_nhwc.device)
+    four = not isinstance(w_dy, (tuple, list))
+    ws = (w_dy,) if four else tuple(w_dy)
+    cout = ws[0].N // (4 if four else 2)
+    dev = x_nhwc.device
+    if not isinstance(x_nhwc, Planes) and (four or out_planes or hyper is not None
+                                           or (Cin % 32 == 0 and B * H * W >= 4096)):
+        x_nhwc = to_planes(x_nhwc.contiguous(), a_scale_log2)
     a = x_nhwc.view(B * H * W, Cin)
-    o2 = out.view(B * 2 * H * W, n2)
-    for dy in (0, 1):
-        _gemm_ct(a, w_dy[dy], o2, bias, act, W, dy, a_scale_log2)
+    dys = (-1,) if four else (0, 1)
+    if hyper is not None:
+        out = torch.empty((B, 2 * H, 2 * W), dtype=torch.float32, device=dev)
+        for w, dy in zip(ws, dys):
+            _gemm_ct(a, w, None, bias, act, W, dy, a_scale_log2, hyper=hyper, hd_out=out, hd_rows=H * W)
+        return out
+    if ln is not None:
+        if not four or cout != 64:
+            raise ValueError('the fused LayerNorm epilogue needs the one-weight form with Cout == 64')
+        out_planes = True
+    if out_planes:
+        pl = empty_planes((B, 2 * H, 2 * W, cout), dev)
+        for w, dy in zip(ws, dys):
+            _gemm_ct(a, w, None, bias, act, W, dy, a_scale_log2, planes_out=pl, c_rows=B * 4 * H * W, ln=ln)
+        return pl
+    out = torch.empty((B, 2 * H, 2 * W, cout), dtype=torch.float32, device=dev)
+    o2 = out.view(B * 2 * H * W, 2 * cout)
+    for w, dy in zip(ws, dys):
+        _gemm_ct(a, w, o2, bias, act, W, dy, a_scale_log2)
     return out
 
 
-def _gemm_ct(a, w, out, bias, act, ct_W, ct_dy, a_scale_log2):
+def _gemm_ct(a, w, out, bias, act, ct_W, ct_dy, a_scale_log2, planes_out=None, c_rows=0, hyper=None, hd_out=None,
+             hd_rows=0, ln=None):
     lib = _lib.load()
     d = _lib.RspGemmDesc()
-    d.A, d.Bhi, d.Blo, d.C = a.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr(), out.data_ptr()
+    is_pl = isinstance(a, Planes)
+    if is_pl:
+        d.Ahi, d.Alo, d.a_rows = a.hi.data_ptr(), a.lo.data_ptr(), a.rows
+        a_scale_log2 = a.scale_log2
+        d.lda = a.shape[1]
+    else:
+        d.A = a.data_ptr()
+        d.lda = a.stride(0)
+    d.Bhi, d.Blo, d.C = w.hi.data_ptr(), w.lo.data_ptr(), _ptr(out)
     d.bias = _ptr(bias)
     d.M, d.N, d.K = a.shape[0], w.N, w.K
-    d.lda, d.ldc = a.stride(0), out.stride(0)
+    d.ldc = out.stride(0) if out is not None else w.N
     d.act = act
     d.a_scale_log2 = a_scale_log2
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
     d.ct_W, d.ct_dy = ct_W, ct_dy
-    _timed('gemm_f16x3_kernel<convT>', 2.0 * d.M * d.N * d.K, 4.0 * (d.M * d.K + d.M * d.N),
-           lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm(convT)"))
+    if planes_out is not None:
+        # the convT output matrix is [B*2H*W rows of 2*Cout]; as planes of the NHWC tensor [.., Cout] the row index
+        # doubles (dx folds into the row): handled by viewing the plane tensor as [rows, 2*Cout]
+        d.Chi, d.Clo, d.c_scale_log2, d.c_rows = planes_out.hi.data_ptr(), planes_out.lo.data_ptr(), planes_out.scale_log2, c_rows
+    if hd_out is not None:
+        d.hd_hyper, d.hd_out, d.hd_rows = hyper.data_ptr(), hd_out.data_ptr(), hd_rows
+    if ln is not None:
+        d.ln_gamma, d.ln_beta, d.ln_eps = ln[0].data_ptr(), ln[1].data_ptr(), ln[2]
+    _timed('gemm_f16x3_dma_kernel<convT>' if is_pl else 'gemm_f16x3_kernel<convT>', 2.0 * d.M * d.N * d.K, 4.0 * (d.M * d.K + d.M * d.N),
+           lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm(convT)"),
+           detail=f'M={d.M} N={d.N} K={d.K}' + (' hyper' if hd_out is not None else '') + (' ln' if ln is not None else ''))
 
 
 def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v_strides, o_strides,
@@ -387,7 +443,8 @@ def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v
     d.o_bs, d.o_ts, d.o_hs = o_strides
     d.B, d.nh, d.dh, d.Tq, d.Tk, d.scale = B, nh, dh, Tq, Tk, scale
     _timed('attn_kernel<sam_decoder>', 4.0 * B * nh * Tq * Tk * dh, 0,
-           lambda: _lib.check(lib.rsp_attention(d, _stream()), "rsp_attention"))
+           lambda: _lib.check(lib.rsp_attention(d, _stream()), "rsp_attention"),
+           detail=f'B={B} nh={nh} dh={dh} Tq={Tq} Tk={Tk}')
     return out if out_planes is None else out_planes
 
 

@@ -88,7 +88,7 @@ class SamMaskDecoderHIP(HIPModule):
         return ops.PackedWeight(m.weight, m.bias if with_bias else None)
 
     def _pack(self):
-        from .necks import convt_weights
+        from .necks import convt_weights4
         P = {}
         for i in range(2):
             p = f'transformer.layers.{i}'
@@ -99,8 +99,14 @@ class SamMaskDecoderHIP(HIPModule):
             P[f'{i}.lin2'] = self._pw(p + '.mlp.lin2')
         for pr in ('q_proj', 'k_proj', 'v_proj', 'out_proj'):
             P[f'final.{pr}'] = self._pw(f'transformer.final_attn_token_to_image.{pr}')
-        P['up1'] = convt_weights(self.upscale_conv1.weight, self.upscale_conv1.bias)
-        P['up2'] = convt_weights(self.upscale_conv2.weight, self.upscale_conv2.bias)
+        P['up1'] = convt_weights4(self.upscale_conv1.weight, self.upscale_conv1.bias)
+        P['up2'] = convt_weights4(self.upscale_conv2.weight, self.upscale_conv2.bias)
+        # K and V projections of the token->image attentions share their A operand: one [256 -> 128+128] GEMM
+        for pre, p in (('0.cross_attn_token_to_image', 'transformer.layers.0.cross_attn_token_to_image'),
+                       ('1.cross_attn_token_to_image', 'transformer.layers.1.cross_attn_token_to_image'),
+                       ('final', 'transformer.final_attn_token_to_image')):
+            kp, vp = _g(self, p + '.k_proj'), _g(self, p + '.v_proj')
+            P[pre + '.kv_proj'] = ops.PackedWeight(torch.cat([kp.weight, vp.weight], 0))
         for i in range(N_MASK_TOKENS):
             for l in ('proj_in', 'layers.0', 'proj_out'):
                 P[f'hyper{i}.{l}'] = self._pw(f'output_hypernetworks_mlps.{i}.{l}')
@@ -119,6 +125,12 @@ class SamMaskDecoderHIP(HIPModule):
                          '0.cross_attn_image_to_token.q_proj', '1.cross_attn_image_to_token.q_proj',
                          'final.k_proj'):
                 t[name] = ops.gemm(pe_rows, P[name])      # includes the projection bias
+            for pre, p in (('0.cross_attn_token_to_image', 'transformer.layers.0.cross_attn_token_to_image'),
+                           ('1.cross_attn_token_to_image', 'transformer.layers.1.cross_attn_token_to_image'),
+                           ('final', 'transformer.final_attn_token_to_image')):
+                vb = _g(self, p + '.v_proj').bias
+                t[pre + '.kv_proj'] = torch.cat([t[pre + '.k_proj'], vb.unsqueeze(0).expand(pe_rows.shape[0], -1)],
+                                                1).contiguous()
             self._pe_cache = {key: t}
         return self._pe_cache[key]
 
@@ -183,12 +195,12 @@ class SamMaskDecoderHIP(HIPModule):
         # tokens -> image
         qpe = ops.add_rows(q, tokens0)
         tq = ops.gemm(qpe, P['0.cross_attn_token_to_image.q_proj'])
-        k_img = ops.gemm(src_pl, P['0.cross_attn_token_to_image.k_proj'], bias=None,
-                         res=pe_t['0.cross_attn_token_to_image.k_proj'], res_mod=N)      # per image
-        v_img = ops.gemm(src_pl, P['0.cross_attn_token_to_image.v_proj'])
+        kv_img = ops.gemm(src_pl, P['0.cross_attn_token_to_image.kv_proj'], bias=None,
+                          res=pe_t['0.cross_attn_token_to_image.kv_proj'], res_mod=N)    # per image, [K | V]
         ao = torch.empty_like(tq)
-        ops.attention(tq, k_img, v_img, ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
-                      q_strides=(T * d2, d2, dh2), k_strides=(N * d2, d2, dh2), v_strides=(N * d2, d2, dh2),
+        kvs = (N * 2 * d2, 2 * d2, dh2)
+        ops.attention(tq, kv_img, kv_img[:, d2:], ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
+                      q_strides=(T * d2, d2, dh2), k_strides=kvs, v_strides=kvs,
                       o_strides=(T * d2, d2, dh2), kv_batch_map=roi_img)
         q = ops.gemm(ao, P['0.cross_attn_token_to_image.out_proj'], res=q)
         q = self._ln(q, 'transformer.layers.0.layer_norm2')
@@ -207,7 +219,7 @@ class SamMaskDecoderHIP(HIPModule):
                       o_strides=(N * d2, d2, dh2), q_batch_map=roi_img, out_planes=ai)
         keys = ops.gemm(ai, P['0.cross_attn_image_to_token.out_proj'], res=src, res_bmap=roi_img, res_brows=N)
         keys, keys_pl = self._ln(keys, 'transformer.layers.0.layer_norm4', planes=True)   # [R*N, 256] f32 + planes
-        del qi, k_img, v_img
+        del qi, kv_img
 
         # ---------------- layer 1 ----------------
         qpe = ops.add_rows(q, tokens0)
@@ -215,11 +227,10 @@ class SamMaskDecoderHIP(HIPModule):
         q = self._ln(q, 'transformer.layers.1.layer_norm1')
         qpe = ops.add_rows(q, tokens0)
         tq = ops.gemm(qpe, P['1.cross_attn_token_to_image.q_proj'])
-        kk = ops.gemm(keys_pl, P['1.cross_attn_token_to_image.k_proj'], bias=None,
-                      res=pe_t['1.cross_attn_token_to_image.k_proj'], res_mod=N)
-        vv = ops.gemm(keys_pl, P['1.cross_attn_token_to_image.v_proj'])
-        ops.attention(tq, kk, vv, ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
-                      q_strides=(T * d2, d2, dh2), k_strides=(N * d2, d2, dh2), v_strides=(N * d2, d2, dh2),
+        kv = ops.gemm(keys_pl, P['1.cross_attn_token_to_image.kv_proj'], bias=None,
+                      res=pe_t['1.cross_attn_token_to_image.kv_proj'], res_mod=N)
+        ops.attention(tq, kv, kv[:, d2:], ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
+                      q_strides=(T * d2, d2, dh2), k_strides=kvs, v_strides=kvs,
                       o_strides=(T * d2, d2, dh2))
         q = ops.gemm(ao, P['1.cross_attn_token_to_image.out_proj'], res=q)
         q = self._ln(q, 'transformer.layers.1.layer_norm2')
@@ -234,33 +245,34 @@ class SamMaskDecoderHIP(HIPModule):
         ops.attention(qi, kt, vt, None, B=R, nh=HEADS, dh=dh2, Tq=N, Tk=T, scale=dh2 ** -0.5,
                       q_strides=(N * d2, d2, dh2), k_strides=(T * d2, d2, dh2), v_strides=(T * d2, d2, dh2),
                       o_strides=(N * d2, d2, dh2), out_planes=ai)
-        keys = ops.gemm(ai, P['1.cross_attn_image_to_token.out_proj'], res=keys)
-        keys, keys_pl = self._ln(keys, 'transformer.layers.1.layer_norm4', planes=True)
+        keys = ops.gemm(ai, P['1.cross_attn_image_to_token.out_proj'], res=keys, out=keys)
+        m4 = _g(self, 'transformer.layers.1.layer_norm4')
+        keys_pl = ops.layernorm(keys, m4.weight, m4.bias, 1e-6, planes=True, f32=False)   # planes only from here on
+        del keys
 
         # ---------------- final token -> image attention (HF:396-404; LayerNorm default eps 1e-5) ----
         qpe = ops.add_rows(q, tokens0)
         tq = ops.gemm(qpe, P['final.q_proj'])
-        kk = ops.gemm(keys_pl, P['final.k_proj'], bias=None, res=pe_t['final.k_proj'], res_mod=N, out=kk)
-        vv = ops.gemm(keys_pl, P['final.v_proj'], out=vv)
-        ops.attention(tq, kk, vv, ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
-                      q_strides=(T * d2, d2, dh2), k_strides=(N * d2, d2, dh2), v_strides=(N * d2, d2, dh2),
+        kv = ops.gemm(keys_pl, P['final.kv_proj'], bias=None, res=pe_t['final.kv_proj'], res_mod=N, out=kv)
+        ops.attention(tq, kv, kv[:, d2:], ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
+                      q_strides=(T * d2, d2, dh2), k_strides=kvs, v_strides=kvs,
                       o_strides=(T * d2, d2, dh2))
         q = ops.gemm(ao, P['final.out_proj'], res=q)
         q = self._ln(q, 'transformer.layer_norm_final_attn', eps=1e-5)
-        del kk, vv, qi, ai, keys_pl
+        del kv, qi, ai
         q3 = q.view(R, T, HID)
 
         # ---------------- upscaling + hyper-network (HF:513-531) ----------------
-        up = ops.conv_transpose2x2(keys.view(R, h, w, HID), *P['up1'])
-        del keys
-        up = ops.layernorm(up, self.upscale_layer_norm.weight, self.upscale_layer_norm.bias, 1e-6,
-                           act=ops.ACT_GELU)
-        up = ops.conv_transpose2x2(up, *P['up2'], act=ops.ACT_GELU)                     # [R, 4h, 4w, 32]
         mt = q3[:, 1, :].contiguous()           # mask token 0 -> the only mask kept (HF:537-542)
         hy = ops.gemm(mt, P['hyper0.proj_in'], act=ops.ACT_RELU)
         hy = ops.gemm(hy, P['hyper0.layers.0'], act=ops.ACT_RELU)
         hy = ops.gemm(hy, P['hyper0.proj_out'])
-        masks = ops.hyper_mask(up.view(R, 16 * N, HID // 8), hy).view(R, 1, 4 * h, 4 * w)
+        # both ConvTransposes run as one GEMM each (columns = (dy, dx, co), planes in); the second one never
+        # stores its [R, 4h, 4w, 32] result: GELU and the product with hyper_in happen in its epilogue
+        up = ops.conv_transpose2x2(keys_pl.view(R, h, w, HID), *P['up1'], act=ops.ACT_GELU,
+                                   ln=(self.upscale_layer_norm.weight, self.upscale_layer_norm.bias, 1e-6))
+        del keys_pl                                                                     # [R, 2h, 2w, 64] planes
+        masks = ops.conv_transpose2x2(up, *P['up2'], act=ops.ACT_GELU, hyper=hy).view(R, 1, 4 * h, 4 * w)
         iou = None
         if want_iou:
             it = q3[:, 0, :].contiguous()

@@ -165,6 +165,11 @@ def test_patchify_preprocess(dev):
     assert torch.equal(p, ref)
 
 
+def packed_like(w, dev):
+    from rsprompter_amd.necks import convt_weights
+    return convt_weights(w.to(dev), None)[0]
+
+
 def test_conv_transpose_pool_add_sincos(dev):
     from rsprompter_amd import ops
     from rsprompter_amd.necks import convt_weights
@@ -178,6 +183,37 @@ def test_conv_transpose_pool_add_sincos(dev):
     assert _rel_err(got.permute(0, 3, 1, 2), ref) < 2e-6
     got = ops.conv_transpose2x2(x.permute(0, 2, 3, 1).contiguous().to(dev), packed, bias2, act=ops.ACT_GELU)
     assert _rel_err(got.permute(0, 3, 1, 2), F.gelu(ref)) < 2e-6
+    # one-GEMM form (columns = (dy, dx, co)) through the plane path: fp32 out, plane out, fused hyper-network dot
+    from rsprompter_amd.necks import convt_weights4
+    x4 = torch.randn(3, 64, 12, 20, generator=g)
+    w4 = torch.randn(64, 32, 2, 2, generator=g) * 0.1
+    ref4 = F.conv_transpose2d(x4.double(), w4.double(), b.double(), stride=2)
+    pk4, bias4 = convt_weights4(w4.to(dev), b.to(dev))
+    x4h = x4.permute(0, 2, 3, 1).contiguous().to(dev)
+    got = ops.conv_transpose2x2(x4h, pk4, bias4)
+    assert _rel_err(got.permute(0, 3, 1, 2), ref4) < 2e-6
+    pl = ops.conv_transpose2x2(x4h, pk4, bias4, act=ops.ACT_GELU, out_planes=True)
+    K = 32
+    back = (pl.hi.float() + pl.lo.float()).permute(1, 0, 2).reshape(3, 24, 40, K) / 2.0 ** pl.scale_log2
+    assert _rel_err(back.permute(0, 3, 1, 2), F.gelu(ref4)) < 2e-6
+    hyp = torch.randn(3, 32, generator=g)
+    refm = torch.einsum('bchw,bc->bhw', F.gelu(ref4), hyp.double())
+    gotm = ops.conv_transpose2x2(x4h, pk4, bias4, act=ops.ACT_GELU, hyper=hyp.to(dev))
+    assert _rel_err(gotm, refm) < 2e-6
+    gotm2 = ops.conv_transpose2x2(x4h, packed_like(w4, dev), b.to(dev).repeat(2), act=ops.ACT_GELU, hyper=hyp.to(dev))
+    assert _rel_err(gotm2, refm) < 2e-6
+    # ConvTranspose + LayerNorm2d(64) + GELU -> planes (first half of the SAM upscaler)
+    x5 = torch.randn(2, 96, 9, 16, generator=g)
+    w5 = torch.randn(96, 64, 2, 2, generator=g) * 0.1
+    b5 = torch.randn(64, generator=g)
+    gam, bet = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    r5 = F.conv_transpose2d(x5.double(), w5.double(), b5.double(), stride=2).permute(0, 2, 3, 1)
+    r5 = F.gelu(F.layer_norm(r5, (64,), gam.double(), bet.double(), 1e-6))
+    pk5, bias5 = convt_weights4(w5.to(dev), b5.to(dev))
+    pl = ops.conv_transpose2x2(x5.permute(0, 2, 3, 1).contiguous().to(dev), pk5, bias5, act=ops.ACT_GELU,
+                               ln=(gam.to(dev), bet.to(dev), 1e-6))
+    back = (pl.hi.float() + pl.lo.float()).permute(1, 0, 2).reshape(2, 18, 32, 64) / 2.0 ** pl.scale_log2
+    assert _rel_err(back, r5) < 3e-6
     xh = x.permute(0, 2, 3, 1).contiguous().to(dev)
     assert torch.equal(ops.pool2(xh, 0).permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 2, 2))
     assert torch.equal(ops.pool2(xh, 1).permute(0, 3, 1, 2).cpu(), F.max_pool2d(x, 1, stride=2))

@@ -94,16 +94,30 @@ def patchify(img, patch):
     return F.unfold(img, patch, stride=patch).transpose(1, 2).reshape(-1, img.shape[1] * patch * patch)
 
 
-def conv_transpose2x2(x, w_dy, bias, act=0, a_scale_log2=6):
+def conv_transpose2x2(x, w_dy, bias, act=0, a_scale_log2=6, out_planes=False, hyper=None, ln=None):
     B, H, W, C = x.shape
-    cout = w_dy[0].N // 2
-    out = torch.zeros(B, 2 * H, 2 * W, cout)
-    for dy in (0, 1):
-        y = x.reshape(-1, C) @ w_dy[dy].w.t()
+    four = not isinstance(w_dy, (tuple, list))
+    if four:
+        cout = w_dy.N // 4
+        y = x.reshape(-1, C) @ w_dy.w.t()
         if bias is not None:
             y = y + bias
-        y = _act(y, act).view(B, H, W, 2, cout)
-        out[:, dy::2] = y.reshape(B, H, 2 * W, cout)
+        y = y.view(B, H, W, 2, 2, cout)                               # [.., dy, dx, co]
+        if ln is not None:
+            y = F.layer_norm(y, (cout,), ln[0], ln[1], ln[2])
+        y = _act(y, act)
+        out = y.permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, cout)
+    else:
+        cout = w_dy[0].N // 2
+        out = torch.zeros(B, 2 * H, 2 * W, cout)
+        for dy in (0, 1):
+            y = x.reshape(-1, C) @ w_dy[dy].w.t()
+            if bias is not None:
+                y = y + bias
+            y = _act(y, act).view(B, H, W, 2, cout)
+            out[:, dy::2] = y.reshape(B, H, 2 * W, cout)
+    if hyper is not None:
+        return torch.einsum('bhwc,bc->bhw', out, hyper)
     return out
 
 
@@ -120,7 +134,7 @@ def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v
     if out is None:
         out = out_planes
     def view(t, st, T, bmap):
-        nb = t.numel() // st[0] if st[0] else 1
+        nb = (int(bmap.max()) + 1) if bmap is not None else B
         tt = torch.as_strided(t, (nb, T, nh, dh), (st[0], st[1], st[2], 1))
         if bmap is not None:
             tt = tt[bmap.long()]
