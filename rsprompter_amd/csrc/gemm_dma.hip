@@ -26,8 +26,28 @@ constexpr int ROWB = BK * 2;  // bytes per LDS row
 
 __device__ uint4 g_zero_page[16];  // zeros: source of padded rows / out-of-image conv taps
 
+// unsigned division by a run-time constant prepared on the host (Granlund-Montgomery, branch-free form):
+// q = (t + ((x - t) >> sh1)) >> sh2 with t = mulhi(m, x); exact for all 32-bit x.
+struct FastDiv {
+  uint32_t m, sh1, sh2;
+  __device__ __forceinline__ int div(int x) const {
+    const uint32_t t = __umulhi(m, (uint32_t)x);
+    return (int)((t + (((uint32_t)x - t) >> sh1)) >> sh2);
+  }
+};
+static FastDiv make_fastdiv(int dv) {
+  FastDiv f{0u, 0u, 0u};
+  if (dv <= 1) return f;              // q = x
+  uint32_t d = (uint32_t)dv, l = 0;
+  while ((1ull << l) < d) ++l;        // ceil(log2 d)
+  f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  f.sh1 = 1; f.sh2 = l - 1;
+  return f;
+}
+
 struct GemmP {
   RspGemmDesc d;
+  FastDiv fd_ctw, fd_resmod, fd_resb, fd_hd;   // ct_W, res_mod, res_brows, hd_rows
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -63,7 +83,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 // EPI: 0 = generic epilogue, 1 = ConvTranspose + GELU + hyper-network dot (no tile store at all),
 // 2 = ConvTranspose + LayerNorm over each 64-channel sub-pixel + act -> planes (pairs of j tiles)
-template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0>
+template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const GemmP p) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -75,7 +95,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   constexpr int OFF_ALO = BM * ROWB, OFF_BHI = 2 * BM * ROWB, OFF_BLO = 2 * BM * ROWB + BN * ROWB;
 
   constexpr int LPT = NA + NB;   // DMA instructions per wave per tile
-  static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 2) * LPT < 64, "ring depth / vmcnt range");
+  static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 2 + (PIPE != 0)) * LPT < 64, "ring depth / vmcnt range");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF][BUF_BYTES];
 
   const RspGemmDesc& d = p.d;
@@ -110,7 +130,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
     a_src[i] = reinterpret_cast<const unsigned char*>(base);
     a_pix[i] = 0; a_y[i] = 0; a_x[i] = 0;
     if (a_ok[i]) {
-      if (d.conv_k == 0) {
+      if constexpr (!CONV) {
         const int srow = d.a_rowmap ? d.a_rowmap[gm] : gm;
         if (srow < 0) a_ok[i] = false;
         a_src[i] += (int64_t)srow * ROWB + chunk * 16;
@@ -142,35 +162,49 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
 
   const int64_t a_kstride = (int64_t)d.a_rows * ROWB;   // bytes between consecutive K blocks of an A plane
   const int64_t b_kstride = (int64_t)(d.b_rows > 0 ? d.b_rows : N) * ROWB;
-  auto issue_tile = [&](int k0, int buf) {
-    int ky = 0, kx = 0, c0 = 0;
-    if (d.conv_k != 0) {
-      const int tap = k0 / d.conv_C;
-      c0 = k0 - tap * d.conv_C;
-      ky = tap / d.conv_k;
-      kx = tap - ky * d.conv_k;
-    }
+  // branch-free: every lane always issues its DMA; out-of-range sources read the zero page.
+  // TileK = the wave-uniform part of a K tile's addresses; issue_slot<I> = ONE 1-KiB DMA instruction (slots
+  // [0, NA) are A, [NA, LPT) are B), so that the pipelined loop can spread them between its MFMAs.
+  struct TileK { int64_t koff, koffb; int ky, kx; };
+  auto tile_k = [&](int k0) {
+    TileK t;
     const int kb = k0 / BK;
-    unsigned char* lbase = &smem[buf][0];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const unsigned char* src = zero;
-      if (a_ok[i]) {
-        if (d.conv_k == 0) {
-          src = a_src[i] + kb * a_kstride;
-        } else {
-          const int y = a_y[i] + ky, x = a_x[i] + kx;
-          if (y >= 0 && y < d.conv_H && x >= 0 && x < d.conv_W)
-            src = a_src[i] + (c0 / BK) * a_kstride + (a_pix[i] + (int64_t)y * d.conv_W + x) * ROWB + a_chunkb[i];
-        }
+    t.koffb = (int64_t)kb * b_kstride;
+    t.ky = 0; t.kx = 0;
+    if constexpr (!CONV) {
+      t.koff = (int64_t)kb * a_kstride;
+    } else {
+      const int tap = k0 / d.conv_C;
+      const int c0 = k0 - tap * d.conv_C;
+      t.ky = tap / d.conv_k;
+      t.kx = tap - t.ky * d.conv_k;
+      t.koff = (int64_t)(c0 / BK) * a_kstride;
+    }
+    return t;
+  };
+  auto issue_slot = [&](auto ic, const TileK& t, unsigned char* lbase) {
+    constexpr int I = decltype(ic)::value;
+    if constexpr (I < NA) {
+      const unsigned char* src;
+      if constexpr (!CONV) {
+        src = a_ok[I] ? a_src[I] + t.koff : zero;
+      } else {
+        const int y = a_y[I] + t.ky, x = a_x[I] + t.kx;
+        const bool inb = a_ok[I] && (unsigned)y < (unsigned)d.conv_H && (unsigned)x < (unsigned)d.conv_W;
+        src = a_src[I] + t.koff + (a_pix[I] + (int64_t)y * d.conv_W + x) * ROWB + a_chunkb[I];
+        src = inb ? src : zero;
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (i * NT + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (I * NT + wave * 64) * 16), 16, 0, 0);
+    } else {
+      constexpr int J = I - NA;
+      const unsigned char* src = b_ok[J] ? b_src[J] + t.koffb : zero;
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (A_UNITS + J * NT + wave * 64) * 16), 16, 0, 0);
     }
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const unsigned char* src = b_ok[i] ? b_src[i] + kb * b_kstride : zero;
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (A_UNITS + i * NT + wave * 64) * 16), 16, 0, 0);
-    }
+  };
+  auto issue_tile = [&](int k0, int buf) {
+    const TileK t = tile_k(k0);
+    unsigned char* lbase = &smem[buf][0];
+    static_for<0, LPT>([&](auto ic) { issue_slot(ic, t, lbase); });
   };
 
   f32x16 acc[TM][TN];
@@ -197,197 +231,324 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   }
 
   const int nk = K / BK;
-#pragma unroll
-  for (int t = 0; t < NBUF - 1; ++t)
-    if (t < nk) issue_tile(t * BK, t);
 
-  int buf = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tile kt must have landed (this wave's part), newer tiles may stay in flight
-    const int ahead = min(NBUF - 2, nk - 1 - kt);
-    if (ahead >= 2) wait_vmcnt<2 * LPT>();
-    else if (ahead == 1) wait_vmcnt<LPT>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();          // ... and everybody else's part; also: all reads of tile kt-1 are done
-    if (ABL != 1 && kt + NBUF - 1 < nk) {
-      int nb = buf + NBUF - 1;
-      if (nb >= NBUF) nb -= NBUF;
-      issue_tile((kt + NBUF - 1) * BK, nb);
+  struct Frags { half8_t ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto read_frags = [&](const unsigned char* sb, int s, Frags& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      f.ah[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i][s]);
+      f.al[i] = *reinterpret_cast<const half8_t*>(sb + OFF_ALO + a_off[i][s]);
     }
-    const unsigned char* sb = &smem[buf][0];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      half8_t ah[TM], al[TM], bh[TN], bl[TN];
+    for (int j = 0; j < TN; ++j) {
+      f.bh[j] = *reinterpret_cast<const half8_t*>(sb + OFF_BHI + b_off[j][s]);
+      f.bl[j] = *reinterpret_cast<const half8_t*>(sb + OFF_BLO + b_off[j][s]);
+    }
+  };
+  auto mfma_frags = [&](const Frags& f) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i][s]);
-        al[i] = *reinterpret_cast<const half8_t*>(sb + OFF_ALO + a_off[i][s]);
-      }
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const half8_t*>(sb + OFF_BHI + b_off[j][s]);
-        bl[j] = *reinterpret_cast<const half8_t*>(sb + OFF_BLO + b_off[j][s]);
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if (ABL == 2) {   // keep the fragments live without the matrix work
-            asm volatile("" ::"v"(al[i]), "v"(ah[i]), "v"(bl[j]), "v"(bh[j]));
-          } else if constexpr (EPI != 0) {
-            // transposed tile (W A^T): every lane owns ONE output row and 16 of the 32 channels of tile j, so the
-            // channel reduction of the hyper-network epilogue is in-lane (plus one cross-half shuffle)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], al[i], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl[j], ah[i], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh[j], ah[i], acc[i][j], 0, 0, 0);
-          } else {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-          }
+        if (ABL == 2) {   // keep the fragments live without the matrix work
+          asm volatile("" ::"v"(f.al[i]), "v"(f.ah[i]), "v"(f.bl[j]), "v"(f.bh[j]));
+        } else if constexpr (EPI != 0) {
+          // transposed tile (W A^T): every lane owns ONE output row and 16 of the 32 channels of tile j, so the
+          // channel reductions of the fused epilogues are in-lane (plus one cross-half shuffle)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+        } else {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
         }
+      }
+  };
+
+  // the same matrix work with the LPT DMA instructions of one K tile spread between the (i, j) groups: a DMA costs
+  // its wave 60-185 issue cycles (MI355X_MICROARCH.md, per-instruction constants); issued as one burst after the
+  // barrier both waves of a SIMD stall together and the MFMA pipe idles, spread out they cover each other
+  auto mfma_frags_dma = [&](const Frags& f, int k0, int buf, bool do_issue) {
+    const TileK t = tile_k(k0);
+    unsigned char* lbase = &smem[buf][0];
+    constexpr int G = TM * TN;
+    static_for<0, G>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, i = g / TN, j = g % TN;
+      if constexpr (EPI != 0) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+      } else {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (do_issue) static_for<g * LPT / G, (g + 1) * LPT / G>([&](auto sc) { issue_slot(sc, t, lbase); });
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  if constexpr (PIPE == 0) {
+    // ---- plain ring: [wait tile kt | barrier | issue tile kt+NBUF-1 | read+MFMA s0 | read+MFMA s1] ----
+#pragma unroll
+    for (int t = 0; t < NBUF - 1; ++t)
+      if (t < nk) issue_tile(t * BK, t);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+      // tile kt must have landed (this wave's part), newer tiles may stay in flight
+      const int ahead = min(NBUF - 2, nk - 1 - kt);
+      if (ahead >= 2) wait_vmcnt<2 * LPT>();
+      else if (ahead == 1) wait_vmcnt<LPT>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();          // ... and everybody else's part; also: all reads of tile kt-1 are done
+      if (ABL != 1 && kt + NBUF - 1 < nk) {
+        int nb = buf + NBUF - 1;
+        if (nb >= NBUF) nb -= NBUF;
+        issue_tile((kt + NBUF - 1) * BK, nb);
+      }
+      const unsigned char* sb = &smem[buf][0];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        Frags f;
+        read_frags(sb, s, f);
+        mfma_frags(f);
+      }
+      if (++buf == NBUF) buf = 0;
     }
-    if (++buf == NBUF) buf = 0;
+  } else {
+    // ---- register-pipelined ring: the LDS reads of the NEXT half tile are issued before the MFMAs of the current
+    // one, also across the tile boundary, so LDS latency and the barrier hide under matrix work:
+    //   step kt:  F1 = read(kt, s1) ; MFMA(F0)
+    //             wait DMA(kt+1), lgkmcnt(0) ; barrier   (tile kt+1 complete everywhere, buffer kt drained)
+    //             issue DMA(kt+NBUF) -> buffer kt ; F0 = read(kt+1, s0) ; MFMA(F1)
+    // All NBUF buffers are filled up front; a buffer is refilled half a step after its last read.
+#pragma unroll
+    for (int t = 0; t < NBUF; ++t)
+      if (t < nk) issue_tile(t * BK, t);
+    {
+      const int ahead = min(NBUF - 1, nk - 1);
+      if (ahead >= 3) wait_vmcnt<3 * LPT>();
+      else if (ahead == 2) wait_vmcnt<2 * LPT>();
+      else if (ahead == 1) wait_vmcnt<LPT>();
+      else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    // s_waitcnt through the builtin (the compiler's own waitcnt insertion understands it, inline asm it does not):
+    // gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]
+    constexpr int WC_LGKM0 = 0xC07F;                                                     // lgkmcnt(0) only
+    constexpr auto wc_vm_lgkm0 = [](int n) { return (n & 15) | ((n >> 4) << 14) | 0x70; };   // vmcnt(n) lgkmcnt(0)
+    Frags f0, f1;
+    read_frags(&smem[0][0], 0, f0);
+    int buf = 0;
+    for (int kt = 0; kt + 1 < nk; ++kt) {        // every step but the last: straight-line, no joins
+      __builtin_amdgcn_s_waitcnt(WC_LGKM0);       // f0 has landed (issued half a step ago: free)
+      read_frags(&smem[buf][0], 1, f1);
+      __builtin_amdgcn_sched_barrier(0);          // keep the LDS reads AHEAD of the matrix work they overlap with
+      mfma_frags(f0);
+      __builtin_amdgcn_sched_barrier(0);          // ... and the matrix work ahead of the wait + barrier it hides
+      int nb = buf + 1;
+      if (nb == NBUF) nb = 0;
+      const int ahead = min(NBUF - 2, nk - 2 - kt);   // tiles beyond kt+1 that may stay in flight
+      if (NBUF >= 4 && ahead >= 2) __builtin_amdgcn_s_waitcnt(wc_vm_lgkm0(NBUF >= 4 ? 2 * LPT : 0));
+      else if (NBUF >= 3 && ahead == 1) __builtin_amdgcn_s_waitcnt(wc_vm_lgkm0(NBUF >= 3 ? LPT : 0));
+      else __builtin_amdgcn_s_waitcnt(wc_vm_lgkm0(0));
+      __builtin_amdgcn_s_barrier();
+      read_frags(&smem[nb][0], 0, f0);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (PIPE == 2) {
+        mfma_frags_dma(f1, (kt + NBUF) * BK, buf, ABL == 0 && kt + NBUF < nk);   // DMA spread between the MFMAs
+      } else {
+        if (ABL == 0 && kt + NBUF < nk) issue_tile((kt + NBUF) * BK, buf);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_frags(f1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      buf = nb;
+    }
+    __builtin_amdgcn_s_waitcnt(WC_LGKM0);
+    read_frags(&smem[buf][0], 1, f1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_frags(f0);
+    mfma_frags(f1);
   }
 
   // ---- epilogue (same contract as gemm.hip) + optional fp16-plane output for the next GEMM ----
+  // The (i, j) loops are expanded by template recursion: a #pragma unroll the optimizer declines here turns the
+  // accumulator indices dynamic and sends all of acc[][] to scratch.
   const float alpha = d.alpha;
   const float cs = d.Chi ? ldexpf(1.0f, d.c_scale_log2) : 1.0f;
-  // the (i, j) loops are expanded by template recursion: a #pragma unroll the optimizer declines here turns the
-  // accumulator indices dynamic and sends all of acc[][] to scratch
-  static_for<0, TM>([&](auto ic) {
-    static_for<0, TN>([&](auto jc) {
-      constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
-      const f32x16 t = acc[i][j];
-      const int col = n0 + wn * WTN + j * 32 + l31;
-      const bool col_ok = col < N;
-      const float bv = (d.bias && col_ok) ? d.bias[col] : 0.f;
-      // ConvTranspose(k2,s2) column decode: ct_dy >= 0 -> columns are (dx, co) of one output-row parity;
-      // ct_dy < 0 -> columns are (dy, dx, co), all four sub-pixels in one GEMM (A is read once)
-      int ct_dyv = d.ct_dy, ccol = col, ct_c = N >> 1;
-      if (d.ct_W > 0 && d.ct_dy < 0) { ct_dyv = col / (N >> 1); ccol = col - ct_dyv * (N >> 1); ct_c = N >> 2; }
-      if constexpr (EPI == 1) {
-        // last ConvTranspose of the SAM upscaler + GELU + <., hyper_in> (HF:519-531).  acc holds the TRANSPOSED
-        // tile: lane l31 <-> GEMM row (input pixel), register r <-> channel (r&3) + 8(r>>2) + 4hh of the
-        // sub-pixel this 32-column group stands for.  Nothing of the [R, 4h, 4w, 32] tensor is ever stored.
-        const int row = m0 + wm * WTM + i * 32 + l31;
+  half_t* const chi = reinterpret_cast<half_t*>(d.Chi);
+  half_t* const clo = reinterpret_cast<half_t*>(d.Clo);
+
+  if constexpr (EPI == 1) {
+    // last ConvTranspose of the SAM upscaler + GELU + <., hyper_in> (HF:519-531).  acc holds the TRANSPOSED tile:
+    // lane l31 <-> GEMM row (input pixel), register r <-> channel (r&3) + 8(r>>2) + 4hh of the sub-pixel this
+    // 32-column group stands for.  Nothing of the [R, 4h, 4w, 32] tensor is ever stored.
+    static_for<0, TM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int row = m0 + wm * WTM + i * 32 + l31;
+      const bool rok = row < M;
+      const int roi = rok ? p.fd_hd.div(row) : 0;
+      const float* hy = d.hd_hyper + (int64_t)roi * 32;
+      const int pix = rok ? row - roi * d.hd_rows : 0;      // input pixel (y, x) of the ConvTranspose
+      const int y = p.fd_ctw.div(pix), x = pix - y * d.ct_W;
+      static_for<0, TN>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const f32x16 t = acc[i][j];
         const int cbase = n0 + wn * WTN + j * 32;
-        const bool ok = row < M && cbase < N;
-        const int roi = ok ? row / d.hd_rows : 0;
-        const float* hy = d.hd_hyper + (int64_t)roi * 32;
         float sum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const float b = d.bias ? d.bias[cbase + c] : 0.f;
+          const float b = (d.bias && cbase < N) ? d.bias[cbase + c] : 0.f;
           sum += rsp_act(t[r] * alpha + b, d.act) * hy[c];
         }
         sum += __shfl_xor(sum, 32, 64);
-        if (ok && hh == 0) {
-          const int pix = row - roi * d.hd_rows;            // input pixel (y, x) of the ConvTranspose
-          const int y = pix / d.ct_W, x = pix - y * d.ct_W;
+        if (rok && cbase < N && hh == 0) {
           const int sp = cbase >> 5;                        // sub-pixel: (dy, dx) when ct_dy < 0, else dx
           const int dy = d.ct_dy < 0 ? (sp >> 1) : d.ct_dy, dx = sp & 1;
           d.hd_out[(int64_t)roi * (4 * d.hd_rows) + (int64_t)(2 * y + dy) * (2 * d.ct_W) + 2 * x + dx] = sum;
         }
-      } else if constexpr (EPI == 2) {
-        // first ConvTranspose of the SAM upscaler + LayerNorm2d(64) + GELU (HF:517-520), written as planes of the
-        // NHWC result.  Transposed tile: the lane owns one GEMM row, tiles (j, j+1) are the 64 channels of one
-        // sub-pixel (WTN % 64 == 0), half of them in this lane and half in lane ^ 32.
-        static_assert(TN % 2 == 0, "LayerNorm epilogue needs whole 64-channel groups per wave");
-        if constexpr ((j & 1) == 0) {
-          const f32x16 t1 = acc[i][j + 1];
-          const int row = m0 + wm * WTM + i * 32 + l31;
-          const int cbase = n0 + wn * WTN + j * 32;          // first column of the sub-pixel group
-          float v0[16], v1[16];
-          float sum = 0.f;
+      });
+    });
+  } else if constexpr (EPI == 2) {
+    // first ConvTranspose of the SAM upscaler + LayerNorm2d(64) + GELU (HF:517-520), written as planes of the NHWC
+    // result.  Transposed tile: the lane owns one GEMM row, tiles (j, j+1) are the 64 channels of one sub-pixel
+    // (WTN % 64 == 0), half of them in this lane and half in lane ^ 32.
+    static_assert(EPI != 2 || TN % 2 == 0, "LayerNorm epilogue needs whole 64-channel groups per wave");
+    static_for<0, TM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int row = m0 + wm * WTM + i * 32 + l31;
+      const bool rok = row < M;
+      const int yy = rok ? p.fd_ctw.div(row) : 0;
+      const int xx = rok ? row - yy * d.ct_W : 0;
+      static_for<0, TN / 2>([&](auto jc) {
+        constexpr int j = 2 * decltype(jc)::value;
+        const f32x16 t0 = acc[i][j], t1 = acc[i][j + 1];
+        const int cbase = n0 + wn * WTN + j * 32;          // first column of the sub-pixel group
+        const bool cok = cbase < N;
+        float v0[16], v1[16];
+        float sum = 0.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
-            v0[r] = t[r] * alpha + (d.bias ? d.bias[cbase + c] : 0.f);
-            v1[r] = t1[r] * alpha + (d.bias ? d.bias[cbase + 32 + c] : 0.f);
-            sum += v0[r] + v1[r];
-          }
-          sum += __shfl_xor(sum, 32, 64);
-          const float mean = sum * (1.0f / 64.0f);
-          float sq = 0.f;
+        for (int r = 0; r < 16; ++r) {
+          const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
+          v0[r] = t0[r] * alpha + ((d.bias && cok) ? d.bias[cbase + c] : 0.f);
+          v1[r] = t1[r] * alpha + ((d.bias && cok) ? d.bias[cbase + 32 + c] : 0.f);
+          sum += v0[r] + v1[r];
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / 64.0f);
+        float sq = 0.f;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float a0 = v0[r] - mean, a1 = v1[r] - mean;
-            sq += a0 * a0 + a1 * a1;
-          }
-          sq += __shfl_xor(sq, 32, 64);
-          const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + d.ln_eps);
-          if (row < M && cbase < N) {
-            const int sp = cbase >> 6;                       // sub-pixel (dy, dx)
-            const int yy = row / d.ct_W;
-            const int64_t prow = ((int64_t)(yy * 2 + (sp >> 1)) * d.ct_W + (row - yy * d.ct_W)) * 2 + (sp & 1);
+        for (int r = 0; r < 16; ++r) {
+          const float a0 = v0[r] - mean, a1 = v1[r] - mean;
+          sq += a0 * a0 + a1 * a1;
+        }
+        sq += __shfl_xor(sq, 32, 64);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + d.ln_eps);
+        if (rok && cok) {
+          const int sp = cbase >> 6;                       // sub-pixel (dy, dx)
+          const int64_t prow = ((int64_t)(yy * 2 + (sp >> 1)) * d.ct_W + xx) * 2 + (sp & 1);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              half4_t h0, l0, h1, l1;
+          for (int g = 0; g < 4; ++g) {
+            half4_t h0, l0, h1, l1;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) {
-                const int c = e + 8 * g + 4 * hh;
-                const float y0 = rsp_act((v0[4 * g + e] - mean) * rstd * d.ln_gamma[c] + d.ln_beta[c], d.act);
-                const float y1 = rsp_act((v1[4 * g + e] - mean) * rstd * d.ln_gamma[32 + c] + d.ln_beta[32 + c], d.act);
-                half_t a, b;
-                rsp_split1(y0 * cs, a, b); h0[e] = a; l0[e] = b;
-                rsp_split1(y1 * cs, a, b); h1[e] = a; l1[e] = b;
-              }
-              const int64_t po = prow * 32 + 8 * g + 4 * hh;          // channel block 0 of KB32 [2][c_rows][32]
-              *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(d.Chi) + po) = h0;
-              *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(d.Clo) + po) = l0;
-              *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(d.Chi) + (int64_t)d.c_rows * 32 + po) = h1;
-              *reinterpret_cast<half4_t*>(reinterpret_cast<half_t*>(d.Clo) + (int64_t)d.c_rows * 32 + po) = l1;
+            for (int e = 0; e < 4; ++e) {
+              const int c = e + 8 * g + 4 * hh;
+              const float y0 = rsp_act((v0[4 * g + e] - mean) * rstd * d.ln_gamma[c] + d.ln_beta[c], d.act);
+              const float y1 = rsp_act((v1[4 * g + e] - mean) * rstd * d.ln_gamma[32 + c] + d.ln_beta[32 + c], d.act);
+              half_t a, b;
+              rsp_split1(y0 * cs, a, b); h0[e] = a; l0[e] = b;
+              rsp_split1(y1 * cs, a, b); h1[e] = a; l1[e] = b;
             }
+            const int64_t po = prow * 32 + 8 * g + 4 * hh;          // channel block 0 of KB32 [2][c_rows][32]
+            *reinterpret_cast<half4_t*>(chi + po) = h0;
+            *reinterpret_cast<half4_t*>(clo + po) = l0;
+            *reinterpret_cast<half4_t*>(chi + (int64_t)d.c_rows * 32 + po) = h1;
+            *reinterpret_cast<half4_t*>(clo + (int64_t)d.c_rows * 32 + po) = l1;
           }
         }
-      } else {
+      });
+    });
+  } else {
+    // generic: lane l31 <-> column, register r <-> row (r&3) + 8(r>>2) + 4hh.  Everything that depends on the row
+    // only (row maps, the ConvTranspose / residual row arithmetic with host-prepared magic division) is done once
+    // per (i, r); the residual loads of all j are issued back to back from clamped, always-valid addresses so that
+    // no branch sits between a load and the next one.
+    const bool ct = d.ct_W > 0;
+    int colj[TN], ccolj[TN], dyj[TN], pchj[TN], pdxj[TN];
+    float bvj[TN];
+    bool cokj[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * WTN + j * 32 + l31;
+      cokj[j] = col < N;
+      colj[j] = cokj[j] ? col : 0;
+      bvj[j] = (d.bias && cokj[j]) ? d.bias[col] : 0.f;
+      // ConvTranspose(k2,s2) column decode: ct_dy >= 0 -> columns are (dx, co) of one output-row parity;
+      // ct_dy < 0 -> columns are (dy, dx, co), all four sub-pixels in one GEMM (A is read once)
+      int dy = d.ct_dy, ccol = col, ct_c = N >> 1;
+      if (ct && d.ct_dy < 0) { dy = col >= (N >> 1); ccol = col - dy * (N >> 1); ct_c = N >> 2; }
+      dyj[j] = dy; ccolj[j] = ccol;
+      pdxj[j] = (ct && ccol >= ct_c) ? 1 : 0;              // planes of a ConvTranspose are those of the NHWC
+      pchj[j] = ct ? ccol - pdxj[j] * ct_c : col;           // output [.., ct_c]: dx folds into the row index
+    }
+    static_for<0, TM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row >= M || !col_ok) continue;
-        int crow = d.c_rowmap ? d.c_rowmap[row] : row;
-        if (crow < 0) continue;
-        if (d.ct_W > 0) {
-          const int yy = crow / d.ct_W;
-          crow = (yy * 2 + ct_dyv) * d.ct_W + (crow - yy * d.ct_W);
-        }
-        float v = t[r] * alpha + bv;
-        v = rsp_act(v, d.act);
+        const bool rok = row < M;
+        int cr = rok ? row : 0;
+        if (d.c_rowmap) cr = d.c_rowmap[cr];
+        const bool ok = rok && cr >= 0;
+        if (!ok) cr = 0;
+        int ct_base = 0;
+        if (ct) { const int yy = p.fd_ctw.div(cr); ct_base = yy * 2 * d.ct_W + (cr - yy * d.ct_W); }
+        int64_t rrow = cr;
         if (d.res) {
-          int64_t rrow = d.res_mod > 0 ? crow % d.res_mod : crow;
+          if (d.res_mod > 0) rrow = cr - p.fd_resmod.div(cr) * d.res_mod;
           if (d.res_bmap) {
-            const int rb = crow / d.res_brows;
-            rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (crow - rb * d.res_brows);
+            const int rb = p.fd_resb.div(cr);
+            rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (cr - rb * d.res_brows);
           }
-          v += d.res[rrow * d.ldr + col];
         }
-        if (d.C) d.C[(int64_t)crow * d.ldc + ccol] = v;
-        if (d.Chi) {
-          // KB32 planes of the [c_rows, N] result; for a ConvTranspose the planes are those of the NHWC output
-          // [.., ct_c]: the sub-pixel dx folds into the row index
-          int64_t prow = crow;
-          int pch = col;
-          if (d.ct_W > 0) { const int dx = ccol / ct_c; pch = ccol - dx * ct_c; prow = (int64_t)crow * 2 + dx; }
-          half_t h, l;
-          rsp_split1(v * cs, h, l);
-          const int64_t po = ((int64_t)(pch >> 5) * d.c_rows + prow) * 32 + (pch & 31);
-          reinterpret_cast<half_t*>(d.Chi)[po] = h;
-          reinterpret_cast<half_t*>(d.Clo)[po] = l;
-        }
-      }
+        float rv[TN];
+        static_for<0, TN>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          rv[j] = d.res ? d.res[rrow * d.ldr + colj[j]] : 0.f;
+        });
+        static_for<0, TN>([&](auto jc) {
+          constexpr int j = decltype(jc)::value;
+          const float v = rsp_act(acc[i][j][r] * alpha + bvj[j], d.act) + rv[j];
+          const int crow = ct ? ct_base + dyj[j] * d.ct_W : cr;
+          if (ok && cokj[j]) {
+            if (d.C) d.C[(int64_t)crow * d.ldc + ccolj[j]] = v;
+            if (d.Chi) {
+              half_t h, l;
+              rsp_split1(v * cs, h, l);
+              const int64_t prow = ct ? (int64_t)crow * 2 + pdxj[j] : crow;
+              const int64_t po = ((int64_t)(pchj[j] >> 5) * d.c_rows + prow) * 32 + (pchj[j] & 31);   // KB32
+              chi[po] = h;
+              clo[po] = l;
+            }
+          }
+        });
       }
     });
-  });
+  }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0>
+template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false>
 int launch_dma(const RspGemmDesc& d, hipStream_t s) {
   GemmP p; p.d = d;
+  p.fd_ctw = make_fastdiv(d.ct_W); p.fd_resmod = make_fastdiv(d.res_mod);
+  p.fd_resb = make_fastdiv(d.res_brows); p.fd_hd = make_fastdiv(d.hd_rows);
   const long long nblk = (long long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
   if (nblk > 0x7fffffffLL) return RSP_EINVAL;
-  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF, ABL, EPI>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
+  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF, ABL, EPI, PIPE, CONV>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
@@ -397,6 +558,7 @@ int launch_dma(const RspGemmDesc& d, hipStream_t s) {
 // called from rsp_gemm (gemm.hip) when the descriptor carries A planes
 int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (d.a_rows <= 0) return RSP_EINVAL;
+  if (d.ct_W > 0 && d.res) return RSP_EINVAL;   // no caller needs a residual on a ConvTranspose
   if (d.hd_out && (!d.hd_hyper || d.ct_W <= 0 || d.N != (d.ct_dy < 0 ? 128 : 64) || d.hd_rows <= 0)) return RSP_EINVAL;
   if (d.ct_W > 0 && d.ct_dy < 0 && (d.N & 127)) return RSP_EINVAL;
   if (d.ct_W > 0 && d.Chi && ((d.N >> (d.ct_dy < 0 ? 2 : 1)) & 31)) return RSP_EINVAL;
@@ -409,11 +571,20 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (d.hd_out)
     return d.N == 128 ? launch_dma<128, 128, 2, 2, 2, 0, 1>(d, s) : launch_dma<128, 64, 2, 2, 3, 0, 1>(d, s);
   auto nblk = [&](int bm, int bn) { return (long long)((d.N + bn - 1) / bn) * ((d.M + bm - 1) / bm); };
+  // Tile rule (tools/gemm_sweep.py on MI355X; run-to-run spread is a few %): the register-pipelined loops win
+  // everywhere; 256x256 needs >= 4 rounds of blocks over the 256 CUs, 256x128 >= 2, else 128x128 (2 blocks/CU).
+  if (d.conv_k != 0) {   // implicit-GEMM convolutions: CONV instantiations of the same kernels
+    if (d.N > 128 && (d.tile_hint == 17 || (d.tile_hint == 0 && nblk(256, 256) >= 1024)))
+      return launch_dma<256, 256, 2, 4, 2, 0, 0, 2, true>(d, s);
+    if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 0, 0, 1, true>(d, s);
+    if (d.N > 32) return launch_dma<128, 64, 2, 2, 3, 0, 0, 0, true>(d, s);
+    return launch_dma<128, 32, 4, 1, 3, 0, 0, 0, true>(d, s);
+  }
   int tile = d.tile_hint;
-  if (tile == 0) {   // pick the largest tile that still fills the 256 CUs reasonably
-    if (d.N > 128 && nblk(256, 256) >= 384) tile = 3;
-    else if (d.N > 64 && nblk(256, 128) >= 384) tile = 2;
-    else tile = 1;
+  if (tile == 0) {
+    if (d.N > 128 && nblk(256, 256) >= 1024) tile = 17;
+    else if (d.N > 64 && nblk(256, 128) >= 512) tile = 18;
+    else tile = 14;
   }
   switch (tile) {   // hints >= 4 are benchmarking variants of the same arithmetic
     case 3: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2>(d, s); break;
@@ -425,9 +596,19 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
     case 8: if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 2>(d, s); break;   // ablation: no MFMA
     case 9: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 1>(d, s); break;
     case 10: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 2>(d, s); break;
+    case 11: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 0, 0, 1>(d, s); break;   // register-pipelined loops
+    case 12: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2, 0, 0, 1>(d, s); break;
+    case 13: if (d.N > 64) return launch_dma<256, 128, 4, 2, 3, 0, 0, 1>(d, s); break;
+    case 14: if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 0, 0, 1>(d, s); break;
+    case 17: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 0, 0, 2>(d, s); break;   // ... with the DMA spread out
+    case 18: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2, 0, 0, 2>(d, s); break;
+    case 19: if (d.N > 64) return launch_dma<256, 128, 4, 2, 3, 0, 0, 2>(d, s); break;
+    case 20: if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 0, 0, 2>(d, s); break;
+    case 15: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 1, 0, 1>(d, s); break;   // ... without the DMA
+    case 16: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2, 1, 0, 1>(d, s); break;
     default: break;
   }
-  if (d.N > 64) return launch_dma<128, 128, 2, 2, 2>(d, s);
+  if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 0, 0, 1>(d, s);
   if (d.N > 32) return launch_dma<128, 64, 2, 2, 3>(d, s);
   return launch_dma<128, 32, 4, 1, 3>(d, s);
 }

@@ -459,11 +459,11 @@ def test_plane_path_gemm_layernorm_attention(dev):
     assert float((_planes_to_f32(pl).view(Bp, T, nh * dh) - ref).abs().max()) < 2e-5
 
 
-@pytest.mark.parametrize('hint', [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('hint', [0, 1, 2, 3, 4, 5, 6, 11, 12, 13, 14, 17, 18, 19, 20])
 def test_plane_gemm_tile_variants(dev, hint):
     from rsprompter_amd import ops
     g = torch.Generator().manual_seed(30 + hint)
-    for (M, N, K) in [(1000, 700, 256), (513, 257, 96), (300, 3072, 64)]:
+    for (M, N, K) in [(1000, 700, 256), (513, 257, 96), (300, 3072, 64), (700, 300, 32)]:
         a = torch.randn(M, K, generator=g)
         w = torch.randn(N, K, generator=g) * 0.05
         b = torch.randn(N, generator=g)
