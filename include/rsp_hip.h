@@ -174,6 +174,18 @@ typedef struct RspAttnDesc {
 } RspAttnDesc;
 int rsp_attention(const RspAttnDesc* desc, rsp_stream_t stream);
 
+/* SAM two-way transformer cross attentions, internal width 128 = 8 heads x 16 (HF:243-288 as used by HF:306-348 and */
+/* HF:396-404), exact fp32:                                                                                          */
+/*  token -> image: q [R,T,128] (T <= 12), kv [Rkv*N, 256] = image rows with K | V side by side, kv_map[r] = image    */
+/*  row block of RoI r (NULL: r); out [R,T,128].                                                                      */
+int rsp_sam_t2i_attention(const float* q, const float* kv, const int32_t* kv_map, float* out, int32_t R, int32_t T,
+                          int32_t N, float scale, rsp_stream_t stream);
+/*  image -> token: q [Rq*N,128] image-side queries (q_map[r] = row block, NULL: r), k, v [R,T,128] (T <= 16);        */
+/*  result [R*N,128] as fp32 `out` and/or fp16 planes (KB32, value * 2^out_scale_log2).                               */
+int rsp_sam_i2t_attention(const float* q, const int32_t* q_map, const float* k, const float* v, float* out,
+                          uint16_t* out_hi, uint16_t* out_lo, int32_t out_scale_log2, int32_t R, int32_t T, int32_t N,
+                          float scale, rsp_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* RoI feature extraction (single_level_roi_extractor.py:44-119 + mmcv RoIAlign, */
 /* sampling_ratio=0, aligned=True) over <=4 NHWC levels; `pe` adds an          */

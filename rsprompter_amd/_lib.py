@@ -92,6 +92,9 @@ PROTOTYPES = {
                                ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_float, c_void_p]),
     "rsp_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rsp_attention": (c_int, [ctypes.POINTER(RspAttnDesc), c_void_p]),
+    "rsp_sam_t2i_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "rsp_sam_i2t_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                      c_int, c_int, c_int, c_float, c_void_p]),
     "rsp_roi_align": (c_int, [ctypes.POINTER(RspRoiAlignDesc), c_void_p]),
     "rsp_rpn_topk": (c_int, [ctypes.POINTER(RspRpnDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsp_rpn_decode": (c_int, [ctypes.POINTER(RspRpnDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

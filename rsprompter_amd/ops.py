@@ -448,6 +448,45 @@ def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v
     return out if out_planes is None else out_planes
 
 
+SAM_T2I_MAX_TOKENS = 12     # rsp_sam_t2i_attention; more tokens go through the generic rsp_attention
+SAM_I2T_MAX_TOKENS = 16
+
+
+def sam_t2i_attention(q, kv, out, *, R, T, N, scale, kv_map=None):
+    """SAM decoder token->image attention (8 heads x 16, exact fp32). q [R*T,128], kv [Rkv*N,256] = K|V, out [R*T,128]."""
+    lib = _lib.load()
+    for t, n in ((q, 'q'), (kv, 'kv'), (out, 'out')):
+        _chk_f32(t, n)
+        if not t.is_contiguous():
+            raise ValueError(f'sam_t2i_attention: {n} must be contiguous')
+    if q.shape[-1] != 128 or kv.shape[-1] != 256:
+        raise ValueError('sam_t2i_attention expects internal width 128 (q) and fused K|V rows of 256')
+    _timed('sam_t2i_kernel', 4.0 * R * T * N * 128, 4.0 * R * N * 256,
+           lambda: _lib.check(lib.rsp_sam_t2i_attention(q.data_ptr(), kv.data_ptr(), _ptr(kv_map), out.data_ptr(),
+                                                        R, T, N, scale, _stream()), "rsp_sam_t2i_attention"),
+           detail=f'R={R} T={T} N={N}')
+    return out
+
+
+def sam_i2t_attention(q, k, v, *, R, T, N, scale, q_map=None, out=None, out_planes=None):
+    """SAM decoder image->token attention. q [Rq*N,128], k/v [R*T,128]; result [R*N,128] into `out` and/or Planes."""
+    lib = _lib.load()
+    for t, n in ((q, 'q'), (k, 'k'), (v, 'v')):
+        _chk_f32(t, n)
+        if not t.is_contiguous():
+            raise ValueError(f'sam_i2t_attention: {n} must be contiguous')
+    hi = lo = 0
+    e = 0
+    if out_planes is not None:
+        hi, lo, e = out_planes.hi.data_ptr(), out_planes.lo.data_ptr(), out_planes.scale_log2
+    _timed('sam_i2t_kernel', 4.0 * R * T * N * 128, 4.0 * R * N * 128 * 2,
+           lambda: _lib.check(lib.rsp_sam_i2t_attention(q.data_ptr(), _ptr(q_map), k.data_ptr(), v.data_ptr(),
+                                                        _ptr(out), hi, lo, e, R, T, N, scale, _stream()),
+                              "rsp_sam_i2t_attention"),
+           detail=f'R={R} T={T} N={N}')
+    return out if out_planes is None else out_planes
+
+
 def roi_align(feats_nhwc, pes, rois, P, strides, finest_scale=56):
     """feats_nhwc: list of [B,H,W,C]; pes: list of [H,W,C] or None; rois [K,5] -> [K,P,P,C]."""
     lib = _lib.load()

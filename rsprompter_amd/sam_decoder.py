@@ -139,6 +139,25 @@ class SamMaskDecoderHIP(HIPModule):
         m = _g(self, name)
         return ops.layernorm(x, m.weight, m.bias, eps, planes=planes)
 
+    def _t2i(self, tq, kv, ao, R, T, N, kv_map=None):
+        """tokens -> image attention on the fused [K | V] projection (HF:326-331, 397-400)."""
+        d2, dh2 = HID // 2, (HID // 2) // HEADS
+        if T <= ops.SAM_T2I_MAX_TOKENS:
+            return ops.sam_t2i_attention(tq, kv, ao, R=R, T=T, N=N, scale=dh2 ** -0.5, kv_map=kv_map)
+        kvs = (N * 2 * d2, 2 * d2, dh2)
+        return ops.attention(tq, kv, kv[:, d2:], ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
+                             q_strides=(T * d2, d2, dh2), k_strides=kvs, v_strides=kvs,
+                             o_strides=(T * d2, d2, dh2), kv_batch_map=kv_map)
+
+    def _i2t(self, qi, kt, vt, ai, R, T, N, q_map=None):
+        """image -> tokens attention; the result feeds the out_proj GEMM as planes (HF:340-345)."""
+        d2, dh2 = HID // 2, (HID // 2) // HEADS
+        if T <= ops.SAM_I2T_MAX_TOKENS:
+            return ops.sam_i2t_attention(qi, kt, vt, R=R, T=T, N=N, scale=dh2 ** -0.5, q_map=q_map, out_planes=ai)
+        return ops.attention(qi, kt, vt, None, B=R, nh=HEADS, dh=dh2, Tq=N, Tk=T, scale=dh2 ** -0.5,
+                             q_strides=(N * d2, d2, dh2), k_strides=(T * d2, d2, dh2), v_strides=(T * d2, d2, dh2),
+                             o_strides=(N * d2, d2, dh2), q_batch_map=q_map, out_planes=ai)
+
     def _token_attn(self, q_in, k_in, v_in, pfx, R, T, res=None):
         """SamAttention among the T prompt tokens of each RoI (self attention, internal dim 256)."""
         P = self._packed
@@ -198,10 +217,7 @@ class SamMaskDecoderHIP(HIPModule):
         kv_img = ops.gemm(src_pl, P['0.cross_attn_token_to_image.kv_proj'], bias=None,
                           res=pe_t['0.cross_attn_token_to_image.kv_proj'], res_mod=N)    # per image, [K | V]
         ao = torch.empty_like(tq)
-        kvs = (N * 2 * d2, 2 * d2, dh2)
-        ops.attention(tq, kv_img, kv_img[:, d2:], ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
-                      q_strides=(T * d2, d2, dh2), k_strides=kvs, v_strides=kvs,
-                      o_strides=(T * d2, d2, dh2), kv_batch_map=roi_img)
+        self._t2i(tq, kv_img, ao, R, T, N, kv_map=roi_img)
         q = ops.gemm(ao, P['0.cross_attn_token_to_image.out_proj'], res=q)
         q = self._ln(q, 'transformer.layers.0.layer_norm2')
         hmid = ops.gemm(q, P['0.lin1'], act=ops.ACT_RELU)
@@ -214,9 +230,7 @@ class SamMaskDecoderHIP(HIPModule):
         kt = ops.gemm(qpe, P['0.cross_attn_image_to_token.k_proj'])
         vt = ops.gemm(q, P['0.cross_attn_image_to_token.v_proj'])
         ai = ops.empty_planes((R * N, d2), dev)      # attention output goes straight to the out_proj GEMM as planes
-        ops.attention(qi, kt, vt, None, B=R, nh=HEADS, dh=dh2, Tq=N, Tk=T, scale=dh2 ** -0.5,
-                      q_strides=(N * d2, d2, dh2), k_strides=(T * d2, d2, dh2), v_strides=(T * d2, d2, dh2),
-                      o_strides=(N * d2, d2, dh2), q_batch_map=roi_img, out_planes=ai)
+        self._i2t(qi, kt, vt, ai, R, T, N, q_map=roi_img)
         keys = ops.gemm(ai, P['0.cross_attn_image_to_token.out_proj'], res=src, res_bmap=roi_img, res_brows=N)
         keys, keys_pl = self._ln(keys, 'transformer.layers.0.layer_norm4', planes=True)   # [R*N, 256] f32 + planes
         del qi, kv_img
@@ -229,9 +243,7 @@ class SamMaskDecoderHIP(HIPModule):
         tq = ops.gemm(qpe, P['1.cross_attn_token_to_image.q_proj'])
         kv = ops.gemm(keys_pl, P['1.cross_attn_token_to_image.kv_proj'], bias=None,
                       res=pe_t['1.cross_attn_token_to_image.kv_proj'], res_mod=N)
-        ops.attention(tq, kv, kv[:, d2:], ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
-                      q_strides=(T * d2, d2, dh2), k_strides=kvs, v_strides=kvs,
-                      o_strides=(T * d2, d2, dh2))
+        self._t2i(tq, kv, ao, R, T, N)
         q = ops.gemm(ao, P['1.cross_attn_token_to_image.out_proj'], res=q)
         q = self._ln(q, 'transformer.layers.1.layer_norm2')
         hmid = ops.gemm(q, P['1.lin1'], act=ops.ACT_RELU)
@@ -242,9 +254,7 @@ class SamMaskDecoderHIP(HIPModule):
                       res=pe_t['1.cross_attn_image_to_token.q_proj'], res_mod=N)
         kt = ops.gemm(qpe, P['1.cross_attn_image_to_token.k_proj'])
         vt = ops.gemm(q, P['1.cross_attn_image_to_token.v_proj'])
-        ops.attention(qi, kt, vt, None, B=R, nh=HEADS, dh=dh2, Tq=N, Tk=T, scale=dh2 ** -0.5,
-                      q_strides=(N * d2, d2, dh2), k_strides=(T * d2, d2, dh2), v_strides=(T * d2, d2, dh2),
-                      o_strides=(N * d2, d2, dh2), out_planes=ai)
+        self._i2t(qi, kt, vt, ai, R, T, N)
         keys = ops.gemm(ai, P['1.cross_attn_image_to_token.out_proj'], res=keys, out=keys)
         m4 = _g(self, 'transformer.layers.1.layer_norm4')
         keys_pl = ops.layernorm(keys, m4.weight, m4.bias, 1e-6, planes=True, f32=False)   # planes only from here on
@@ -254,9 +264,7 @@ class SamMaskDecoderHIP(HIPModule):
         qpe = ops.add_rows(q, tokens0)
         tq = ops.gemm(qpe, P['final.q_proj'])
         kv = ops.gemm(keys_pl, P['final.kv_proj'], bias=None, res=pe_t['final.kv_proj'], res_mod=N, out=kv)
-        ops.attention(tq, kv, kv[:, d2:], ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
-                      q_strides=(T * d2, d2, dh2), k_strides=kvs, v_strides=kvs,
-                      o_strides=(T * d2, d2, dh2))
+        self._t2i(tq, kv, ao, R, T, N)
         q = ops.gemm(ao, P['final.out_proj'], res=q)
         q = self._ln(q, 'transformer.layer_norm_final_attn', eps=1e-5)
         del kv, qi, ai

@@ -477,3 +477,38 @@ def test_plane_gemm_tile_variants(dev, hint):
     pw = ops.PackedWeight(cw.permute(0, 2, 3, 1).reshape(300, -1), None, device=dev)
     got = ops.gemm(ops.to_planes(x.permute(0, 2, 3, 1).contiguous().to(dev)), pw, conv=(3, 1, 1), tile_hint=hint)
     assert _rel_err(got.view(2, 20, 24, 300).permute(0, 3, 1, 2), ref) < 2e-6
+
+
+@pytest.mark.parametrize('T', [7, 10, 12])
+def test_sam_cross_attention_kernels(dev, T):
+    """rsp_sam_t2i_attention / rsp_sam_i2t_attention against fp64 softmax attention (HF:243-288 semantics)."""
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(50 + T)
+    R, Rimg, N = 5, 2, 1000 if T != 10 else 4096
+    scale = 16 ** -0.5
+    q = torch.randn(R, T, 128, generator=g)
+    kv = torch.randn(Rimg, N, 256, generator=g)
+    kv[..., :128] *= 2.0          # spread the scores so that the online softmax rescaling is exercised
+    mp = torch.tensor([0, 1, 1, 0, 1], dtype=torch.int32)
+    kk = kv[mp.long()][..., :128].view(R, N, 8, 16).permute(0, 2, 1, 3).double()
+    vv = kv[mp.long()][..., 128:].view(R, N, 8, 16).permute(0, 2, 1, 3).double()
+    qq = q.view(R, T, 8, 16).permute(0, 2, 1, 3).double()
+    ref = ((qq * scale) @ kk.transpose(-1, -2)).softmax(-1) @ vv
+    ref = ref.permute(0, 2, 1, 3).reshape(R, T, 128)
+    out = torch.empty(R * T, 128, device=dev)
+    ops.sam_t2i_attention(q.view(R * T, 128).to(dev), kv.view(Rimg * N, 256).to(dev), out, R=R, T=T, N=N, scale=scale,
+                          kv_map=mp.to(dev))
+    assert float((out.cpu().view(R, T, 128) - ref).abs().max()) < 2e-6
+    # image -> token
+    qi = torch.randn(Rimg, N, 128, generator=g) * 2.0
+    kt, vt = torch.randn(R, T, 128, generator=g), torch.randn(R, T, 128, generator=g)
+    qq = qi[mp.long()].view(R, N, 8, 16).permute(0, 2, 1, 3).double()
+    kk = kt.view(R, T, 8, 16).permute(0, 2, 1, 3).double()
+    vv = vt.view(R, T, 8, 16).permute(0, 2, 1, 3).double()
+    ref = (((qq * scale) @ kk.transpose(-1, -2)).softmax(-1) @ vv).permute(0, 2, 1, 3).reshape(R * N, 128)
+    o32 = torch.empty(R * N, 128, device=dev)
+    pl = ops.empty_planes((R * N, 128), dev)
+    ops.sam_i2t_attention(qi.view(Rimg * N, 128).to(dev), kt.view(R * T, 128).to(dev), vt.view(R * T, 128).to(dev),
+                          R=R, T=T, N=N, scale=scale, q_map=mp.to(dev), out=o32, out_planes=pl)
+    assert float((o32.cpu() - ref).abs().max()) < 2e-6
+    assert float((_planes_to_f32(pl) - ref).abs().max()) < 4e-6

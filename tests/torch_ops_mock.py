@@ -146,6 +146,33 @@ def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v
     return out
 
 
+SAM_T2I_MAX_TOKENS = 12
+SAM_I2T_MAX_TOKENS = 16
+
+
+def sam_t2i_attention(q, kv, out, *, R, T, N, scale, kv_map=None):
+    qq = q.view(R, T, 8, 16).permute(0, 2, 1, 3)
+    kvv = kv.view(-1, N, 2, 8, 16)
+    if kv_map is not None:
+        kvv = kvv[kv_map.long()]
+    kk, vv = kvv[:, :, 0].permute(0, 2, 1, 3), kvv[:, :, 1].permute(0, 2, 1, 3)
+    o = ((qq * scale) @ kk.transpose(-1, -2)).softmax(-1) @ vv
+    out.view(R, T, 8, 16).copy_(o.permute(0, 2, 1, 3))
+    return out
+
+
+def sam_i2t_attention(q, k, v, *, R, T, N, scale, q_map=None, out=None, out_planes=None):
+    qq = q.view(-1, N, 8, 16)
+    if q_map is not None:
+        qq = qq[q_map.long()]
+    qq = qq.permute(0, 2, 1, 3)
+    kk, vv = k.view(R, T, 8, 16).permute(0, 2, 1, 3), v.view(R, T, 8, 16).permute(0, 2, 1, 3)
+    o = ((qq * scale) @ kk.transpose(-1, -2)).softmax(-1) @ vv
+    dst = out_planes if out_planes is not None else out
+    dst.view(R, N, 8, 16).copy_(o.permute(0, 2, 1, 3))
+    return dst
+
+
 def add_rows(x, v, vmod=None, out=None):
     C = x.shape[-1]
     rows = x.numel() // C
