@@ -21,6 +21,16 @@ FLAGS = [
 ]
 
 
+def file_flags(src):
+    """Extra per-file flags: a `// hipcc-flags: ...` line among the first lines of the source."""
+    with open(src) as f:
+        for _ in range(5):
+            line = f.readline()
+            if line.startswith("// hipcc-flags:"):
+                return line.split(":", 1)[1].split()
+    return []
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -49,7 +59,7 @@ def build(force=False, verbose=True):
     os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
     for src in sources():
         obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
-        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + file_flags(src) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd)))

@@ -351,74 +351,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   }
 }
 
-// rel[bh, t, 0:S] = q . Rh[qh - kh + S-1], rel[bh, t, S:2S] = q . Rw[qw - kw + S-1]
-// plain fp32 FMA dot products (same arithmetic class as the reference einsum).
-template <int DH>
-__global__ __launch_bounds__(256) void vit_relpos_kernel(const float* __restrict__ qkv,
-                                                         const float* __restrict__ rph,
-                                                         const float* __restrict__ rpw,
-                                                         float* __restrict__ rel, int T, int S,
-                                                         int nh) {
-  extern __shared__ float smem[];
-  constexpr int LD = DH + 1;
-  const int nrow = 2 * S - 1;
-  float* sH = smem;                 // [nrow][LD]
-  float* sW = sH + nrow * LD;       // [nrow][LD]
-  float* sQ = sW + nrow * LD;       // [64][LD]
-  const int tid = threadIdx.x;
-  const int bp = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
-  for (int idx = tid; idx < nrow * DH; idx += 256) {
-    const int r = idx / DH, d = idx - r * DH;
-    sH[r * LD + d] = rph[idx];
-    sW[r * LD + d] = rpw[idx];
-  }
-  const int64_t tok_stride = (int64_t)3 * nh * DH;
-  for (int idx = tid; idx < 64 * DH; idx += 256) {
-    const int r = idx / DH, d = idx - r * DH;
-    const int q = q0 + r;
-    sQ[r * LD + d] = (q < T) ? qkv[((int64_t)bp * T + q) * tok_stride + (int64_t)h * DH + d] : 0.f;
-  }
-  __syncthreads();
-  const int W2 = 2 * S;
-  for (int o = tid; o < 64 * W2; o += 256) {
-    const int r = o / W2, j = o - r * W2;
-    const int q = q0 + r;
-    if (q >= T) continue;
-    const int qy = q / S, qx = q - qy * S;
-    const float* tab = (j < S) ? (sH + (qy - j + S - 1) * LD) : (sW + (qx - (j - S) + S - 1) * LD);
-    const float* qv = sQ + r * LD;
-    float acc = 0.f;
-#pragma unroll 8
-    for (int d = 0; d < DH; ++d) acc = fmaf(qv[d], tab[d], acc);
-    rel[(((int64_t)bp * nh + h) * T + q) * W2 + j] = acc;
-  }
-}
-
 }  // namespace
-
-extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const float* rel_pos_w,
-                              float* rel, int32_t Bp, int32_t S, int32_t nh, int32_t dh,
-                              rsp_stream_t stream) {
-  if (!qkv || !rel_pos_h || !rel_pos_w || !rel || Bp <= 0 || S <= 0 || S > 64 || nh <= 0)
-    return RSP_EINVAL;
-  const int T = S * S;
-  dim3 grid((T + 63) / 64, nh, Bp);
-  const size_t smem = (size_t)(2 * (2 * S - 1) + 64) * (dh + 1) * sizeof(float);
-  hipStream_t s = (hipStream_t)stream;
-  if (dh == 64) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_relpos_kernel<64>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((vit_relpos_kernel<64>), grid, dim3(256), smem, s, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh);
-  } else if (dh == 80) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_relpos_kernel<80>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((vit_relpos_kernel<80>), grid, dim3(256), smem, s, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh);
-  } else {
-    return RSP_EINVAL;
-  }
-  RSP_CHECK_LAUNCH();
-  return RSP_OK;
-}
 
 template <int DH, int REL, bool MASK>
 static int launch_attn(const AttnP& p, int B, hipStream_t s) {

@@ -72,18 +72,35 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const MaskPostP p) {
     const float v10 = low[ay.i1 * p.w + ax.i0], v11 = low[ay.i1 * p.w + ax.i1];
     return ay.l0 * (ax.l0 * v00 + ax.l1 * v01) + ay.l1 * (ax.l0 * v10 + ax.l1 * v11);
   };
+  auto pixel = [&](int oy, int ox) -> float {
+    if (IDENT) return stage1(oy, ox);
+    const Lin cy = lin_coef(oy, s2h, p.ch), cx = lin_coef(ox, s2w, p.cw);
+    const float a00 = stage1(cy.i0, cx.i0), a01 = stage1(cy.i0, cx.i1);
+    const float a10 = stage1(cy.i1, cx.i0), a11 = stage1(cy.i1, cx.i1);
+    return cy.l0 * (cx.l0 * a00 + cx.l1 * a01) + cy.l1 * (cx.l0 * a10 + cx.l1 * a11);
+  };
+  if ((p.ow & 3) == 0) {
+    // four pixels of one row per thread: one 32-bit store of the bool mask instead of four byte stores
+    const int qw = p.ow >> 2;
+    const int nq = p.oh * qw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
+      const int oy = i / qw, ox = (i - oy * qw) << 2;
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = pixel(oy, ox + e);
+      uint32_t bits = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bits |= (v[e] >= p.thr ? 1u : 0u) << (8 * e);
+      const int64_t o = (int64_t)m * total + (int64_t)oy * p.ow + ox;
+      *reinterpret_cast<uint32_t*>(p.out + o) = bits;
+      if (p.prob) *reinterpret_cast<f32x4*>(p.prob + o) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int oy = (int)(i / p.ow), ox = (int)(i - (int64_t)oy * p.ow);
-    float val;
-    if (IDENT) {
-      val = stage1(oy, ox);
-    } else {
-      const Lin cy = lin_coef(oy, s2h, p.ch), cx = lin_coef(ox, s2w, p.cw);
-      const float a00 = stage1(cy.i0, cx.i0), a01 = stage1(cy.i0, cx.i1);
-      const float a10 = stage1(cy.i1, cx.i0), a11 = stage1(cy.i1, cx.i1);
-      val = cy.l0 * (cx.l0 * a00 + cx.l1 * a01) + cy.l1 * (cx.l0 * a10 + cx.l1 * a11);
-    }
+    const float val = pixel(oy, ox);
     p.out[(int64_t)m * total + i] = val >= p.thr ? 1 : 0;
     if (p.prob) p.prob[(int64_t)m * total + i] = val;
   }
@@ -118,7 +135,8 @@ extern "C" int rsp_mask_post(const float* low_res, float* sig_ws, int32_t k, int
   MaskPostP p;
   p.low = sig_ws; p.out = out_mask; p.prob = out_prob; p.k = k; p.h = h; p.w = w; p.Hb = Hb; p.Wb = Wb;
   p.ch = crop_h; p.cw = crop_w; p.oh = out_h; p.ow = out_w; p.thr = thr;
-  int64_t gx = ((int64_t)out_h * out_w + 255) / 256;
+  if ((int64_t)out_h * out_w > 0x7fffffffLL) return RSP_EINVAL;
+  int64_t gx = ((int64_t)out_h * out_w / ((out_w & 3) == 0 ? 4 : 1) + 255) / 256;
   if (gx > 4096) gx = 4096;
   if (crop_h == out_h && crop_w == out_w)
     hipLaunchKernelGGL((mask_post_kernel<true>), dim3((unsigned)gx, k), dim3(256), 0, (hipStream_t)stream, p);

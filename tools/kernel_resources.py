@@ -2,7 +2,9 @@
 import re, subprocess, sys, os
 src = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
+sys.path.insert(0, root)
+from rsprompter_amd.build import file_flags  # noqa: E402
+cmd = ['/opt/rocm/bin/hipcc'] + file_flags(src) + ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off',
        f'-I{root}/include', '-c', src, '-o', '/tmp/_kr.o', '-Rpass-analysis=kernel-resource-usage']
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None
