@@ -473,70 +473,112 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
       });
     });
   } else {
-    // generic: lane l31 <-> column, register r <-> row (r&3) + 8(r>>2) + 4hh.  Everything that depends on the row
-    // only (row maps, the ConvTranspose / residual row arithmetic with host-prepared magic division) is done once
-    // per (i, r); the residual loads of all j are issued back to back from clamped, always-valid addresses so that
-    // no branch sits between a load and the next one.
+    // generic epilogue, staged through LDS: the accumulators (lane <-> column, register <-> row) are written to the
+    // now idle ring as an fp32 tile [rows][BN] (alpha, bias and activation already applied), then read back ROW-wise
+    // so that every thread owns 4 consecutive columns of one row: residual loads, fp32 stores and plane stores are
+    // 16-/8-byte accesses on whole cache lines (a wave writes one full output row per instruction) instead of one
+    // dword (or one half!) per lane.  Row-only work (row maps, ConvTranspose / residual row arithmetic with the
+    // host-prepared magic division) happens once per 4 outputs.
+    constexpr int LDS_FLOATS = NBUF * BUF_BYTES / 4;
+    constexpr int IP_MAX = LDS_FLOATS / (WGM * 32 * BN);
+    static_assert(IP_MAX >= 1, "epilogue tile does not fit the LDS ring");
+    constexpr int IP = IP_MAX >= TM ? TM : (IP_MAX >= 2 && TM % 2 == 0 ? 2 : 1);   // i-tiles per pass
+    constexpr int NPASS = TM / IP;
+    constexpr int ROWS_P = WGM * 32 * IP;
+    constexpr int C4 = BN / 4;                      // float4 units per tile row
+    float* stile = reinterpret_cast<float*>(&smem[0][0]);
     const bool ct = d.ct_W > 0;
-    int colj[TN], ccolj[TN], dyj[TN], pchj[TN], pdxj[TN];
     float bvj[TN];
-    bool cokj[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = n0 + wn * WTN + j * 32 + l31;
-      cokj[j] = col < N;
-      colj[j] = cokj[j] ? col : 0;
-      bvj[j] = (d.bias && cokj[j]) ? d.bias[col] : 0.f;
-      // ConvTranspose(k2,s2) column decode: ct_dy >= 0 -> columns are (dx, co) of one output-row parity;
-      // ct_dy < 0 -> columns are (dy, dx, co), all four sub-pixels in one GEMM (A is read once)
-      int dy = d.ct_dy, ccol = col, ct_c = N >> 1;
-      if (ct && d.ct_dy < 0) { dy = col >= (N >> 1); ccol = col - dy * (N >> 1); ct_c = N >> 2; }
-      dyj[j] = dy; ccolj[j] = ccol;
-      pdxj[j] = (ct && ccol >= ct_c) ? 1 : 0;              // planes of a ConvTranspose are those of the NHWC
-      pchj[j] = ct ? ccol - pdxj[j] * ct_c : col;           // output [.., ct_c]: dx folds into the row index
+      bvj[j] = (d.bias && col < N) ? d.bias[col] : 0.f;
     }
-    static_for<0, TM>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
+    // vector path needs 16-byte aligned rows everywhere it touches memory
+    const bool vec = ((N & 3) == 0) && (!d.C || (((d.ldc & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.C) & 15) == 0))) &&
+                     (!d.res || (((d.ldr & 3) == 0) && ((reinterpret_cast<uintptr_t>(d.res) & 15) == 0))) &&
+                     (!ct || ((N >> (d.ct_dy < 0 ? 2 : 1)) & 3) == 0);
+    __syncthreads();                                // every wave is done reading the last K tile
+    static_for<0, NPASS>([&](auto pc) {
+      constexpr int pass = decltype(pc)::value;
+      static_for<0, IP>([&](auto iic) {
+        constexpr int ii = decltype(iic)::value, i = pass * IP + ii;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        const bool rok = row < M;
-        int cr = rok ? row : 0;
-        if (d.c_rowmap) cr = d.c_rowmap[cr];
-        const bool ok = rok && cr >= 0;
-        if (!ok) cr = 0;
-        int ct_base = 0;
-        if (ct) { const int yy = p.fd_ctw.div(cr); ct_base = yy * 2 * d.ct_W + (cr - yy * d.ct_W); }
-        int64_t rrow = cr;
+        for (int r = 0; r < 16; ++r) {
+          const int rowp = wm * (32 * IP) + ii * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          const int sw = BN >= 64 ? ((rowp >> 2) & 1) << 5 : 0;   // XOR swizzle: the half waves hit different banks
+          static_for<0, TN>([&](auto jc) {
+            constexpr int j = decltype(jc)::value;
+            const int colp = wn * WTN + j * 32 + l31;
+            stile[rowp * BN + (colp ^ sw)] = rsp_act(acc[i][j][r] * alpha + bvj[j], d.act);
+          });
+        }
+      });
+      __syncthreads();
+      for (int u = tid; u < ROWS_P * C4; u += NT) {
+        const int rowp = u / C4, c4 = u - rowp * C4;
+        const int c4p = BN >= 64 ? c4 ^ (((rowp >> 2) & 1) << 3) : c4;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(&stile[rowp * BN + (c4p << 2)]);
+        const int wmr = rowp / (32 * IP), rin = rowp - wmr * (32 * IP);     // rin = ii*32 + row in 32
+        const int row = m0 + wmr * WTM + pass * IP * 32 + rin;
+        const int col = n0 + c4 * 4;
+        if (row >= M || col >= N) continue;
+        int cr = d.c_rowmap ? d.c_rowmap[row] : row;
+        if (cr < 0) continue;
+        // ConvTranspose(k2,s2) column decode: ct_dy >= 0 -> columns are (dx, co) of one output-row parity;
+        // ct_dy < 0 -> columns are (dy, dx, co), all four sub-pixels in one GEMM (A is read once)
+        int dy = d.ct_dy, ccol = col, ct_c = N >> 1, crow = cr;
+        if (ct) {
+          if (d.ct_dy < 0) { dy = col >= (N >> 1); ccol = col - dy * (N >> 1); ct_c = N >> 2; }
+          const int yy = p.fd_ctw.div(cr);
+          crow = (yy * 2 + dy) * d.ct_W + (cr - yy * d.ct_W);
+        }
+        f32x4 v = t;
+        const int nv = vec ? 4 : min(4, N - col);
         if (d.res) {
-          if (d.res_mod > 0) rrow = cr - p.fd_resmod.div(cr) * d.res_mod;
+          int64_t rrow = crow;
+          if (d.res_mod > 0) rrow = crow - p.fd_resmod.div(crow) * d.res_mod;
           if (d.res_bmap) {
-            const int rb = p.fd_resb.div(cr);
-            rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (cr - rb * d.res_brows);
+            const int rb = p.fd_resb.div(crow);
+            rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (crow - rb * d.res_brows);
+          }
+          const float* rp = d.res + rrow * d.ldr + col;
+          if (vec) {
+            const f32x4 rv = *reinterpret_cast<const f32x4*>(rp);
+            v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+          } else {
+            for (int e = 0; e < nv; ++e) v[e] += rp[e];
           }
         }
-        float rv[TN];
-        static_for<0, TN>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          rv[j] = d.res ? d.res[rrow * d.ldr + colj[j]] : 0.f;
-        });
-        static_for<0, TN>([&](auto jc) {
-          constexpr int j = decltype(jc)::value;
-          const float v = rsp_act(acc[i][j][r] * alpha + bvj[j], d.act) + rv[j];
-          const int crow = ct ? ct_base + dyj[j] * d.ct_W : cr;
-          if (ok && cokj[j]) {
-            if (d.C) d.C[(int64_t)crow * d.ldc + ccolj[j]] = v;
-            if (d.Chi) {
-              half_t h, l;
-              rsp_split1(v * cs, h, l);
-              const int64_t prow = ct ? (int64_t)crow * 2 + pdxj[j] : crow;
-              const int64_t po = ((int64_t)(pchj[j] >> 5) * d.c_rows + prow) * 32 + (pchj[j] & 31);   // KB32
-              chi[po] = h;
-              clo[po] = l;
+        if (d.C) {
+          float* cp = d.C + (int64_t)crow * d.ldc + ccol;
+          if (vec) *reinterpret_cast<f32x4*>(cp) = v;
+          else for (int e = 0; e < nv; ++e) cp[e] = v[e];
+        }
+        if (d.Chi) {
+          // KB32 planes of the [c_rows, N] result; for a ConvTranspose the planes are those of the NHWC output
+          // [.., ct_c]: the sub-pixel dx folds into the row index
+          int64_t prow = crow;
+          int pch = col;
+          if (ct) { const int dx = ccol >= ct_c; pch = ccol - dx * ct_c; prow = (int64_t)crow * 2 + dx; }
+          half4_t h4, l4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { half_t a, b; rsp_split1(v[e] * cs, a, b); h4[e] = a; l4[e] = b; }
+          const int64_t po = ((int64_t)(pch >> 5) * d.c_rows + prow) * 32 + (pch & 31);
+          if (vec) {
+            *reinterpret_cast<half4_t*>(chi + po) = h4;
+            *reinterpret_cast<half4_t*>(clo + po) = l4;
+          } else {
+            for (int e = 0; e < nv; ++e) {      // ragged N: element-wise (a 4-group may straddle a 32-column block)
+              const int pc = pch + e;
+              const int64_t pe = ((int64_t)(pc >> 5) * d.c_rows + prow) * 32 + (pc & 31);
+              chi[pe] = h4[e];
+              clo[pe] = l4[e];
             }
           }
-        });
+        }
       }
+      if constexpr (pass + 1 < NPASS) __syncthreads();
     });
   }
 }

@@ -12,7 +12,7 @@ dev = torch.device('cuda:0')
 SHAPES = [(3276800, 256, 128, 1), (3276800, 256, 256, 0), (3276800, 128, 256, 0),
           (32768, 3072, 768, 0), (32768, 768, 3072, 1), (39200, 2304, 768, 0), (39200, 768, 768, 1),
           (32768, 768, 768, 1)]
-HINTS = [(3, '256x256'), (9, '256x256 noDMA'), (1, '128x128'), (11, 'P256x256'), (17, 'Q256x256'), (3, '256x256 again')]
+HINTS = [(0, 'auto'), (14, 'P128x128'), (18, 'Q256x128'), (17, 'Q256x256')]
 
 
 def run(M, N, K, with_res, iters=5):
