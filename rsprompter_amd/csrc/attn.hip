@@ -15,6 +15,7 @@
 // (P^T) of the PV MFMA for k-step s, provided the A operand (V^T) is read with
 // the same key permutation  slot t<4 -> key 16s+4hh+t, t>=4 -> key 16s+8+4hh+t-4.
 // No LDS round trip and no cross-lane traffic for P.
+#include <type_traits>
 #include "rsp_common.h"
 
 namespace {
@@ -351,6 +352,246 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnP p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Windowed ViT layers (HF:900-972: 14x14 windows, T = 196 tokens): the whole K and V of one (window, head) fit in
+// LDS as fp16 hi/lo, so a block stages them ONCE and its 7 waves (32 queries each) run all 7 key blocks without any
+// further barrier.  The decomposed rel-pos bias of a query is 14 + 14 scalars kept in registers; key -> (kh, kw)
+// is compile-time after unrolling.  Same arithmetic as attn_kernel (fp16x3 MFMA, fp32 online softmax).
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_w(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for_w<I + 1, N>(f);
+  }
+}
+
+template <int DH>
+__global__ __launch_bounds__(448) void attn_window_kernel(const AttnP p) {
+  constexpr int S = 14, T = S * S;             // 196 tokens
+  constexpr int NKB = (T + 31) / 32;           // 7 key blocks of 32
+  constexpr int KP = NKB * 32;                 // 224 padded keys
+  constexpr int NT = NKB * 64;                 // 7 waves
+  constexpr int DSTEPS = DH / 16;
+  constexpr int DBLK = (DH + 31) / 32;
+  constexpr int K_LD = DH + 8;                 // halves per K row
+  constexpr int V_LD = KP + 4;                 // halves per V^T row (114 dwords: conflict-free b64 reads)
+  constexpr int DCH = DH / 4;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+  half_t* sK0 = reinterpret_cast<half_t*>(wsm);            // [KP][K_LD] hi
+  half_t* sK1 = sK0 + KP * K_LD;                            // lo
+  half_t* sV0 = sK1 + KP * K_LD;                            // [DH][V_LD] hi (V transposed)
+  half_t* sV1 = sV0 + DH * V_LD;                            // lo
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int bp = blockIdx.z, h = blockIdx.y;
+  const int q = wave * 32 + l31;
+  const int nh = p.nh;
+  const float* q_b = p.q + (int64_t)bp * p.q_bs + (int64_t)h * p.q_hs;
+  const float* k_b = p.k + (int64_t)bp * p.k_bs + (int64_t)h * p.k_hs;
+  const float* v_b = p.v + (int64_t)bp * p.v_bs + (int64_t)h * p.v_hs;
+  const float* rel_b = p.rel + ((int64_t)bp * nh + h) * T * (2 * S);
+
+  // ---- stage K (row = key) and V^T (row = d) of the whole window, split to fp16 hi/lo; padded keys are zero ----
+  {
+    const float ks = ldexpf(1.0f, EK), vs = ldexpf(1.0f, EV);
+    for (int mt = tid; mt < (KP / 4) * DCH; mt += NT) {
+      const int kg = mt / DCH, dc = mt - kg * DCH;
+      f32x4 kr[4], vr[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int key = kg * 4 + j;
+        if (key < T) {
+          kr[j] = *reinterpret_cast<const f32x4*>(k_b + (int64_t)key * p.k_ts + dc * 4);
+          vr[j] = *reinterpret_cast<const f32x4*>(v_b + (int64_t)key * p.v_ts + dc * 4);
+        } else {
+          kr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          vr[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        half4_t hi, lo;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { half_t a, b; rsp_split1(kr[j][c] * ks, a, b); hi[c] = a; lo[c] = b; }
+        const int off = (kg * 4 + j) * K_LD + dc * 4;
+        *reinterpret_cast<half4_t*>(sK0 + off) = hi;
+        *reinterpret_cast<half4_t*>(sK1 + off) = lo;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        half4_t hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { half_t a, b; rsp_split1(vr[j][c] * vs, a, b); hi[j] = a; lo[j] = b; }
+        const int off = (dc * 4 + c) * V_LD + kg * 4;
+        *reinterpret_cast<half4_t*>(sV0 + off) = hi;
+        *reinterpret_cast<half4_t*>(sV1 + off) = lo;
+      }
+    }
+  }
+
+  // ---- Q fragments and this query's 14 + 14 bias scalars ----
+  half8_t qh[DSTEPS], qlo[DSTEPS];
+  {
+    const float qs = p.scale * ldexpf(1.0f, EQ);
+#pragma unroll
+    for (int st = 0; st < DSTEPS; ++st) {
+      float x[8];
+      if (q < T) {
+        const float* src = q_b + (int64_t)q * p.q_ts + st * 16 + hh * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { x[i] = a[i] * qs; x[4 + i] = b[i] * qs; }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) x[i] = 0.f;
+      }
+      split8(x, qh[st], qlo[st]);
+    }
+  }
+  float bH[S], bW[S];
+  {
+    const float* rq = rel_b + (int64_t)(q < T ? q : 0) * (2 * S);
+#pragma unroll
+    for (int j = 0; j < S; j += 2) {   // rows are 28 floats = 112 B: 8-byte aligned
+      const float2 a = *reinterpret_cast<const float2*>(rq + j);
+      const float2 b = *reinterpret_cast<const float2*>(rq + S + j);
+      bH[j] = a.x; bH[j + 1] = a.y; bW[j] = b.x; bW[j + 1] = b.y;
+    }
+  }
+  __syncthreads();                      // the only barrier: K / V^T are complete
+
+  f32x16 acc_o[DBLK];
+#pragma unroll
+  for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  const float s_unscale = ldexpf(1.0f, -(EQ + EK));
+  const float LOG2E = 1.4426950408889634f;
+
+  static_for_w<0, (NKB + 1) / 2>([&](auto tc) {
+    constexpr int tile = decltype(tc)::value;               // 64 keys: blocks 2*tile, 2*tile + 1
+    constexpr int NB = (2 * tile + 1 < NKB) ? 2 : 1;
+    f32x16 sc[NB];
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sc[blk][r] = 0.f;
+#pragma unroll
+      for (int st = 0; st < DSTEPS; ++st) {
+        const int off = ((2 * tile + blk) * 32 + l31) * K_LD + st * 16 + hh * 8;
+        const half8_t kh8 = *reinterpret_cast<const half8_t*>(sK0 + off);
+        const half8_t kl8 = *reinterpret_cast<const half8_t*>(sK1 + off);
+        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[st], sc[blk], 0, 0, 0);
+        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qlo[st], sc[blk], 0, 0, 0);
+        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh[st], sc[blk], 0, 0, 0);
+      }
+    }
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // key index for the two half waves; (kh, kw) and validity are compile-time constants
+        const int key0 = (2 * tile + blk) * 32 + (r & 3) + 8 * (r >> 2), key1 = key0 + 4;
+        const float b0 = key0 < T ? bH[key0 < T ? key0 / S : 0] + bW[key0 < T ? key0 % S : 0] : -INFINITY;
+        const float b1 = key1 < T ? bH[key1 < T ? key1 / S : 0] + bW[key1 < T ? key1 % S : 0] : -INFINITY;
+        const float v = sc[blk][r] * s_unscale + (hh ? b1 : b0);
+        sc[blk][r] = v;
+        tmax = fmaxf(tmax, v);
+      }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float m_new = fmaxf(m_run, tmax);                 // finite: every tile has valid keys for hh == 0
+    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+    const float m_l2 = m_new * LOG2E;
+    float psum = 0.f;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(sc[blk][r] * LOG2E - m_l2) * P_SCALE;
+        sc[blk][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+    m_run = m_new;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
+#pragma unroll
+    for (int s = 0; s < 2 * NB; ++s) {
+      float pf[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) pf[t] = sc[s >> 1][8 * (s & 1) + t];
+      half8_t ph, pl;
+      split8(pf, ph, pl);
+#pragma unroll
+      for (int db = 0; db < DBLK; ++db) {
+        int row = db * 32 + l31;
+        if (DBLK * 32 > DH && row >= DH) row = DH - 1;       // rows >= DH feed output rows nobody stores
+        const int off = row * V_LD + 64 * tile + 16 * s + 4 * hh;
+        half8_t vh8, vl8;
+        const half4_t a0 = *reinterpret_cast<const half4_t*>(sV0 + off);
+        const half4_t a1 = *reinterpret_cast<const half4_t*>(sV0 + off + 8);
+        const half4_t b0 = *reinterpret_cast<const half4_t*>(sV1 + off);
+        const half4_t b1 = *reinterpret_cast<const half4_t*>(sV1 + off + 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { vh8[t] = a0[t]; vh8[4 + t] = a1[t]; vl8[t] = b0[t]; vl8[4 + t] = b1[t]; }
+        acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph, acc_o[db], 0, 0, 0);
+        acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl, acc_o[db], 0, 0, 0);
+        acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph, acc_o[db], 0, 0, 0);
+      }
+    }
+  });
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  if (q < T) {
+    const float inv = ldexpf(1.0f, -EV) / l_tot;
+    float* dst = p.out + (int64_t)bp * p.o_bs + (int64_t)q * p.o_ts + (int64_t)h * p.o_hs;
+#pragma unroll
+    for (int db = 0; db < DBLK; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d0 = db * 32 + 8 * g + 4 * hh;
+        if (d0 < DH) {
+          f32x4 o;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) o[c] = acc_o[db][4 * g + c] * inv;
+          if (p.out) *reinterpret_cast<f32x4*>(dst + d0) = o;
+          if (p.out_hi) {
+            half4_t h4, l4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { half_t a, b; rsp_split1(o[c] * p.out_pscale, a, b); h4[c] = a; l4[c] = b; }
+            const int col = h * DH + d0;
+            const int64_t eo = ((int64_t)(col >> 5) * p.out_rows + ((int64_t)bp * T + q)) * 32 + (col & 31);
+            *reinterpret_cast<half4_t*>(p.out_hi + eo) = h4;
+            *reinterpret_cast<half4_t*>(p.out_lo + eo) = l4;
+          }
+        }
+      }
+  }
+}
+
+template <int DH>
+static int launch_attn_window(const AttnP& p, int B, hipStream_t s) {
+  constexpr int KP = 224;
+  const size_t smem = (size_t)2 * (KP * (DH + 8) + DH * (KP + 4)) * sizeof(half_t);
+  static bool configured = false;
+  if (!configured) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_window_kernel<DH>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+      return RSP_ELAUNCH;
+    configured = true;
+  }
+  hipLaunchKernelGGL((attn_window_kernel<DH>), dim3(1, p.nh, B), dim3(448), smem, s, p);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
 }  // namespace
 
 template <int DH, int REL, bool MASK>
@@ -393,6 +634,10 @@ extern "C" int rsp_vit_attention_ex(const float* qkv, const float* rel, float* o
   p.o_bs = (int64_t)T * D; p.o_ts = D; p.o_hs = dh;
   p.Tq = T; p.Tk = T; p.S = S; p.nh = nh; p.scale = scale;
   hipStream_t s = (hipStream_t)stream;
+  if (S == 14) {   // the SAM window size: whole-window-resident kernel
+    if (dh == 64) return launch_attn_window<64>(p, Bp, s);
+    if (dh == 80) return launch_attn_window<80>(p, Bp, s);
+  }
   if (dh == 64) return S == 64 ? launch_attn<64, 1, false>(p, Bp, s) : launch_attn<64, 2, false>(p, Bp, s);
   if (dh == 80) return S == 64 ? launch_attn<80, 1, false>(p, Bp, s) : launch_attn<80, 2, false>(p, Bp, s);
   return RSP_EINVAL;
