@@ -131,15 +131,34 @@ __global__ __launch_bounds__(TK_THREADS) void rpn_topk_kernel(const TopkP p) {
         skeys[n_gt + rank] = ((unsigned long long)kth << 32) | (uint32_t)(0xffffffffu - (uint32_t)c);
     }
   } else {
-    // pathological tie count (e.g. constant input): ordered scan, one thread
-    if (tid == 0) {
-      int taken = 0;
-      for (int c = 0; c < n && taken < n_eq_take; ++c) {
-        if (f2ord(score_at(c)) == kth) {
-          skeys[n_gt + taken] = ((unsigned long long)kth << 32) | (uint32_t)(0xffffffffu - (uint32_t)c);
-          ++taken;
-        }
+    // many ties (saturated scores): take the first n_eq_take tied candidates in index order with a block-wide
+    // ordered compaction, 1024 candidates per round (ballot + wave prefix, wave offsets through LDS)
+    __shared__ unsigned int wcnt[TK_THREADS / 64];
+    __shared__ unsigned int s_taken;
+    if (tid == 0) s_taken = 0;
+    __syncthreads();
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int c0 = 0; c0 < n; c0 += TK_THREADS) {
+      const unsigned int taken = s_taken;
+      if ((int)taken >= n_eq_take) break;
+      const int c = c0 + tid;
+      const bool flag = c < n && f2ord(score_at(c)) == kth;
+      const unsigned long long bal = __ballot(flag);
+      if (lane == 0) wcnt[wave] = (unsigned int)__popcll(bal);
+      __syncthreads();
+      unsigned int off = taken, total = 0;
+      for (int w = 0; w < TK_THREADS / 64; ++w) {
+        if (w < wave) off += wcnt[w];
+        total += wcnt[w];
       }
+      if (flag) {
+        const unsigned int rank = off + (unsigned int)__popcll(bal & ((1ull << lane) - 1ull));
+        if ((int)rank < n_eq_take)
+          skeys[n_gt + rank] = ((unsigned long long)kth << 32) | (uint32_t)(0xffffffffu - (uint32_t)c);
+      }
+      __syncthreads();
+      if (tid == 0) s_taken = taken + total;
+      __syncthreads();
     }
   }
   for (int i = k + tid; i < TK_MAXK; i += TK_THREADS) skeys[i] = 0ull;

@@ -81,7 +81,7 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// EPI: 0 = generic epilogue, 1 = ConvTranspose + GELU + hyper-network dot (no tile store at all),
+// EPI: reserved (0); the fused LayerNorm / hyper-network epilogues are run-time modes of the generic epilogue,
 // 2 = ConvTranspose + LayerNorm over each 64-channel sub-pixel + act -> planes (pairs of j tiles)
 template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const GemmP p) {
@@ -252,12 +252,6 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
       for (int j = 0; j < TN; ++j) {
         if (ABL == 2) {   // keep the fragments live without the matrix work
           asm volatile("" ::"v"(f.al[i]), "v"(f.ah[i]), "v"(f.bl[j]), "v"(f.bh[j]));
-        } else if constexpr (EPI != 0) {
-          // transposed tile (W A^T): every lane owns ONE output row and 16 of the 32 channels of tile j, so the
-          // channel reductions of the fused epilogues are in-lane (plus one cross-half shuffle)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
         } else {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
@@ -275,11 +269,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
     constexpr int G = TM * TN;
     static_for<0, G>([&](auto gc) {
       constexpr int g = decltype(gc)::value, i = g / TN, j = g % TN;
-      if constexpr (EPI != 0) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
-      } else {
+      {
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
@@ -382,97 +372,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   half_t* const chi = reinterpret_cast<half_t*>(d.Chi);
   half_t* const clo = reinterpret_cast<half_t*>(d.Clo);
 
-  if constexpr (EPI == 1) {
-    // last ConvTranspose of the SAM upscaler + GELU + <., hyper_in> (HF:519-531).  acc holds the TRANSPOSED tile:
-    // lane l31 <-> GEMM row (input pixel), register r <-> channel (r&3) + 8(r>>2) + 4hh of the sub-pixel this
-    // 32-column group stands for.  Nothing of the [R, 4h, 4w, 32] tensor is ever stored.
-    static_for<0, TM>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const int row = m0 + wm * WTM + i * 32 + l31;
-      const bool rok = row < M;
-      const int roi = rok ? p.fd_hd.div(row) : 0;
-      const float* hy = d.hd_hyper + (int64_t)roi * 32;
-      const int pix = rok ? row - roi * d.hd_rows : 0;      // input pixel (y, x) of the ConvTranspose
-      const int y = p.fd_ctw.div(pix), x = pix - y * d.ct_W;
-      static_for<0, TN>([&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const f32x16 t = acc[i][j];
-        const int cbase = n0 + wn * WTN + j * 32;
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
-          const float b = (d.bias && cbase < N) ? d.bias[cbase + c] : 0.f;
-          sum += rsp_act(t[r] * alpha + b, d.act) * hy[c];
-        }
-        sum += __shfl_xor(sum, 32, 64);
-        if (rok && cbase < N && hh == 0) {
-          const int sp = cbase >> 5;                        // sub-pixel: (dy, dx) when ct_dy < 0, else dx
-          const int dy = d.ct_dy < 0 ? (sp >> 1) : d.ct_dy, dx = sp & 1;
-          d.hd_out[(int64_t)roi * (4 * d.hd_rows) + (int64_t)(2 * y + dy) * (2 * d.ct_W) + 2 * x + dx] = sum;
-        }
-      });
-    });
-  } else if constexpr (EPI == 2) {
-    // first ConvTranspose of the SAM upscaler + LayerNorm2d(64) + GELU (HF:517-520), written as planes of the NHWC
-    // result.  Transposed tile: the lane owns one GEMM row, tiles (j, j+1) are the 64 channels of one sub-pixel
-    // (WTN % 64 == 0), half of them in this lane and half in lane ^ 32.
-    static_assert(EPI != 2 || TN % 2 == 0, "LayerNorm epilogue needs whole 64-channel groups per wave");
-    static_for<0, TM>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      const int row = m0 + wm * WTM + i * 32 + l31;
-      const bool rok = row < M;
-      const int yy = rok ? p.fd_ctw.div(row) : 0;
-      const int xx = rok ? row - yy * d.ct_W : 0;
-      static_for<0, TN / 2>([&](auto jc) {
-        constexpr int j = 2 * decltype(jc)::value;
-        const f32x16 t0 = acc[i][j], t1 = acc[i][j + 1];
-        const int cbase = n0 + wn * WTN + j * 32;          // first column of the sub-pixel group
-        const bool cok = cbase < N;
-        float v0[16], v1[16];
-        float sum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int c = (r & 3) + 8 * (r >> 2) + 4 * hh;
-          v0[r] = t0[r] * alpha + ((d.bias && cok) ? d.bias[cbase + c] : 0.f);
-          v1[r] = t1[r] * alpha + ((d.bias && cok) ? d.bias[cbase + 32 + c] : 0.f);
-          sum += v0[r] + v1[r];
-        }
-        sum += __shfl_xor(sum, 32, 64);
-        const float mean = sum * (1.0f / 64.0f);
-        float sq = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float a0 = v0[r] - mean, a1 = v1[r] - mean;
-          sq += a0 * a0 + a1 * a1;
-        }
-        sq += __shfl_xor(sq, 32, 64);
-        const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + d.ln_eps);
-        if (rok && cok) {
-          const int sp = cbase >> 6;                       // sub-pixel (dy, dx)
-          const int64_t prow = ((int64_t)(yy * 2 + (sp >> 1)) * d.ct_W + xx) * 2 + (sp & 1);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            half4_t h0, l0, h1, l1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int c = e + 8 * g + 4 * hh;
-              const float y0 = rsp_act((v0[4 * g + e] - mean) * rstd * d.ln_gamma[c] + d.ln_beta[c], d.act);
-              const float y1 = rsp_act((v1[4 * g + e] - mean) * rstd * d.ln_gamma[32 + c] + d.ln_beta[32 + c], d.act);
-              half_t a, b;
-              rsp_split1(y0 * cs, a, b); h0[e] = a; l0[e] = b;
-              rsp_split1(y1 * cs, a, b); h1[e] = a; l1[e] = b;
-            }
-            const int64_t po = prow * 32 + 8 * g + 4 * hh;          // channel block 0 of KB32 [2][c_rows][32]
-            *reinterpret_cast<half4_t*>(chi + po) = h0;
-            *reinterpret_cast<half4_t*>(clo + po) = l0;
-            *reinterpret_cast<half4_t*>(chi + (int64_t)d.c_rows * 32 + po) = h1;
-            *reinterpret_cast<half4_t*>(clo + (int64_t)d.c_rows * 32 + po) = l1;
-          }
-        }
-      });
-    });
-  } else {
+  {
     // generic epilogue, staged through LDS: the accumulators (lane <-> column, register <-> row) are written to the
     // now idle ring as an fp32 tile [rows][BN] (alpha, bias and activation already applied), then read back ROW-wise
     // so that every thread owns 4 consecutive columns of one row: residual loads, fp32 stores and plane stores are
@@ -488,6 +388,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
     constexpr int C4 = BN / 4;                      // float4 units per tile row
     float* stile = reinterpret_cast<float*>(&smem[0][0]);
     const bool ct = d.ct_W > 0;
+    const int act_w = d.ln_gamma ? RSP_ACT_NONE : d.act;   // LayerNorm mode: activation after the normalisation
     float bvj[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -510,7 +411,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
           static_for<0, TN>([&](auto jc) {
             constexpr int j = decltype(jc)::value;
             const int colp = wn * WTN + j * 32 + l31;
-            stile[rowp * BN + (colp ^ sw)] = rsp_act(acc[i][j][r] * alpha + bvj[j], d.act);
+            stile[rowp * BN + (colp ^ sw)] = rsp_act(acc[i][j][r] * alpha + bvj[j], act_w);
           });
         }
       });
@@ -534,6 +435,44 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
           crow = (yy * 2 + dy) * d.ct_W + (cr - yy * d.ct_W);
         }
         f32x4 v = t;
+        if (d.hd_out) {
+          // last ConvTranspose of the SAM upscaler + GELU + <., hyper_in> (HF:519-531): the 32 channels of one output
+          // sub-pixel are the 8 consecutive lanes of this row; nothing of the [R, 4h, 4w, 32] tensor is stored.
+          // (row validity is uniform over a row's lanes, so whole shuffle groups are active or idle together)
+          const int roi = p.fd_hd.div(row);
+          const f32x4 hy = *reinterpret_cast<const f32x4*>(d.hd_hyper + (int64_t)roi * 32 + (col & 31));
+          float sdot = v[0] * hy[0] + v[1] * hy[1] + v[2] * hy[2] + v[3] * hy[3];
+          sdot += __shfl_xor(sdot, 1, 64);
+          sdot += __shfl_xor(sdot, 2, 64);
+          sdot += __shfl_xor(sdot, 4, 64);
+          if ((c4 & 7) == 0) {
+            const int pix = row - roi * d.hd_rows;            // input pixel (y, x) of the ConvTranspose
+            const int y = p.fd_ctw.div(pix), x = pix - y * d.ct_W;
+            const int sp = col >> 5;                          // sub-pixel: (dy, dx) when ct_dy < 0, else dx
+            const int sdy = d.ct_dy < 0 ? (sp >> 1) : d.ct_dy, sdx = sp & 1;
+            d.hd_out[(int64_t)roi * (4 * d.hd_rows) + (int64_t)(2 * y + sdy) * (2 * d.ct_W) + 2 * x + sdx] = sdot;
+          }
+          continue;
+        }
+        if (d.ln_gamma) {
+          // first ConvTranspose of the SAM upscaler + LayerNorm2d over the 64 channels of each output sub-pixel
+          // (HF:517-520) = the 16 consecutive lanes of this row, two-pass statistics like the LayerNorm kernel
+          float sm = (v[0] + v[1]) + (v[2] + v[3]);
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o, 64);
+          const float mean = sm * (1.0f / 64.0f);
+          float sq = 0.f;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float dl = v[e] - mean; sq += dl * dl; }
+#pragma unroll
+          for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
+          const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + d.ln_eps);
+          const int ch = col & 63;
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(d.ln_gamma + ch);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(d.ln_beta + ch);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rsp_act((v[e] - mean) * rstd * g4[e] + b4[e], d.act);
+        }
         const int nv = vec ? 4 : min(4, N - col);
         if (d.res) {
           int64_t rrow = crow;
@@ -605,13 +544,10 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (d.ct_W > 0 && d.ct_dy < 0 && (d.N & 127)) return RSP_EINVAL;
   if (d.ct_W > 0 && d.Chi && ((d.N >> (d.ct_dy < 0 ? 2 : 1)) & 31)) return RSP_EINVAL;
   if (d.conv_k != 0 && (d.conv_C % BK) != 0) return RSP_EINVAL;
-  if (d.ln_gamma) {
-    if (!d.ln_beta || !(d.Chi && d.Clo) || d.C || d.ct_W <= 0 || d.ct_dy >= 0 || d.N != 256 || d.res || d.c_rowmap)
-      return RSP_EINVAL;
-    return launch_dma<128, 128, 2, 2, 2, 0, 2>(d, s);
-  }
-  if (d.hd_out)
-    return d.N == 128 ? launch_dma<128, 128, 2, 2, 2, 0, 1>(d, s) : launch_dma<128, 64, 2, 2, 3, 0, 1>(d, s);
+  if (d.ln_gamma && (!d.ln_beta || !(d.Chi && d.Clo) || d.C || d.ct_W <= 0 || d.ct_dy >= 0 || d.N != 256 || d.res ||
+                     d.c_rowmap || d.hd_out))
+    return RSP_EINVAL;
+  if (d.hd_out && (d.C || d.Chi || d.res || d.c_rowmap)) return RSP_EINVAL;
   auto nblk = [&](int bm, int bn) { return (long long)((d.N + bn - 1) / bn) * ((d.M + bm - 1) / bm); };
   // Tile rule (tools/gemm_sweep.py on MI355X; run-to-run spread is a few %): the register-pipelined loops win
   // everywhere; 256x256 needs >= 4 rounds of blocks over the 256 CUs, 256x128 >= 2, else 128x128 (2 blocks/CU).
@@ -624,7 +560,9 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   }
   int tile = d.tile_hint;
   if (tile == 0) {
-    if (d.N > 128 && nblk(256, 256) >= 1024) tile = 17;
+    // short K (<= 8 K tiles): the block is mostly prologue + epilogue, two 128x128 blocks per CU overlap them
+    if (d.K <= 256) tile = 14;
+    else if (d.N > 128 && nblk(256, 256) >= 1024) tile = 17;
     else if (d.N > 64 && nblk(256, 128) >= 512) tile = 18;
     else tile = 14;
   }

@@ -211,9 +211,11 @@ class PlaneWeight:
         self.bias = None
 
 
-def _dma_tile_name(m, n, hint=0, conv=False):
+def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30):
     """Mirror of the tile choice in rsp_gemm_dma_dispatch (gemm_dma.hip) - profiler labels only."""
     nblk = lambda bm, bn: -(-n // bn) * -(-m // bm)
+    if hint == 0 and not conv and k <= 256:
+        return '128x128' if n > 64 else ('128x64' if n > 32 else '128x32')
     if hint in (3, 9, 10, 11, 15, 17) or (hint == 0 and n > 128 and nblk(256, 256) >= 1024):
         return '256x256'
     if hint in (2, 4, 12, 13, 16, 18, 19) or (hint == 0 and not conv and n > 64 and nblk(256, 128) >= 512):
@@ -291,7 +293,7 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.act = act
     d.a_scale_log2 = a_scale_log2
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
-    tile = _dma_tile_name(m, n, tile_hint, conv is not None) if is_planes else ('128x128' if n > 64 else ('128x64' if n > 32 else '128x32'))
+    tile = _dma_tile_name(m, n, tile_hint, conv is not None, w.K) if is_planes else ('128x128' if n > 64 else ('128x64' if n > 32 else '128x32'))
     kname = 'gemm_f16x3_dma_kernel' if is_planes else 'gemm_f16x3_kernel'
     _timed(f'{kname}<{tile}>', 2.0 * m * n * w.K, 4.0 * (m * w.K + m * n) + 4.0 * n * w.K,
            lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm"),
