@@ -57,7 +57,8 @@ def test_query_kernels_unit(dev):
     assert _maxerr(got.permute(0, 3, 1, 2), ref + add.permute(0, 3, 1, 2).double()) < 2e-5
     up = ops.resize_bilinear(xh, (40, 48))
     assert _maxerr(up.permute(0, 3, 1, 2), F.interpolate(x, size=(40, 48), mode='bilinear', align_corners=False)) < 1e-5
-    # MSDeformAttn core
+    # MSDeformAttn core (module init draws from the global RNG: pin it, the solve below is conditioning-sensitive)
+    torch.manual_seed(1234)
     m = MSDeformAttn()
     shapes = [(4, 4), (8, 8), (16, 16)]
     ntok = sum(h * w_ for h, w_ in shapes)
