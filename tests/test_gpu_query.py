@@ -57,7 +57,7 @@ def test_query_kernels_unit(dev):
     assert _maxerr(got.permute(0, 3, 1, 2), ref + add.permute(0, 3, 1, 2).double()) < 2e-5
     up = ops.resize_bilinear(xh, (40, 48))
     assert _maxerr(up.permute(0, 3, 1, 2), F.interpolate(x, size=(40, 48), mode='bilinear', align_corners=False)) < 1e-5
-    # MSDeformAttn core (module init draws from the global RNG: pin it, the solve below is conditioning-sensitive)
+    # MSDeformAttn core (module init draws from the global RNG: pin it)
     torch.manual_seed(1234)
     m = MSDeformAttn()
     shapes = [(4, 4), (8, 8), (16, 16)]
@@ -69,11 +69,12 @@ def test_query_kernels_unit(dev):
         qq = q + pos
         value = m.value_proj(q)
         ow = torch.cat([m.sampling_offsets(qq), m.attention_weights(qq)], -1)
-        want = m(q, pos, refp[None, :, None].repeat(2, 1, 3, 1), torch.tensor(shapes)) - q
-        want = torch.linalg.solve(m.output_proj.weight.double(), (want.double() - m.output_proj.bias.double()).transpose(-1, -2)).transpose(-1, -2)
+        want = (m(q, pos, refp[None, :, None].repeat(2, 1, 3, 1), torch.tensor(shapes)) - q).double()
     got = ops.msdeform_attn(value.reshape(-1, 128).contiguous().to(dev), ow.reshape(-1, 288).contiguous().to(dev),
                             refp.to(dev), 2, ntok, shapes)
-    assert _maxerr(got.view(2, ntok, 128), want) < 1e-4
+    # the kernel stops before output_proj: apply it here (fp64) instead of inverting it out of the oracle's result
+    got_full = got.cpu().double().view(2, ntok, 128) @ m.output_proj.weight.double().t() + m.output_proj.bias.double()
+    assert _maxerr(got_full, want) < 1e-4
     # masked attention incl. rows whose first key tiles are fully masked
     Bq, Tq, Tk, nh, dh = 2, 30, 200, 8, 16
     D = nh * dh
