@@ -55,6 +55,20 @@ def cpu_baseline(arch, num_classes):
                        f'single timed pass of {dt:.1f} s, no warm-up')
 
 
+def _pmc_traffic():
+    """HBM bytes per launch of the dominant GEMM from the committed rocprofv3 PMC passes (profiles/r1_pmc/,
+    FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes); the counters cannot be collected inside this
+    process, so the number is the one measured with tools/pmc_gemm.sh on the kernel's most frequent shape."""
+    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_pmc', 'gemm_lin1_traffic.json')
+    try:
+        with open(f) as fh:
+            t = json.load(fh)
+        return {'bytes_per_launch': t['traffic_bytes_per_launch'], 'algorithmic_bytes_per_launch': t['algorithmic_bytes_per_launch'],
+                'shape': t['shape'], 'source': 'profiles/r1_pmc/gemm_lin1_traffic.json'}
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -145,7 +159,7 @@ def main():
                        'parallelism': f'dp{world} (images sharded by batch, result all-gather)' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'mfma', 'kernel': dom_name, 'achieved': round(achieved, 2),
                          'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
-                         'traffic': None,
+                         'traffic': _pmc_traffic(),
                          'note': 'achieved = algorithmic fp32 FLOPs (2MNK) of all launches of the kernel in one step / '
                                  'their summed HIP-event durations; the kernel issues 3 fp16 MFMA passes per algorithmic '
                                  'FLOP (fp16x3), so its ceiling is peak/3 = 833 TFLOP/s',
