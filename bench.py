@@ -128,13 +128,15 @@ def main():
     n_dets = sum(len(r.bboxes) for r in step())
 
     result = None
-    if rank == 0:
-        # ---- roofline leg: one extra instrumented step, per-kernel HIP events on the launch stream ----
-        prof = ops.Profiler()
+    # ---- roofline leg: one extra instrumented step, per-kernel HIP events on the launch stream.  Every rank runs
+    # the step (it contains the result all-gather); only rank 0 records and reports ----
+    prof = ops.Profiler() if rank == 0 else None
+    if prof is not None:
         prof.shapes = args.shapes
         ops.set_profiler(prof)
-        step()
-        ops.set_profiler(None)
+    step()
+    ops.set_profiler(None)
+    if rank == 0:
         agg = prof.summary()
         kernels = {k: dict(ms=round(v['ms'], 3), calls=v['calls'],
                            tflops=round(v['flops'] / v['ms'] / 1e9, 1) if v['ms'] > 0 and v['flops'] else None,
