@@ -26,8 +26,21 @@ __device__ __forceinline__ void rsp_split1(float x, half_t& hi, half_t& lo) {
   lo = (half_t)(x - (float)hi);
 }
 
+// exact-erf GELU (nn.GELU default, HF "gelu").  erf through Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7 absolute,
+// i.e. <= 1e-7 * |x| on the GELU value): branch-free, 2 transcendentals + ~12 VALU ops per element instead of the
+// two-branch libm erff (~40 with divergence).  GELU sits in GEMM epilogues (encoder lin1, SAM upscaler), where
+// VALU time is not hidden behind matrix work.
 __device__ __forceinline__ float rsp_gelu(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  const float ax = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  pl *= t;
+  const float e = __builtin_amdgcn_exp2f(ax * ax * -1.4426950408889634f);
+  const float erf_abs = fmaf(-pl, e, 1.0f);               // erf(|x| / sqrt 2)
+  return 0.5f * x + 0.5f * fabsf(x) * erf_abs;            // 0.5 x (1 + sign(x) erf_abs)
 }
 
 __device__ __forceinline__ float rsp_act(float v, int act) {
