@@ -144,7 +144,7 @@ def main():
                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
         dom_name, dom = max(((k, v) for k, v in agg.items() if v['flops'] > 0), key=lambda kv: kv[1]['ms'])
         achieved = dom['flops'] / dom['ms'] / 1e9
-        attn = [v for k, v in agg.items() if k.startswith('attn_kernel<vit')]
+        attn = [v for k, v in agg.items() if k.startswith('attn_kernel<vit') or k.startswith('attn_global_kernel')]
         attn_ms = sum(v['ms'] for v in attn)
         attn_tf = sum(v['flops'] for v in attn) / attn_ms / 1e9 if attn_ms else None
         value = world * B * args.steps / elapsed

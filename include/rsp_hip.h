@@ -150,6 +150,13 @@ int rsp_vit_attention(const float* qkv, const float* rel, float* out,
 int rsp_vit_attention_ex(const float* qkv, const float* rel, float* out, uint16_t* out_hi,
                          uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t S,
                          int32_t nh, int32_t dh, float scale, rsp_stream_t stream);
+/* Global-attention layers (S == 64 or 32): K and V of every (image, head) are split once into fp16 hi/lo planes   */
+/* (K as [key][dh], V transposed) inside `workspace` (rsp_vit_attention_global_ws_bytes) and the attention kernel   */
+/* streams them HBM -> LDS with the DMA engine.  Same semantics and outputs as rsp_vit_attention_ex.                */
+int64_t rsp_vit_attention_global_ws_bytes(int32_t Bp, int32_t S, int32_t nh, int32_t dh);
+int rsp_vit_attention_global(const float* qkv, const float* rel, void* workspace, float* out, uint16_t* out_hi,
+                             uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t S, int32_t nh, int32_t dh,
+                             float scale, rsp_stream_t stream);
 
 /* Generic multi-head attention out = softmax((q*scale) k^T) v with strided    */
 /* operands (element strides; all multiples of 4), used by the SAM mask        */

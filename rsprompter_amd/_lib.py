@@ -87,6 +87,9 @@ PROTOTYPES = {
     "rsp_vit_attention_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_int, c_float, c_void_p]),
     "rsp_vit_relpos": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "rsp_vit_attention_global_ws_bytes": (ctypes.c_int64, [c_int, c_int, c_int, c_int]),
+    "rsp_vit_attention_global": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                         c_int, c_int, c_float, c_void_p]),
     "rsp_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rsp_preprocess": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_float, c_void_p]),

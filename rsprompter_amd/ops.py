@@ -336,23 +336,38 @@ def vit_relpos(qkv, rel_pos_h, rel_pos_w, Bp, S, nh, dh):
     return rel
 
 
+_attn_ws = {}
+
+
+def _attn_workspace(nbytes, device):
+    """K / V^T plane scratch of the global-attention path, kept per device (layers run back to back on one stream)."""
+    key = str(device)
+    buf = _attn_ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty((nbytes,), dtype=torch.uint8, device=device)
+        _attn_ws[key] = buf
+    return buf
+
+
 def vit_attention(qkv, rel, Bp, S, nh, dh, scale, planes=False):
     """planes=True: return the output only as fp16 Planes (it feeds the proj GEMM's DMA path)."""
     lib = _lib.load()
-    kind = 'global' if S * S > 1024 else 'window'
+    kind = 'global' if S * S >= 1024 else 'window'
     fl = 4.0 * Bp * nh * (S * S) ** 2 * dh
-    if planes:
-        pl = empty_planes((Bp * S * S, nh * dh), qkv.device)
+    pl = empty_planes((Bp * S * S, nh * dh), qkv.device) if planes else None
+    out = None if planes else torch.empty((Bp * S * S, nh * dh), dtype=torch.float32, device=qkv.device)
+    hi, lo, e = (pl.hi.data_ptr(), pl.lo.data_ptr(), pl.scale_log2) if planes else (0, 0, 0)
+    if S in (64, 32):
+        ws = _attn_workspace(int(lib.rsp_vit_attention_global_ws_bytes(Bp, S, nh, dh)), qkv.device)
+        _timed(f'attn_global_kernel<vit>', fl, 0,
+               lambda: _lib.check(lib.rsp_vit_attention_global(qkv.data_ptr(), rel.data_ptr(), ws.data_ptr(), _ptr(out),
+                                                               hi, lo, e, Bp, S, nh, dh, scale, _stream()),
+                                  "rsp_vit_attention_global"))
+    else:
         _timed(f'attn_kernel<vit,{kind}>', fl, 0,
-               lambda: _lib.check(lib.rsp_vit_attention_ex(qkv.data_ptr(), rel.data_ptr(), 0, pl.hi.data_ptr(),
-                                                           pl.lo.data_ptr(), pl.scale_log2, Bp, S, nh, dh, scale,
-                                                           _stream()), "rsp_vit_attention_ex"))
-        return pl
-    out = torch.empty((Bp * S * S, nh * dh), dtype=torch.float32, device=qkv.device)
-    _timed(f'attn_kernel<vit,{kind}>', fl, 0,
-           lambda: _lib.check(lib.rsp_vit_attention(qkv.data_ptr(), rel.data_ptr(), out.data_ptr(), Bp, S, nh, dh,
-                                                    scale, _stream()), "rsp_vit_attention"))
-    return out
+               lambda: _lib.check(lib.rsp_vit_attention_ex(qkv.data_ptr(), rel.data_ptr(), _ptr(out), hi, lo, e, Bp, S,
+                                                           nh, dh, scale, _stream()), "rsp_vit_attention_ex"))
+    return pl if planes else out
 
 
 def patchify(img, patch):

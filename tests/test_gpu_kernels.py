@@ -129,7 +129,7 @@ def _ref_vit_attention(qkv, rph, rpw, S, nh, dh, scale):
     return out, rel
 
 
-@pytest.mark.parametrize('S,nh,dh,Bp', [(14, 3, 64, 5), (64, 2, 64, 1), (14, 2, 80, 3), (64, 1, 80, 1), (32, 2, 64, 2)])
+@pytest.mark.parametrize('S,nh,dh,Bp', [(14, 3, 64, 5), (64, 2, 64, 1), (14, 2, 80, 3), (64, 1, 80, 1), (32, 2, 64, 2), (32, 1, 80, 2), (64, 3, 64, 2)])
 def test_vit_attention(dev, S, nh, dh, Bp):
     from rsprompter_amd import ops
     g = torch.Generator().manual_seed(5)
