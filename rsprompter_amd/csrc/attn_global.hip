@@ -17,6 +17,7 @@ constexpr int KT = 64;                 // keys per tile
 constexpr int QB = 128;                // queries per block (4 waves x 32)
 constexpr int EQ = 6, EK = 6, EV = 6;  // power-of-two operand scales (same as attn.hip)
 constexpr float P_SCALE = 16384.0f;
+constexpr float LOG2E_C = 1.4426950408889634f;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -179,14 +180,14 @@ __global__ __launch_bounds__(256) void attn_global_kernel(const AttnGP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int kl = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      bw[blk][r] = (q < T) ? rel_b[(int64_t)q * (2 * S) + S + (kl % S)] : 0.f;
+      bw[blk][r] = (q < T) ? rel_b[(int64_t)q * (2 * S) + S + (kl % S)] * LOG2E_C : 0.f;   // log2 domain
     }
   (void)tiles_per_row;
   // rel_h of the key row(s) of a tile: blk b of tile kt covers key row (kt*64 + 32 b) / S
   auto load_bh = [&](int kt, float& b0, float& b1) {
     const int kh0 = (kt * KT) / S, kh1 = (kt * KT + 32) / S;
-    b0 = (q < T) ? rel_b[(int64_t)q * (2 * S) + kh0] : 0.f;
-    b1 = (rows_per_tile > 1 && q < T) ? rel_b[(int64_t)q * (2 * S) + kh1] : b0;
+    b0 = (q < T) ? rel_b[(int64_t)q * (2 * S) + kh0] * LOG2E_C : 0.f;
+    b1 = (rows_per_tile > 1 && q < T) ? rel_b[(int64_t)q * (2 * S) + kh1] * LOG2E_C : b0;
   };
   float bhn0, bhn1;
   load_bh(0, bhn0, bhn1);
@@ -197,8 +198,7 @@ __global__ __launch_bounds__(256) void attn_global_kernel(const AttnGP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
-  const float s_unscale = ldexpf(1.0f, -(EQ + EK));
-  const float LOG2E = 1.4426950408889634f;
+  const float s_unscale2 = ldexpf(1.0f, -(EQ + EK)) * LOG2E_C;
 
   int buf = 0;
   for (int kt = 0; kt < nt; ++kt) {
@@ -233,28 +233,29 @@ __global__ __launch_bounds__(256) void attn_global_kernel(const AttnGP p) {
     // ---- bias, online softmax (per-lane query column) ----
     const float bh0 = bhn0, bh1 = bhn1;
     if (kt + 1 < nt) load_bh(kt + 1, bhn0, bhn1);         // a whole tile ahead of its use
-    float tmax = -INFINITY;
+    // everything in the log2 domain: u = s * (2^-12 log2 e) + rel_w' ; the per-block rel_h' term and the running
+    // maximum enter as ONE scalar per block inside the exponent (softmax is shift invariant), the 2^14 scale of P too
+    float tm0 = -INFINITY, tm1 = -INFINITY;
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = sc[blk][r] * s_unscale + ((blk ? bh1 : bh0) + bw[blk][r]);
-        sc[blk][r] = v;
-        tmax = fmaxf(tmax, v);
-      }
+    for (int r = 0; r < 16; ++r) {
+      sc[0][r] = fmaf(sc[0][r], s_unscale2, bw[0][r]);
+      sc[1][r] = fmaf(sc[1][r], s_unscale2, bw[1][r]);
+      tm0 = fmaxf(tm0, sc[0][r]);
+      tm1 = fmaxf(tm1, sc[1][r]);
+    }
+    float tmax = fmaxf(tm0 + bh0, tm1 + bh1);
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    const float m_new = fmaxf(m_run, tmax);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);   // 0 on the first tile
-    const float m_l2 = m_new * LOG2E;
+    const float m_new = fmaxf(m_run, tmax);                              // log2 units
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);           // 0 on the first tile
+    const float k0 = bh0 - m_new + 14.0f, k1 = bh1 - m_new + 14.0f;      // 14 = log2(P_SCALE)
     float psum = 0.f;
 #pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(sc[blk][r] * LOG2E - m_l2) * P_SCALE;
-        sc[blk][r] = pv;
-        psum += pv;
-      }
+    for (int r = 0; r < 16; ++r) {
+      const float p0 = __builtin_amdgcn_exp2f(sc[0][r] + k0);
+      const float p1 = __builtin_amdgcn_exp2f(sc[1][r] + k1);
+      sc[0][r] = p0; sc[1][r] = p1;
+      psum += p0 + p1;
+    }
     l_run = l_run * alpha + psum;
     m_run = m_new;
 #pragma unroll
