@@ -147,13 +147,15 @@ extern "C" int rsp_layernorm_ex(const float* x, const float* gamma, const float*
   }
   const int64_t blocks = (rows + 3) / 4;
   if (blocks > 0x7fffffffLL) return RSP_EINVAL;
-  if (C <= 256) {
-    hipLaunchKernelGGL((layernorm_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act, hi, lo, ps);
-  } else if (C <= 1024) {
-    hipLaunchKernelGGL((layernorm_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act, hi, lo, ps);
-  } else {
-    hipLaunchKernelGGL((layernorm_kernel<8>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act, hi, lo, ps);
-  }
+  // one instantiation per 256-channel step actually used (ViT widths 768 / 1024 / 1280): no idle chunk iterations
+#define RSP_LN_LAUNCH(NC) hipLaunchKernelGGL((layernorm_kernel<NC>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act, hi, lo, ps)
+  if (C <= 256) RSP_LN_LAUNCH(1);
+  else if (C <= 512) RSP_LN_LAUNCH(2);
+  else if (C <= 768) RSP_LN_LAUNCH(3);
+  else if (C <= 1024) RSP_LN_LAUNCH(4);
+  else if (C <= 1280) RSP_LN_LAUNCH(5);
+  else RSP_LN_LAUNCH(8);
+#undef RSP_LN_LAUNCH
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
