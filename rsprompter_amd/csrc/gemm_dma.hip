@@ -562,9 +562,19 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (tile == 0) {
     // short K (<= 8 K tiles): the block is mostly prologue + epilogue, two 128x128 blocks per CU overlap them
     if (d.K <= 256) tile = 14;
-    else if (d.N > 128 && nblk(256, 256) >= 1024) tile = 17;
-    else if (d.N > 64 && nblk(256, 128) >= 512) tile = 18;
-    else tile = 14;
+    else {
+      // cost = rounds over the 256 CUs x tile area / relative efficiency (tools/gemm_sweep.py: 256x256 1.0,
+      // 256x128 0.96, 128x128 0.88 with its two blocks per CU sharing the matrix pipe): the partially filled last
+      // round is what separates the candidates (e.g. M = 39200, N = 1280: 7 rounds of 256x128 vs 6 of 128x128)
+      auto cost = [&](int bm, int bn, int bpc, double eff) {
+        const long long nb = nblk(bm, bn), slots = 256LL * bpc;
+        return (double)((nb + slots - 1) / slots) * bm * bn * bpc / eff;
+      };
+      double best = cost(128, 128, 2, 0.88);
+      tile = 14;
+      if (d.N > 64) { const double c = cost(256, 128, 1, 0.96); if (c < best) { best = c; tile = 18; } }
+      if (d.N > 128) { const double c = cost(256, 256, 1, 1.0); if (c <= best) { best = c; tile = 17; } }
+    }
   }
   switch (tile) {   // hints >= 4 are benchmarking variants of the same arithmetic
     case 3: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2>(d, s); break;
@@ -584,6 +594,8 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
     case 18: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2, 0, 0, 2>(d, s); break;
     case 19: if (d.N > 64) return launch_dma<256, 128, 4, 2, 3, 0, 0, 2>(d, s); break;
     case 20: if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 0, 0, 2>(d, s); break;
+    case 21: return launch_dma<128, 64, 2, 2, 3, 0, 0, 1>(d, s);                         // narrow tile, 3-deep ring
+    case 22: return launch_dma<128, 64, 2, 2, 4, 0, 0, 1>(d, s);
     case 15: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 1, 0, 1>(d, s); break;   // ... without the DMA
     case 16: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2, 1, 0, 1>(d, s); break;
     default: break;

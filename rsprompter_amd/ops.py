@@ -214,13 +214,25 @@ class PlaneWeight:
 def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30):
     """Mirror of the tile choice in rsp_gemm_dma_dispatch (gemm_dma.hip) - profiler labels only."""
     nblk = lambda bm, bn: -(-n // bn) * -(-m // bm)
-    if hint == 0 and not conv and k <= 256:
-        return '128x128' if n > 64 else ('128x64' if n > 32 else '128x32')
-    if hint in (3, 9, 10, 11, 15, 17) or (hint == 0 and n > 128 and nblk(256, 256) >= 1024):
+    small = '128x128' if n > 64 else ('128x64' if n > 32 else '128x32')
+    if hint in (3, 9, 10, 11, 15, 17):
         return '256x256'
-    if hint in (2, 4, 12, 13, 16, 18, 19) or (hint == 0 and not conv and n > 64 and nblk(256, 128) >= 512):
+    if hint in (2, 4, 12, 13, 16, 18, 19):
         return '256x128'
-    return '128x128' if n > 64 else ('128x64' if n > 32 else '128x32')
+    if hint != 0:
+        return small
+    if conv:
+        return '256x256' if n > 128 and nblk(256, 256) >= 1024 else small
+    if k <= 256 or n <= 64:
+        return small
+    cost = lambda bm, bn, bpc, eff: -(-nblk(bm, bn) // (256 * bpc)) * bm * bn * bpc / eff
+    best, name = cost(128, 128, 2, 0.88), '128x128'
+    c = cost(256, 128, 1, 0.96)
+    if c < best:
+        best, name = c, '256x128'
+    if n > 128 and cost(256, 256, 1, 1.0) <= best:
+        name = '256x256'
+    return name
 
 
 def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, c_rowmap=None,

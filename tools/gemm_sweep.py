@@ -12,7 +12,7 @@ dev = torch.device('cuda:0')
 SHAPES = [(3276800, 256, 128, 1), (3276800, 256, 256, 0), (3276800, 128, 256, 0),
           (32768, 3072, 768, 0), (32768, 768, 3072, 1), (39200, 2304, 768, 0), (39200, 768, 768, 1),
           (32768, 768, 768, 1)]
-HINTS = [(0, 'auto'), (14, 'P128x128'), (18, 'Q256x128'), (17, 'Q256x256')]
+HINTS = [(0, 'auto'), (14, 'P128x128'), (18, 'Q256x128'), (21, 'P128x64 nbuf3'), (22, 'P128x64 nbuf4')]
 
 
 def run(M, N, K, with_res, iters=5):
