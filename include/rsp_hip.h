@@ -250,6 +250,12 @@ int rsp_batched_nms(const float* boxes, const float* scores, const int32_t* ids,
 /* SAM decoder tail / mask post-process                                        */
 /* ------------------------------------------------------------------------ */
 /* out[r, pix] = sum_c up[r, pix, c] * hyper[r, c]     (HF:523-531)             */
+/* SAM upscaler tail, streaming form (HF:521-531): rows = R*H2*W2 input pixels as fp16 planes (KB32, K = 64),      */
+/* weight planes [2][128][32] with rows (dy, dx, c) of ConvTranspose2d(64 -> 32, k2, s2), bias tiled x4 [128],       */
+/* hyper [R, 32]; out [R, 2*H2, 2*W2] = sum_c GELU(convT)[.., c] * hyper[r, c].  rows_per_roi = H2*W2, ct_W = W2.    */
+int rsp_sam_upscale2(const uint16_t* a_hi, const uint16_t* a_lo, int64_t rows, int32_t a_scale_log2,
+                     const uint16_t* w_hi, const uint16_t* w_lo, int32_t w_scale_log2, const float* bias,
+                     const float* hyper, float* out, int32_t rows_per_roi, int32_t ct_W, rsp_stream_t stream);
 int rsp_hyper_mask(const float* up, const float* hyper, float* out, int32_t R, int32_t npix,
                    int32_t C, rsp_stream_t stream);
 /* models.py:1746-1784: sigmoid, bilinear (h,w)->(Hb,Wb), crop (crop_h,crop_w),  */

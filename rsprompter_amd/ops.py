@@ -442,6 +442,17 @@ def conv_transpose2x2(x_nhwc, w_dy, bias, act=ACT_NONE, a_scale_log2=DEFAULT_A_S
     dys = (-1,) if four else (0, 1)
     if hyper is not None:
         out = torch.empty((B, 2 * H, 2 * W), dtype=torch.float32, device=dev)
+        if four and Cin == 64 and cout == 32 and act == ACT_GELU and bias is not None:
+            # the SAM upscaler's last stage: dedicated streaming kernel (weights resident in LDS)
+            lib = _lib.load()
+            w = ws[0]
+            rows = B * H * W
+            _timed('sam_upscale2_kernel', 2.0 * rows * 128 * 64, 4.0 * rows * 64 + 4.0 * rows * 4,
+                   lambda: _lib.check(lib.rsp_sam_upscale2(a.hi.data_ptr(), a.lo.data_ptr(), rows, a.scale_log2,
+                                                           w.hi.data_ptr(), w.lo.data_ptr(), w.scale_log2,
+                                                           bias.data_ptr(), hyper.data_ptr(), out.data_ptr(), H * W, W,
+                                                           _stream()), "rsp_sam_upscale2"))
+            return out
         for w, dy in zip(ws, dys):
             _gemm_ct(a, w, None, bias, act, W, dy, a_scale_log2, hyper=hyper, hd_out=out, hd_rows=H * W)
         return out
