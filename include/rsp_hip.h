@@ -107,6 +107,9 @@ typedef struct RspGemmDesc {
   /* ct_W > 0, ct_dy < 0 and N == 256 every 64-column group (one output sub-pixel) is normalised over its  */
   /* 64 channels (LayerNorm2d, eps ln_eps, affine ln_gamma/ln_beta [64]) BEFORE `act`; plane output only.  */
   const float* ln_gamma; const float* ln_beta; float ln_eps;
+  /* residual given as fp16 planes (KB32 [N/32][res_rows][32], value * 2^res_scale_log2) instead of fp32 `res`:    */
+  /* C = act(...) + (hi + lo) * 2^-e, rows mapped like `res` (res_mod / res_bmap).                                */
+  const uint16_t* res_hi; const uint16_t* res_lo; int32_t res_scale_log2, res_rows;
   const float* hd_hyper; float* hd_out;
   int32_t hd_rows;    /* GEMM rows per RoI (input pixels of the ConvTranspose)                                */
   int32_t tile_hint;  /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile (plane path; benchmarking) */

@@ -31,6 +31,7 @@ class RspGemmDesc(ctypes.Structure):
         ("Ahi", c_void_p), ("Alo", c_void_p), ("Chi", c_void_p), ("Clo", c_void_p), ("c_scale_log2", c_int),
         ("a_rows", c_int), ("c_rows", c_int), ("b_rows", c_int),
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
+        ("res_hi", c_void_p), ("res_lo", c_void_p), ("res_scale_log2", c_int), ("res_rows", c_int),
         ("hd_hyper", c_void_p), ("hd_out", c_void_p), ("hd_rows", c_int),
         ("tile_hint", c_int),
     ]

@@ -319,7 +319,7 @@ extern "C" int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream) {
   if (!d.C && !(d.Chi && d.Clo) && !d.hd_out) return RSP_EINVAL;
   if ((d.Chi == nullptr) != (d.Clo == nullptr)) return RSP_EINVAL;
   if (d.Chi && (d.c_rows <= 0 || (d.N & 31))) return RSP_EINVAL;
-  if ((d.hd_out || d.ln_gamma || (d.ct_W > 0 && d.ct_dy < 0)) && !(d.Ahi && d.Alo)) return RSP_EINVAL;   // the fused hyper-network epilogue lives in the plane path
+  if ((d.hd_out || d.ln_gamma || d.res_hi || (d.ct_W > 0 && d.ct_dy < 0)) && !(d.Ahi && d.Alo)) return RSP_EINVAL;   // the fused hyper-network epilogue lives in the plane path
   if (d.M < 0 || d.N <= 0 || d.K <= 0 || (d.K % BK) != 0) return RSP_EINVAL;
   if (d.M == 0) return RSP_OK;
   if (d.conv_k != 0) {

@@ -474,6 +474,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
           for (int e = 0; e < 4; ++e) v[e] = rsp_act((v[e] - mean) * rstd * g4[e] + b4[e], d.act);
         }
         const int nv = vec ? 4 : min(4, N - col);
+        if (d.res_hi) {
+          // residual from fp16 planes (hi + lo carries ~22 significant bits of the fp32 value)
+          int64_t rrow = crow;
+          if (d.res_mod > 0) rrow = crow - p.fd_resmod.div(crow) * d.res_mod;
+          if (d.res_bmap) {
+            const int rb = p.fd_resb.div(crow);
+            rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (crow - rb * d.res_brows);
+          }
+          const int64_t ro = ((int64_t)(col >> 5) * d.res_rows + rrow) * 32 + (col & 31);
+          const half4_t rh = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(d.res_hi) + ro);
+          const half4_t rl = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(d.res_lo) + ro);
+          const float rsc = ldexpf(1.0f, -d.res_scale_log2);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += ((float)rh[e] + (float)rl[e]) * rsc;
+        }
         if (d.res) {
           int64_t rrow = crow;
           if (d.res_mod > 0) rrow = crow - p.fd_resmod.div(crow) * d.res_mod;
@@ -539,7 +554,8 @@ int launch_dma(const RspGemmDesc& d, hipStream_t s) {
 // called from rsp_gemm (gemm.hip) when the descriptor carries A planes
 int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (d.a_rows <= 0) return RSP_EINVAL;
-  if (d.ct_W > 0 && d.res) return RSP_EINVAL;   // no caller needs a residual on a ConvTranspose
+  if (d.ct_W > 0 && (d.res || d.res_hi)) return RSP_EINVAL;   // no caller needs a residual on a ConvTranspose
+  if (d.res_hi && (!d.res_lo || d.res || d.res_rows <= 0 || (d.N & 3))) return RSP_EINVAL;
   if (d.hd_out && (!d.hd_hyper || d.ct_W <= 0 || d.N != (d.ct_dy < 0 ? 128 : 64) || d.hd_rows <= 0)) return RSP_EINVAL;
   if (d.ct_W > 0 && d.ct_dy < 0 && (d.N & 127)) return RSP_EINVAL;
   if (d.ct_W > 0 && d.Chi && ((d.N >> (d.ct_dy < 0 ? 2 : 1)) & 31)) return RSP_EINVAL;

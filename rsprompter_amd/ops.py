@@ -286,6 +286,11 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
         _chk_f32(out, "out")
     if bias == "auto":
         bias = w.bias
+    if isinstance(res, Planes):
+        if not is_planes:
+            raise ValueError('a plane residual needs the plane path')
+        d.res_hi, d.res_lo, d.res_scale_log2, d.res_rows = res.hi.data_ptr(), res.lo.data_ptr(), res.scale_log2, res.rows
+        res = None
     if res is not None:
         _chk_f32(res, "res")
         d.ldr = res.stride(0)

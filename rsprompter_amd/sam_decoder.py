@@ -232,7 +232,11 @@ class SamMaskDecoderHIP(HIPModule):
         ai = ops.empty_planes((R * N, d2), dev)      # attention output goes straight to the out_proj GEMM as planes
         self._i2t(qi, kt, vt, ai, R, T, N, q_map=roi_img)
         keys = ops.gemm(ai, P['0.cross_attn_image_to_token.out_proj'], res=src, res_bmap=roi_img, res_brows=N)
-        keys, keys_pl = self._ln(keys, 'transformer.layers.0.layer_norm4', planes=True)   # [R*N, 256] f32 + planes
+        # layer_norm4 emits planes only: they are both the A operand of layer 1's projections and (hi + lo) the
+        # residual of its out_proj GEMM, so the fp32 copy of the per-RoI keys is never written
+        m4 = _g(self, 'transformer.layers.0.layer_norm4')
+        keys_pl = ops.layernorm(keys, m4.weight, m4.bias, 1e-6, planes=True, f32=False)   # [R*N, 256] planes
+        del keys
         del qi, kv_img
 
         # ---------------- layer 1 ----------------
@@ -255,7 +259,7 @@ class SamMaskDecoderHIP(HIPModule):
         kt = ops.gemm(qpe, P['1.cross_attn_image_to_token.k_proj'])
         vt = ops.gemm(q, P['1.cross_attn_image_to_token.v_proj'])
         self._i2t(qi, kt, vt, ai, R, T, N)
-        keys = ops.gemm(ai, P['1.cross_attn_image_to_token.out_proj'], res=keys, out=keys)
+        keys = ops.gemm(ai, P['1.cross_attn_image_to_token.out_proj'], res=keys_pl)
         m4 = _g(self, 'transformer.layers.1.layer_norm4')
         keys_pl = ops.layernorm(keys, m4.weight, m4.bias, 1e-6, planes=True, f32=False)   # planes only from here on
         del keys

@@ -512,3 +512,17 @@ def test_sam_cross_attention_kernels(dev, T):
                           R=R, T=T, N=N, scale=scale, q_map=mp.to(dev), out=o32, out_planes=pl)
     assert float((o32.cpu() - ref).abs().max()) < 2e-6
     assert float((_planes_to_f32(pl) - ref).abs().max()) < 4e-6
+
+
+def test_gemm_plane_residual(dev):
+    """residual handed over as fp16 planes (hi + lo) instead of fp32, incl. the RoI -> image row map"""
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(91)
+    M, K, N = 3 * 200, 128, 256
+    a, w, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g)
+    res = torch.randn(2 * 200, N, generator=g) * 3
+    mp = torch.tensor([1, 0, 1], dtype=torch.int32)
+    ref = a.double() @ w.double().t() + b.double() + res.view(2, 200, N)[mp.long()].reshape(M, N).double()
+    pw = ops.PackedWeight(w, b, device=dev)
+    out = ops.gemm(ops.to_planes(a.to(dev)), pw, res=ops.to_planes(res.to(dev)), res_bmap=mp.to(dev), res_brows=200)
+    assert _rel_err(out, ref) < 2e-6
