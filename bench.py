@@ -27,13 +27,14 @@ PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, /opt/skills/guides/
 ATTN_GEMM_GFLOP_PER_IMAGE = {'base': 229.8, 'large': 353.6, 'huge': 481.3}   # SURVEY.md §8d / BASELINE.md §3
 
 
-def build_model(arch, num_classes, device):
+def build_model(arch, num_classes, device, kind='anchor'):
     import rsprompter_amd as ra
-    from rsprompter_amd.default_configs import rsprompter_anchor
+    from rsprompter_amd.default_configs import rsprompter_anchor, rsprompter_query
     from rsprompter_amd.synth import synth_state_dict
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        model = ra.build_model(rsprompter_anchor(arch, num_classes))
+        cfg = rsprompter_anchor(arch, num_classes) if kind == 'anchor' else rsprompter_query(arch, num_classes)
+        model = ra.build_model(cfg)
     model.load_state_dict(synth_state_dict(model, seed=0), strict=True)
     return model.to(device)
 
@@ -76,6 +77,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--arch', default='base')
     ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
+    ap.add_argument('--model', default='anchor', choices=['anchor', 'query'],
+                    help="prompter variant; the headline line is 'anchor' (BASELINE.json configs[1])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shapes', action='store_true', help='break the kernel table down by GEMM/attention shape')
     args = ap.parse_args()
@@ -94,8 +97,8 @@ def main():
         raise RuntimeError('bench.py needs an MI355X (no CPU fallback)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
-    num_classes = 10
-    model = build_model(args.arch, num_classes, dev)
+    num_classes = 10 if args.model == 'anchor' else 1
+    model = build_model(args.arch, num_classes, dev, args.model)
     B = args.batch
     imgs = [im.to(dev) for im in synth_images(B, seed=1234 + 1000 * rank)]
     metas = synth_metas(B)
@@ -158,14 +161,14 @@ def main():
         attn_tf = sum(v['flops'] for v in attn) / attn_ms / 1e9 if attn_ms else None
         value = world * B * args.steps / elapsed
         result = {
-            'metric': 'images/sec (1024x1024 synthetic tiles, rsprompter_anchor SAM-ViT-%s, full predict path)' % args.arch[0].upper(),
+            'metric': 'images/sec (1024x1024 synthetic tiles, rsprompter_%s SAM-ViT-%s, full predict path)' % (args.model, args.arch[0].upper()),
             'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f32 (fp32 in/out; GEMMs and attention as fp16x3 split-precision MFMA with fp32 accumulate)',
             'data': 'synthetic',
-            'config': {'workload': f'rsprompter_anchor SAM-ViT-{args.arch}, batch {B}x1024x1024 per GPU, '
-                                   f'{num_classes} classes, seeded synthetic weights (BASELINE.json configs[1])',
+            'config': {'workload': f'rsprompter_{args.model} SAM-ViT-{args.arch}, batch {B}x1024x1024 per GPU, '
+                                   f'{num_classes} classes, seeded synthetic weights' + (' (BASELINE.json configs[1])' if args.model == 'anchor' and args.arch == 'base' and B == 8 else ''),
                        'images_per_gpu_per_step': B, 'detections_per_step_rank0': n_dets,
                        'parallelism': f'dp{world} (images sharded by batch, result all-gather)' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'mfma', 'kernel': dom_name, 'launches_per_step': dom['calls'],
@@ -182,7 +185,7 @@ def main():
                                    'attention_gemm_gflop_per_image': ATTN_GEMM_GFLOP_PER_IMAGE[args.arch]},
             'kernels': kernels,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == 'anchor':
             try:
                 result['cpu_baseline'] = cpu_baseline(args.arch, num_classes)
             except Exception as e:  # the baseline is context, never a reason to lose the measurement

@@ -380,25 +380,59 @@ __global__ __launch_bounds__(256) void query_mask_kernel(const QMaskP p) {
   };
   double sum = 0.0, cnt = 0.0;
   int xmin = 0x7fffffff, ymin = 0x7fffffff, xmax = -1, ymax = -1;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int oy = (int)(i / p.ow), ox = (int)(i - (int64_t)oy * p.ow);
-    float v;
-    if (IDENT) {
-      v = stage1(oy, ox);
-    } else {
-      const Lin2 cy = lin2(oy, s2h, p.ch), cx = lin2(ox, s2w, p.cw);
-      v = cy.l0 * (cx.l0 * stage1(cy.i0, cx.i0) + cx.l1 * stage1(cy.i0, cx.i1)) +
-          cy.l1 * (cx.l0 * stage1(cy.i1, cx.i0) + cx.l1 * stage1(cy.i1, cx.i1));
-    }
-    const bool pos = v > 0.f;
-    p.out[(int64_t)m * total + i] = pos ? 1 : 0;
-    if (p.logits) p.logits[(int64_t)m * total + i] = v;
-    if (pos) {
-      sum += (double)(1.0f / (1.0f + expf(-v)));
-      cnt += 1.0;
+  auto pixel = [&](int oy, int ox) -> float {
+    if (IDENT) return stage1(oy, ox);
+    const Lin2 cy = lin2(oy, s2h, p.ch), cx = lin2(ox, s2w, p.cw);
+    return cy.l0 * (cx.l0 * stage1(cy.i0, cx.i0) + cx.l1 * stage1(cy.i0, cx.i1)) +
+           cy.l1 * (cx.l0 * stage1(cy.i1, cx.i0) + cx.l1 * stage1(cy.i1, cx.i1));
+  };
+  float fsum = 0.f;   // per-thread partial (a thread sees <= a few dozen pixels); widened to double once at the end
+  int icnt = 0;
+  auto account = [&](float v, int oy, int ox) {
+    if (v > 0.f) {
+      // sigmoid through v_exp_f32 / v_rcp_f32 (1-2 ulp): it only enters the mask-average score
+      fsum += __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
+      icnt += 1;
       xmin = min(xmin, ox); xmax = max(xmax, ox); ymin = min(ymin, oy); ymax = max(ymax, oy);
     }
+  };
+  if ((p.ow & 3) == 0) {
+    // four pixels of one row per thread: one 32-bit store of the bool mask instead of four byte stores
+    const int qw = p.ow >> 2;
+    const int nq = p.oh * qw;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nq; i += gridDim.x * blockDim.x) {
+      const int oy = i / qw, ox = (i - oy * qw) << 2;
+      float v[4];
+      if (IDENT) {          // the row coefficients are shared by the four pixels
+        const Lin2 ay = lin2(oy, s1h, p.h);
+        const float* r0 = low + ay.i0 * p.w;
+        const float* r1 = low + ay.i1 * p.w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const Lin2 ax = lin2(ox + e, s1w, p.w);
+          v[e] = ay.l0 * (ax.l0 * r0[ax.i0] + ax.l1 * r0[ax.i1]) + ay.l1 * (ax.l0 * r1[ax.i0] + ax.l1 * r1[ax.i1]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = pixel(oy, ox + e);
+      }
+      uint32_t bits = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bits |= (v[e] > 0.f ? 1u : 0u) << (8 * e); account(v[e], oy, ox + e); }
+      const int64_t o = (int64_t)m * total + (int64_t)oy * p.ow + ox;
+      *reinterpret_cast<uint32_t*>(p.out + o) = bits;
+      if (p.logits) *reinterpret_cast<f32x4*>(p.logits + o) = f32x4{v[0], v[1], v[2], v[3]};
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+      const int oy = (int)(i / p.ow), ox = (int)(i - (int64_t)oy * p.ow);
+      const float v = pixel(oy, ox);
+      p.out[(int64_t)m * total + i] = v > 0.f ? 1 : 0;
+      if (p.logits) p.logits[(int64_t)m * total + i] = v;
+      account(v, oy, ox);
+    }
   }
+  sum = (double)fsum; cnt = (double)icnt;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     sum += __shfl_xor(sum, o, 64); cnt += __shfl_xor(cnt, o, 64);
@@ -552,8 +586,12 @@ extern "C" int rsp_query_mask_post(const float* low_res, const int32_t* qidx, co
   p.stats = (double*)stats_ws; p.box = (int32_t*)((char*)stats_ws + sizeof(double) * 2 * k);
   p.h = h; p.w = w; p.Hb = Hb; p.Wb = Wb; p.ch = crop_h; p.cw = crop_w; p.oh = out_h; p.ow = out_w;
   hipLaunchKernelGGL(init_qstats_kernel, dim3((k + 63) / 64), dim3(64), 0, s, p.stats, p.box, k);
-  int64_t gx = ((int64_t)out_h * out_w + 255) / 256;
-  if (gx > 1024) gx = 1024;
+  if ((int64_t)out_h * out_w > 0x7fffffffLL) return RSP_EINVAL;
+  int64_t gx = ((int64_t)out_h * out_w / ((out_w & 3) == 0 ? 4 : 1) + 255) / 256;
+  // every block ends with 6 atomics on its mask's statistics: with 1024 blocks per mask those same-address atomics
+  // (0.6 M per call) were the whole run time; keep the grid just large enough to fill the chip
+  const int64_t cap = k >= 64 ? 64 : (k >= 8 ? 256 : 1024);
+  if (gx > cap) gx = cap;
   if (crop_h == out_h && crop_w == out_w)
     hipLaunchKernelGGL((query_mask_kernel<true>), dim3((unsigned)gx, k), dim3(256), 0, s, p);
   else
