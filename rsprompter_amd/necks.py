@@ -235,19 +235,21 @@ class RSSimpleFPN(HIPModule):
         x = nhwc_view(input)
         B, H, W, C = x.shape
         ln = _g(self, 'fpn1.1')
-        t = ops.conv_transpose2x2(x, *P['t1a'])
-        t = ops.layernorm(t, ln.weight, ln.bias, 1e-6, act=ops.ACT_GELU)   # LN2d -> GELU (models.py:1299-1300)
-        f1 = ops.conv_transpose2x2(t, *P['t1b'])
-        f2 = ops.conv_transpose2x2(x, *P['t2'])
+        # intermediates that only feed GEMMs travel as fp16 planes (no fp32 copy, no separate split pass)
+        xp = ops.to_planes(x.contiguous())
+        t = ops.conv_transpose2x2(xp, *P['t1a'])
+        t = ops.layernorm(t, ln.weight, ln.bias, 1e-6, act=ops.ACT_GELU, planes=True, f32=False)   # models.py:1299-1300
+        f1 = ops.conv_transpose2x2(t, *P['t1b'], out_planes=True)
+        f2 = ops.conv_transpose2x2(xp, *P['t2'], out_planes=True)
         f4 = ops.pool2(x, 0)
-        ins = [f1, f2, x, f4]
+        ins = [f1, f2, xp, f4]
         outs = []
         for i in range(self.num_ins):
             xi = ins[i]
             b, h, w, ci = xi.shape
             ll, lo = _g(self, f'lateral_convs.{i}.norm_layer'), _g(self, f'fpn_convs.{i}.norm_layer')
             y = ops.gemm(xi.view(b * h * w, ci), P['lat'][i], bias=None)
-            y = ops.layernorm(y, ll.weight, ll.bias, 1e-6)
+            y = ops.layernorm(y, ll.weight, ll.bias, 1e-6, planes=True, f32=False)
             y = ops.gemm(y.view(b, h, w, self.out_channels), P['out'][i], bias=None, conv=(3, 1, 1))
             y = ops.layernorm(y, lo.weight, lo.bias, 1e-6)
             outs.append(y.view(b, h, w, self.out_channels))
