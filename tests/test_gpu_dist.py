@@ -1,0 +1,82 @@
+"""-m gpu: the device side of the result exchange: rsp_pack_bits against numpy.packbits, and
+all_gather_results on device tensors -- single process, and two processes sharing cuda:0 over gloo (RCCL refuses two
+ranks on one device; the collectives are the same calls bench.py issues over RCCL on an 8-GPU node)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_results(rank, n_imgs, dev, hw=(64, 96)):
+    from rsprompter_amd.structures import InstanceData
+    out = []
+    for i in range(n_imgs):
+        g = torch.Generator().manual_seed(100 * rank + i)
+        k = [3, 0, 5, 2][(2 * rank + i) % 4]
+        out.append(InstanceData(bboxes=(torch.rand(k, 4, generator=g) * 50).to(dev), scores=torch.rand(k, generator=g).to(dev),
+                                labels=torch.randint(0, 10, (k,), generator=g).to(dev),
+                                masks=(torch.rand(k, *hw, generator=g) > 0.5).to(dev)))
+    return out
+
+
+def test_pack_masks_matches_numpy(dev):
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(3)
+    m = torch.rand(7, 1024, 1024, generator=g) > 0.3
+    got = ops.pack_masks(m.to(dev)).cpu().numpy()
+    ref = np.packbits(m.reshape(7, -1).numpy().astype(np.uint8), axis=1, bitorder='little')
+    assert np.array_equal(got, ref)
+
+
+def test_all_gather_results_single_process_on_device(dev):
+    from rsprompter_amd import dist as rdist
+    res = _make_results(0, 2, dev)
+    g = rdist.all_gather_results(res)
+    assert g['counts'].tolist() == [3, 0] and g['records'].shape[1] == 3
+    bits = np.unpackbits(g['masks'][0, :3].cpu().numpy(), axis=1, bitorder='little').astype(bool)
+    assert np.array_equal(bits.reshape(3, *g['mask_hw']), res[0].masks.cpu().numpy())
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from rsprompter_amd import dist as rdist
+    dev = torch.device('cuda:0')
+    try:
+        rdist.init_from_env(backend='gloo')
+        g = rdist.all_gather_results(_make_results(rank, 2, dev))
+        ret[rank] = {k: (v.cpu() if isinstance(v, torch.Tensor) else v) for k, v in g.items()}
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:  # reported to the parent, which decides between failure and "backend cannot do this"
+        ret[rank] = repr(e)
+
+
+def test_all_gather_results_two_ranks_on_one_device():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
+    if isinstance(ret[0], str) or isinstance(ret[1], str):
+        msg = f'{ret[0]} / {ret[1]}'
+        if 'gloo' in msg.lower() or 'not supported' in msg.lower() or 'not implemented' in msg.lower():
+            pytest.skip(f'gloo cannot run this collective on device tensors here: {msg[:200]}')
+        raise AssertionError(msg)
+    g0, g1 = ret[0], ret[1]
+    for k in ('counts', 'records', 'masks'):
+        assert torch.equal(g0[k], g1[k])
+    assert g0['counts'].tolist() == [3, 0, 5, 2] and g0['records'].shape[1] == 5
+    cpu = torch.device('cpu')
+    for rank in range(2):
+        for i, r in enumerate(_make_results(rank, 2, cpu)):
+            j, k = rank * 2 + i, len(r.bboxes)
+            assert torch.equal(g0['records'][j, :k, :4], r.bboxes)
+            if k:
+                bits = np.unpackbits(g0['masks'][j, :k].numpy(), axis=1, bitorder='little').astype(bool)
+                assert np.array_equal(bits.reshape(k, *g0['mask_hw']), r.masks.numpy())
