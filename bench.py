@@ -174,7 +174,7 @@ def main():
             'roofline': {'bound': 'mfma', 'kernel': dom_name, 'launches_per_step': dom['calls'],
                          'ms_per_step': round(dom['ms'], 3), 'achieved': round(achieved, 2),
                          'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
-                         'traffic': _pmc_traffic(),
+                         'traffic': (_pmc_traffic() or {}).get('bytes_per_launch'), 'traffic_detail': _pmc_traffic(),
                          'note': 'achieved = algorithmic fp32 FLOPs (2MNK) of all launches of the kernel in one step / '
                                  'their summed HIP-event durations; the kernel issues 3 fp16 MFMA passes per algorithmic '
                                  'FLOP (fp16x3), so its ceiling is peak/3 = 833 TFLOP/s',
