@@ -253,6 +253,12 @@ int rsp_batched_nms(const float* boxes, const float* scores, const int32_t* ids,
 /* SAM decoder tail / mask post-process                                        */
 /* ------------------------------------------------------------------------ */
 /* out[r, pix] = sum_c up[r, pix, c] * hyper[r, c]     (HF:523-531)             */
+/* Evaluation hand-off: COCO RLE counts of k bool masks [k,H,W] (row-major bytes), i.e. the run      */
+/* lengths of the column-major pixel stream, first run = zeros (pycocotools.mask.encode as used by                   */
+/* encode_mask_results, mmdet/structures/mask/utils.py:38-53).  counts [k, cap] uint32, n_counts[k] = number of runs */
+/* or -(needed) when cap is too small; workspace: k*cap uint32.  W <= 8192.                                          */
+int rsp_mask_rle(const uint8_t* masks, int32_t k, int32_t H, int32_t W, void* workspace, uint32_t* counts,
+                 int32_t* n_counts, int32_t cap, rsp_stream_t stream);
 /* SAM upscaler tail, streaming form (HF:521-531): rows = R*H2*W2 input pixels as fp16 planes (KB32, K = 64),      */
 /* weight planes [2][128][32] with rows (dy, dx, c) of ConvTranspose2d(64 -> 32, k2, s2), bias tiled x4 [128],       */
 /* hyper [R, 32]; out [R, 2*H2, 2*W2] = sum_c GELU(convT)[.., c] * hyper[r, c].  rows_per_roi = H2*W2, ct_W = W2.    */

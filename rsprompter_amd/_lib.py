@@ -96,6 +96,7 @@ PROTOTYPES = {
                                ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_float, c_void_p]),
     "rsp_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rsp_attention": (c_int, [ctypes.POINTER(RspAttnDesc), c_void_p]),
+    "rsp_mask_rle": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "rsp_sam_upscale2": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                  c_void_p, c_int, c_int, c_void_p]),
     "rsp_sam_t2i_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),

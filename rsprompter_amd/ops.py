@@ -761,6 +761,27 @@ def pack_masks(masks):
     return out
 
 
+def mask_rle_counts(masks, cap=4096):
+    """bool [k, H, W] -> (counts int32 [k, cap'], n int32 [k]): COCO RLE run lengths (column-major stream, first run
+    counts zeros).  Retries with a larger capacity when a mask has more runs than `cap`."""
+    lib = _lib.load()
+    k, H, W = masks.shape
+    m = masks.contiguous()
+    dev = masks.device
+    while True:
+        counts = torch.empty((k, cap), dtype=torch.int32, device=dev)
+        ws = torch.empty((k, cap), dtype=torch.int32, device=dev)
+        n = torch.empty((k,), dtype=torch.int32, device=dev)
+        if k:
+            _lib.check(lib.rsp_mask_rle(m.data_ptr(), k, H, W, ws.data_ptr(), counts.data_ptr(), n.data_ptr(), cap,
+                                        _stream()), "rsp_mask_rle")
+            need = int((-n).max().item())
+            if need > 0:
+                cap = 1 << (need - 1).bit_length()
+                continue
+        return counts, n
+
+
 # ----------------------------------------------------------------------------- query prompter ops
 def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, add=None):
     """GroupNorm on channels-last [B, ..., C]; `add` (same shape) is added after the norm."""

@@ -80,3 +80,26 @@ def test_all_gather_results_two_ranks_on_one_device():
             if k:
                 bits = np.unpackbits(g0['masks'][j, :k].numpy(), axis=1, bitorder='little').astype(bool)
                 assert np.array_equal(bits.reshape(k, *g0['mask_hw']), r.masks.numpy())
+
+
+def test_mask_rle_matches_coco_restatement(dev):
+    """rsp_mask_rle + host string compression against oracle/rle.py (pinned on the reference's RLE strings)."""
+    import json
+    from oracle import rle
+    from rsprompter_amd.rle import encode_mask_results
+    g = torch.Generator().manual_seed(8)
+    masks = torch.zeros(6, 720, 1280, dtype=torch.bool)
+    masks[0, 100:150, 100:150] = True
+    masks[1] = torch.rand(720, 1280, generator=g) > 0.5                  # ~460k runs: exercises the capacity retry
+    masks[2, :, 0] = True
+    masks[3, 0, :] = True
+    masks[4] = True
+    blob = torch.rand(720, 1280, generator=g)
+    masks[5] = torch.nn.functional.avg_pool2d(blob[None, None], 31, 1, 15)[0, 0] > 0.5
+    got = encode_mask_results(masks.to(dev))
+    for i in range(masks.shape[0]):
+        ref = rle.encode(masks[i].numpy())
+        assert got[i]['size'] == ref['size'] and got[i]['counts'] == ref['counts'], i
+    d = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'coco_rle_strings.json')))
+    it = d['items'][0]
+    assert got[0]['counts'].decode() == it['counts']                      # the reference's own string for this box

@@ -137,3 +137,26 @@ def test_mask_postprocess_matches_reference_source(gold):
         masks, boxes, _ = glue.mask_postprocess_single(d['low'], d['boxes'].clone(), d['meta'], 0.5, True)
         assert torch.equal(masks, d['masks']), tag
         assert torch.equal(boxes, d['boxes_out']), tag
+
+
+def test_coco_rle_restatement_reproduces_reference_strings():
+    """oracle/rle.py against the compressed RLE strings of the reference's tests/data/vis_sample.json."""
+    import json
+    import os
+    import numpy as np
+    from oracle import rle
+    d = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'coco_rle_strings.json')))
+    assert len(d['items']) >= 3
+    for it in d['items']:
+        h, w = it['size']
+        m = rle.rle_decode(rle.rle_from_string(it['counts']), h, w)
+        assert int(m.sum()) == int(it['area'])
+        ys, xs = np.nonzero(m)
+        assert [int(xs.min()), int(ys.min()), int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)] == it['bbox']
+        assert rle.encode(m)['counts'].decode() == it['counts']
+    g = np.random.default_rng(0)
+    for shape in ((7, 5), (64, 33), (1, 9)):
+        m = g.random(shape) > 0.5
+        c = rle.rle_counts(m)
+        assert int(c.sum()) == m.size
+        assert np.array_equal(rle.rle_decode(rle.rle_from_string(rle.rle_to_string(c)), *shape), m)
