@@ -110,6 +110,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Windowed layers (S <= 16, tables of 2S-1 <= 32 rows): the same terms as ONE small matrix product per table,
+//   G[idx, q] = R[idx, :] . q        (fp16x3 MFMA, 32 queries x 32 table rows per wave, K = dh)
+// followed by the Toeplitz gather rel_h[q, j] = G_h[qy - j + S-1, q], rel_w[q, j] = G_w[qx - j + S-1, q] through a
+// per-wave LDS transpose.  28 of the 32 ViT-H layers are windowed; the FMA kernel above is LDS-read bound there.
+constexpr int RQ = 6, RT = 6;          // power-of-two operand scales (fp16 range), as in the attention kernels
+
+template <int DH>
+__global__ __launch_bounds__(256) void vit_relpos_win_kernel(const float* __restrict__ qkv,
+                                                             const float* __restrict__ rph,
+                                                             const float* __restrict__ rpw,
+                                                             float* __restrict__ rel, int T, int S, int nh,
+                                                             int64_t rows_total) {
+  constexpr int DSTEPS = DH / 16;
+  constexpr int LDT = DH + 8;                                  // halves per table row (conflict-free b128 reads)
+  __shared__ __attribute__((aligned(16))) half_t sT[2][2][32 * LDT];   // [table][hi/lo][idx][d]
+  __shared__ float sG[4][32][33];                              // per wave: [query][idx]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y;
+  const int nrow = 2 * S - 1;
+  const float ts = ldexpf(1.0f, RT);
+  for (int idx = tid; idx < 2 * 32 * (DH / 4); idx += 256) {
+    const int tb = idx / (32 * (DH / 4)), rem = idx - tb * 32 * (DH / 4);
+    const int r = rem / (DH / 4), c = rem - r * (DH / 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (r < nrow) v = *reinterpret_cast<const f32x4*>((tb ? rpw : rph) + (int64_t)r * DH + 4 * c);
+    half4_t hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { half_t a, b; rsp_split1(v[e] * ts, a, b); hi[e] = a; lo[e] = b; }
+    *reinterpret_cast<half4_t*>(&sT[tb][0][r * LDT + 4 * c]) = hi;
+    *reinterpret_cast<half4_t*>(&sT[tb][1][r * LDT + 4 * c]) = lo;
+  }
+  const int64_t g = ((int64_t)blockIdx.x * 4 + wave) * 32 + l31;
+  const bool ok = g < rows_total;
+  const int64_t gg = ok ? g : 0;
+  const int q = (int)(gg % T);
+  const int qy = q / S, qx = q - qy * S;
+  // Q fragments (B operand): lane = query column, k slots 8hh..8hh+7 of every 16
+  half8_t qh[DSTEPS], ql[DSTEPS];
+  {
+    const float qs = ldexpf(1.0f, RQ);
+    const float* src = qkv + gg * ((int64_t)3 * nh * DH) + (int64_t)h * DH;
+#pragma unroll
+    for (int st = 0; st < DSTEPS; ++st) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + st * 16 + hh * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(src + st * 16 + hh * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        half_t x, y;
+        rsp_split1((ok ? a[e] : 0.f) * qs, x, y); qh[st][e] = x; ql[st][e] = y;
+        rsp_split1((ok ? b[e] : 0.f) * qs, x, y); qh[st][4 + e] = x; ql[st][4 + e] = y;
+      }
+    }
+  }
+  __syncthreads();
+  const float unscale = ldexpf(1.0f, -(RQ + RT));
+  const int64_t bpw = gg / T;                                  // window index: rel is [Bp*nh, T, 2S]
+  float* dst = rel + ((bpw * nh + h) * T + q) * (2 * S);
+  // the half waves split the S outputs of a table into [0, S0) and [S0, S) with S0 even (8-byte stores stay aligned)
+  const int S0 = ((S / 2) + 1) & ~1;
+  const int jb = hh ? S0 : 0, je = hh ? S : S0;
+#pragma unroll
+  for (int tb = 0; tb < 2; ++tb) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int st = 0; st < DSTEPS; ++st) {
+      const int off = l31 * LDT + st * 16 + hh * 8;
+      const half8_t th = *reinterpret_cast<const half8_t*>(&sT[tb][0][off]);
+      const half8_t tl = *reinterpret_cast<const half8_t*>(&sT[tb][1][off]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl, qh[st], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, ql[st], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(th, qh[st], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sG[wave][l31][(r & 3) + 8 * (r >> 2) + 4 * hh] = acc[r] * unscale;
+    __syncthreads();
+    if (ok) {
+      const int pos = (tb ? qx : qy) + S - 1;
+      float* d2 = dst + (tb ? S : 0);
+      if ((S & 1) == 0) {
+        for (int j = jb; j < je; j += 2)
+          *reinterpret_cast<float2*>(d2 + j) = make_float2(sG[wave][l31][pos - j], sG[wave][l31][pos - j - 1]);
+      } else {
+        for (int j = jb; j < je; ++j) d2[j] = sG[wave][l31][pos - j];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace
 
 extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const float* rel_pos_w,
@@ -119,6 +213,15 @@ extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const fl
     return RSP_EINVAL;
   const int T = S * S;
   const int64_t rows_total = (int64_t)Bp * T;
+  if (S <= 16 && (dh == 64 || dh == 80)) {   // windowed layers: MFMA form
+    dim3 g2((unsigned)((rows_total + 127) / 128), nh, 1);
+    if (dh == 64)
+      hipLaunchKernelGGL((vit_relpos_win_kernel<64>), g2, dim3(256), 0, (hipStream_t)stream, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total);
+    else
+      hipLaunchKernelGGL((vit_relpos_win_kernel<80>), g2, dim3(256), 0, (hipStream_t)stream, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total);
+    RSP_CHECK_LAUNCH();
+    return RSP_OK;
+  }
   dim3 grid((unsigned)((rows_total + 63) / 64), nh, 1);
   const size_t smem = (size_t)(2 * (2 * S - 1)) * (dh + 4) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
