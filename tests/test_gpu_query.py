@@ -162,6 +162,6 @@ def test_query_end_to_end(setup, dev):
     if not bool(same.all()):
         near_tie = torch.zeros_like(same)
         d = (sc[:, None] - sc[None, :]).abs() + torch.eye(len(sc)) * 1e9
-        near_tie = (d.min(1).values < 2e-5) | ((sc - cut).abs() < 2e-5)
+        near_tie = (d.min(1).values < 5e-5) | ((sc - cut).abs() < 5e-5)
         assert bool(near_tie[~same].all()) and int((~same).sum()) <= 4
     assert _maxerr(pi.scores, ref['scores']) < 1e-4 and mism < 1e-3
