@@ -160,3 +160,21 @@ def test_coco_rle_restatement_reproduces_reference_strings():
         c = rle.rle_counts(m)
         assert int(c.sum()) == m.size
         assert np.array_equal(rle.rle_decode(rle.rle_from_string(rle.rle_to_string(c)), *shape), m)
+
+
+def test_rle_host_string_compression_matches_restatement():
+    """rsprompter_amd/rle.py::_counts_to_string (the host half of encode_mask_results) vs oracle/rle.py, incl. the
+    reference's own strings."""
+    import json
+    import os
+    import numpy as np
+    from oracle import rle
+    from rsprompter_amd.rle import _counts_to_string
+    d = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'coco_rle_strings.json')))
+    for it in d['items']:
+        cnts = [int(c) for c in rle.rle_from_string(it['counts'])]
+        assert _counts_to_string(cnts).decode() == it['counts']
+    g = np.random.default_rng(1)
+    for _ in range(20):
+        cnts = [int(v) for v in g.integers(0, 5000, size=int(g.integers(1, 60)))]
+        assert _counts_to_string(cnts) == rle.rle_to_string(cnts)
