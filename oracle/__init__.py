@@ -21,7 +21,12 @@ Pinning status:
     (tests/golden/make_golden.py -> tests/golden/*.pt) and against the two
     known-answer tests the reference inherits
     (test_delta_xywh_bbox_coder.py:9-24, test_anchor_generator.py:290-309).
+  * query path: mask2bbox and MaskFormerFusionHead.instance_postprocess are checked the same way
+    (tests/golden/make_golden_query.py, order-free: the reference's topk is sorted=False).
+  * COCO RLE (oracle/rle.py, pycocotools restated): pinned on the compressed RLE strings of the reference's
+    tests/data/vis_sample.json (tests/golden/coco_rle_strings.json).
   * SAM encoder / mask decoder: HF modules themselves (the reference's dependency).
-  * mmcv RoIAlign / nms / batched_nms: source not in /root/reference ->
-    restated from documented semantics: PARITY UNPINNED at that boundary.
+  * mmcv RoIAlign / nms / batched_nms / MultiScaleDeformableAttention / MultiheadAttention / FFN and peft's LoRA
+    wrapping: source not in /root/reference -> restated from documented semantics:
+    PARITY UNPINNED at that boundary.
 """

@@ -178,3 +178,28 @@ def test_rle_host_string_compression_matches_restatement():
     for _ in range(20):
         cnts = [int(v) for v in g.integers(0, 5000, size=int(g.integers(1, 60)))]
         assert _counts_to_string(cnts) == rle.rle_to_string(cnts)
+
+
+def test_query_postprocess_restatements_match_reference_vectors():
+    """oracle/query.py::mask2bbox / instance_postprocess against vectors produced by the REAL reference sources
+    (tests/golden/make_golden_query.py: structures/mask/utils.py:56-77, maskformer_fusion_head.py:126-182).
+    The reference keeps its top-k with sorted=False (order unspecified): compared order-free by (query, label)."""
+    import os
+    from oracle import query as oq
+    d = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_vectors_query.pt'))
+    m = d['mask2bbox']
+    assert torch.equal(oq.mask2bbox(m['masks']), m['out'])
+    for c in d['instance_postprocess']:
+        r = oq.instance_postprocess(c['mask_cls'], c['mask_pred'], c['num_classes'], c['max_per_image'])
+        assert r['labels'].shape[0] == c['labels'].shape[0]
+
+        def key(scores, labels, boxes):
+            # det score, label and box identify an entry; sort for an order-free comparison
+            k = torch.stack([scores.double(), labels.double(), boxes[:, 0].double(), boxes[:, 1].double()], 1)
+            idx = sorted(range(k.shape[0]), key=lambda i: tuple(k[i].tolist()))
+            return torch.tensor(idx)
+        ia, ib = key(r['scores'], r['labels'], r['bboxes']), key(c['scores'], c['labels'], c['bboxes'])
+        assert torch.equal(r['labels'][ia], c['labels'][ib])
+        assert torch.equal(r['bboxes'][ia], c['bboxes'][ib])
+        assert float((r['scores'][ia] - c['scores'][ib]).abs().max()) < 1e-6
+        assert torch.equal(r['masks'][ia], c['masks'][ib])
