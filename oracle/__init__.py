@@ -21,8 +21,13 @@ Pinning status:
     (tests/golden/make_golden.py -> tests/golden/*.pt) and against the two
     known-answer tests the reference inherits
     (test_delta_xywh_bbox_coder.py:9-24, test_anchor_generator.py:290-309).
-  * query path: mask2bbox and MaskFormerFusionHead.instance_postprocess are checked the same way
-    (tests/golden/make_golden_query.py, order-free: the reference's topk is sorted=False).
+  * query path: mask2bbox, MaskFormerFusionHead.instance_postprocess and RSMaskFormerFusionHead.predict are checked
+    the same way (tests/golden/make_golden_query.py, order-free: the reference's topk is sorted=False).
+  * detection glue of the anchor path -- RPNHead._predict_by_feat_single/_bbox_post_process, multiclass_nms,
+    BBoxHead._predict_by_feat_single, SingleRoIExtractor.map_roi_levels -- is checked against the real reference
+    sources run AROUND an injected batched_nms (tests/golden/make_golden_heads.py): everything that decides which
+    indices come out except the NMS primitive itself (exact score ties compared order-free: the reference's sort is
+    not stable).
   * COCO RLE (oracle/rle.py, pycocotools restated): pinned on the compressed RLE strings of the reference's
     tests/data/vis_sample.json (tests/golden/coco_rle_strings.json).
   * SAM encoder / mask decoder: HF modules themselves (the reference's dependency).

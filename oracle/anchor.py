@@ -283,12 +283,8 @@ class AnchorOracle(nn.Module):
                 out.append(dict(bboxes=p.new_zeros((0, 4)), scores=p.new_zeros(0),
                                 labels=torch.zeros(0, dtype=torch.long), cand=torch.zeros(0, dtype=torch.long)))
                 continue
-            scores = F.softmax(cs, dim=-1)
-            nc = self.num_classes
-            bboxes = glue.delta2bbox(roi[:, 1:].repeat_interleave(nc, dim=0), bp.view(-1, 4),
-                                     stds=(0.1, 0.1, 0.2, 0.2), max_shape=meta['img_shape']).view(n, -1)
-            dets, labels, cand = glue.multiclass_nms(bboxes, scores, c['score_thr'], c['iou_threshold'],
-                                                     c['max_per_img'])
+            dets, labels, cand = glue.bbox_head_predict_single(roi, cs, bp, meta['img_shape'], self.num_classes,
+                                                               c['score_thr'], c['iou_threshold'], c['max_per_img'])
             out.append(dict(bboxes=dets[:, :4], scores=dets[:, 4], labels=labels, cand=cand))
         return out, dict(rois=rois, roi_feats=feats, cls_score=cls_score, bbox_pred=bbox_pred)
 

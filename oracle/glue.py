@@ -115,6 +115,18 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, iou_threshold, max_num
     return dets, labels[keep], inds[keep]
 
 
+def bbox_head_predict_single(roi, cls_score, bbox_pred, img_shape, num_classes, score_thr, iou_threshold, max_per_img,
+                             stds=(0.1, 0.1, 0.2, 0.2)):
+    """BBoxHead._predict_by_feat_single (bbox_head.py:476-571), class-specific regression, rescale=False:
+    softmax scores, per-class delta decode of the repeated RoIs, multiclass NMS.  roi [n,5], cls_score [n,nc+1],
+    bbox_pred [n,nc*4] -> dets [k,5], labels [k], flat (roi, class) candidate index [k]."""
+    n = roi.shape[0]
+    scores = torch.softmax(cls_score, dim=-1)
+    bboxes = delta2bbox(roi[:, 1:].repeat_interleave(num_classes, dim=0), bbox_pred.view(-1, 4), stds=stds,
+                        max_shape=img_shape).view(n, -1)
+    return multiclass_nms(bboxes, scores, score_thr, iou_threshold, max_per_img)
+
+
 # --------------------------------------------------------------------------- RPN
 def rpn_predict_single(cls_score_list, bbox_pred_list, mlvl_priors, img_shape, nms_pre=1000,
                        max_per_img=1000, iou_thr=0.7, min_bbox_size=0):

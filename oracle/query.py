@@ -283,6 +283,20 @@ def instance_postprocess(mask_cls, mask_pred, num_classes, max_per_image=100):
                 query_indices=query_indices, cls_scores=scores_per_image, mask_logits=mask_pred)
 
 
+def fusion_predict(mask_cls_results, mask_pred_results, metas, num_classes, max_per_image=100, rescale=True):
+    """RSMaskFormerFusionHead.predict (models.py:663-715) with instance_on only: crop the padding
+    (`int(ori * scale_factor)`), optionally resize the LOGITS to ori_shape, then instance_postprocess."""
+    results = []
+    for c, m, meta in zip(mask_cls_results, mask_pred_results, metas):
+        oh, ow = meta['ori_shape'][:2]
+        sf = meta['scale_factor']
+        m = m[:, :int(oh * sf[1]), :int(ow * sf[0])]
+        if rescale:
+            m = F.interpolate(m[:, None], size=(oh, ow), mode='bilinear', align_corners=False)[:, 0]
+        results.append(instance_postprocess(c, m, num_classes, max_per_image))
+    return results
+
+
 class QueryOracle(nn.Module):
     """RSPrompterQuery predict path, configs/rsprompter/_base_/rsprompter_query.py."""
 
@@ -308,13 +322,6 @@ class QueryOracle(nn.Module):
         cls, mask, trace = self.panoptic_head(x, emb, ipe)
         img_shape = metas[0]['batch_input_shape']
         mask_up = F.interpolate(mask, size=(img_shape[0], img_shape[1]), mode='bilinear', align_corners=False)
-        results = []
-        for c, m, meta in zip(cls, mask_up, metas):
-            oh, ow = meta['ori_shape'][:2]
-            sf = meta['scale_factor']
-            m = m[:, :int(oh * sf[1]), :int(ow * sf[0])]
-            if rescale:
-                m = F.interpolate(m[:, None], size=(oh, ow), mode='bilinear', align_corners=False)[:, 0]
-            results.append(instance_postprocess(c, m, self.num_classes, self.max_per_image))
+        results = fusion_predict(cls, mask_up, metas, self.num_classes, self.max_per_image, rescale)
         trace.update(t0, fpn=x, image_embeddings=emb, image_pe=ipe)
         return results, trace

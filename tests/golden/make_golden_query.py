@@ -48,6 +48,25 @@ def main():
         cases.append(dict(num_classes=nc, max_per_image=head.test_cfg['max_per_image'], mask_cls=mask_cls,
                           mask_pred=mask_pred, bboxes=r.bboxes, labels=r.labels, scores=r.scores, masks=r.masks))
     out['instance_postprocess'] = cases
+
+    # RSMaskFormerFusionHead.predict (mmdet/rsprompter/models.py:663-715) on top of the real fusion head
+    import transformers  # noqa: F401  (real; models.py imports it)
+    sys.modules['mmdet.models'].MaskFormerFusionHead = fh.MaskFormerFusionHead
+    models = mg._load('mmdet/rsprompter/models.py', '_ref_models')
+    preds = []
+    for (meta, nq, nc, seed) in ((dict(img_shape=(64, 64), ori_shape=(64, 64), scale_factor=(1.0, 1.0)), 20, 1, 0),
+                                 (dict(img_shape=(64, 64), ori_shape=(32, 32), scale_factor=(2.0, 2.0)), 20, 2, 1),
+                                 (dict(img_shape=(64, 64), ori_shape=(40, 27), scale_factor=(1.5, 1.5)), 16, 3, 2)):
+        g = torch.Generator().manual_seed(40 + seed)
+        head = models.RSMaskFormerFusionHead()
+        head.num_things_classes, head.num_stuff_classes, head.num_classes = nc, 0, nc
+        head.test_cfg = dict(max_per_image=10, panoptic_on=False, semantic_on=False, instance_on=True)
+        mask_cls = torch.randn(1, nq, nc + 1, generator=g) * 2
+        mask_pred = torch.randn(1, nq, 64, 64, generator=g) * 3          # already at batch_input_shape (models.py:652-656)
+        r = head.predict(mask_cls, mask_pred, [types.SimpleNamespace(metainfo=meta)], rescale=True)[0]['ins_results']
+        preds.append(dict(meta=meta, num_classes=nc, max_per_image=10, mask_cls=mask_cls, mask_pred=mask_pred,
+                          bboxes=r.bboxes, labels=r.labels, scores=r.scores, masks=r.masks))
+    out['fusion_predict'] = preds
     torch.save(out, OUT)
     print('wrote', OUT, {k: (len(v) if isinstance(v, list) else list(v.keys())) for k, v in out.items()})
 

@@ -203,3 +203,46 @@ def test_query_postprocess_restatements_match_reference_vectors():
         assert torch.equal(r['bboxes'][ia], c['bboxes'][ib])
         assert float((r['scores'][ia] - c['scores'][ib]).abs().max()) < 1e-6
         assert torch.equal(r['masks'][ia], c['masks'][ib])
+    # RSMaskFormerFusionHead.predict (models.py:663-715): padding crop, logit resize, then the above
+    for c in d['fusion_predict']:
+        r = oq.fusion_predict(c['mask_cls'], c['mask_pred'], [c['meta']], c['num_classes'], c['max_per_image'], True)[0]
+        ia, ib = key(r['scores'], r['labels'], r['bboxes']), key(c['scores'], c['labels'], c['bboxes'])
+        assert tuple(r['masks'].shape) == tuple(c['masks'].shape)
+        assert torch.equal(r['labels'][ia], c['labels'][ib]) and torch.equal(r['bboxes'][ia], c['bboxes'][ib])
+        assert float((r['scores'][ia] - c['scores'][ib]).abs().max()) < 1e-6
+        assert torch.equal(r['masks'][ia], c['masks'][ib])
+
+
+def test_detection_glue_restatements_match_reference_vectors():
+    """oracle/glue.py::rpn_predict_single / multiclass_nms / map_roi_levels against vectors produced by the REAL
+    reference sources around an injected batched_nms (tests/golden/make_golden_heads.py): pins the index-deciding glue
+    of the anchor path (rpn_head.py:134-304, bbox_nms.py:12-105, single_level_roi_extractor.py:44-63)."""
+    import os
+    from oracle import glue
+    d = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_vectors_heads.pt'))
+    for c in d['rpn_predict_single']:
+        priors = glue.grid_priors(c['sizes'], [4, 8, 16, 32, 64], [4, 8], [0.5, 1.0, 2.0])
+        r = glue.rpn_predict_single(c['cls'], c['reg'], priors, c['img_shape'], nms_pre=c['nms_pre'],
+                                    max_per_img=c['max_per_img'], iou_thr=c['iou_thr'], min_bbox_size=c['min_bbox_size'])
+        assert r['bboxes'].shape == c['bboxes'].shape, (r['bboxes'].shape, c['bboxes'].shape)
+        assert torch.equal(r['scores'], c['scores'])
+
+        def canon(boxes, scores):
+            # the reference sorts with torch.sort(descending=True) (NOT stable, rpn_head.py:208): entries whose fp32
+            # sigmoid scores are exactly equal may come in either order -> canonical order inside equal-score runs
+            k = torch.cat([-scores[:, None].double(), boxes.double()], 1)
+            idx = sorted(range(k.shape[0]), key=lambda i: tuple(k[i].tolist()))
+            return boxes[torch.tensor(idx)]
+        assert torch.equal(canon(r['bboxes'], r['scores']), canon(c['bboxes'], c['scores']))
+        n_swapped = int((r['bboxes'] != c['bboxes']).any(1).sum())
+        assert n_swapped <= 4                                # only exact ties may differ in position
+    for c in d['multiclass_nms']:
+        dets, labels, inds = glue.multiclass_nms(c['boxes'], c['scores'], c['score_thr'], c['iou_thr'], c['max_num'])
+        assert torch.equal(dets, c['dets']) and torch.equal(labels, c['labels']) and torch.equal(inds, c['inds'])
+    for c in d['bbox_head_predict_single']:
+        dets, labels, _ = glue.bbox_head_predict_single(c['roi'], c['cls_score'], c['bbox_pred'], c['img_shape'],
+                                                        c['num_classes'], c['score_thr'], c['iou_thr'], c['max_per_img'])
+        assert torch.equal(dets[:, :4], c['bboxes']) and torch.equal(dets[:, 4], c['scores'])
+        assert torch.equal(labels, c['labels'])
+    m = d['map_roi_levels']
+    assert torch.equal(glue.map_roi_levels(m['rois'], m['num_levels'], m['finest_scale']), m['out'])
