@@ -165,3 +165,32 @@ def test_query_end_to_end(setup, dev):
         near_tie = (d.min(1).values < 5e-5) | ((sc - cut).abs() < 5e-5)
         assert bool(near_tie[~same].all()) and int((~same).sum()) <= 4
     assert _maxerr(pi.scores, ref['scores']) < 1e-4 and mism < 1e-3
+
+
+def test_fusion_head_rescale_paths(dev):
+    """RSMaskFormerFusionHead.predict with padded / rescaled images (BASELINE.json configs[4] "WHU-shape": 512 px tiles
+    resized x2; and a non-square 1.5x case): crop of the padding, second bilinear resize of the LOGITS to ori_shape,
+    then instance_postprocess -- against oracle.query.fusion_predict (pinned on the reference's own code)."""
+    import torch.nn.functional as F
+    from oracle import query as oq
+    from rsprompter_amd.query_heads import LazyUpsampledMasks, RSMaskFormerFusionHead
+    from rsprompter_amd.structures import DetDataSample
+    g = torch.Generator().manual_seed(21)
+    nq, nc, k = 24, 2, 10
+    head = RSMaskFormerFusionHead(num_things_classes=nc, num_stuff_classes=0,
+                                  test_cfg=dict(panoptic_on=False, semantic_on=False, instance_on=True, max_per_image=k))
+    for meta in (dict(img_shape=(1024, 1024), ori_shape=(512, 512), scale_factor=(2.0, 2.0), batch_input_shape=(1024, 1024)),
+                 dict(img_shape=(900, 600), ori_shape=(600, 400), scale_factor=(1.5, 1.5), batch_input_shape=(1024, 1024))):
+        cls = torch.randn(1, nq, nc + 1, generator=g) * 2
+        blob = F.avg_pool2d(torch.randn(1, nq, 256, 256, generator=g), 9, 1, 4) * 12      # smooth logits, both signs
+        up = F.interpolate(blob, size=(1024, 1024), mode='bilinear', align_corners=False)
+        ref = oq.fusion_predict(cls, up, [meta], nc, k, rescale=True)[0]
+        res = head.predict(cls.to(dev), LazyUpsampledMasks(blob.to(dev), (1024, 1024)), [DetDataSample(metainfo=dict(meta))],
+                           rescale=True)[0]['ins_results']
+        assert torch.equal(res.query_indices.cpu().long(), ref['query_indices'])
+        assert torch.equal(res.labels.cpu(), ref['labels'])
+        assert tuple(res.masks.shape) == tuple(ref['masks'].shape)
+        assert _maxerr(res.scores, ref['scores']) < 1e-5
+        mism = float((res.masks.cpu() != ref['masks']).float().mean())
+        assert mism < 1e-5, mism
+        assert float((res.bboxes.cpu() - ref['bboxes']).abs().max()) <= 1.0       # a flipped boundary pixel moves a box edge by 1
