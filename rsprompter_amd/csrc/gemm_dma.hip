@@ -14,8 +14,10 @@
 // column), so the 16-B chunk index is XOR-swizzled with (row >> 2) & 3 -- applied on the per-lane
 // GLOBAL source address (the DMA destination must stay linear) and again on the read.
 //
-// Pipeline: 2 LDS buffers; the DMA for tile k+1 is issued before the MFMA block of tile k and is
-// drained by the __syncthreads() that ends the iteration (one barrier per K step).
+// Pipeline (template PIPE, see the kernel): an NBUF-deep LDS ring fed by the DMA; the product variants
+// (PIPE = 1 / 2) issue the fragment reads of the next half K tile before the MFMAs of the current one and spread the
+// DMA instructions of the tile after next between the MFMA groups; ONE s_barrier per K tile.  The epilogue stages the
+// accumulators through the (then idle) ring and stores row-wise, 4 consecutive columns per thread.
 #include <type_traits>
 #include "rsp_common.h"
 
@@ -81,8 +83,9 @@ __device__ __forceinline__ void static_for(F&& f) {
   }
 }
 
-// EPI: reserved (0); the fused LayerNorm / hyper-network epilogues are run-time modes of the generic epilogue,
-// 2 = ConvTranspose + LayerNorm over each 64-channel sub-pixel + act -> planes (pairs of j tiles)
+// EPI: reserved (0); the fused LayerNorm / hyper-network epilogues are run-time modes of the generic epilogue.
+// PIPE: 0 = plain ring, 1 = register-pipelined loop, 2 = 1 + DMA instructions spread between the MFMA groups.
+// CONV: implicit-GEMM 3x3 convolution loader (A addresses from (pixel, tap)).
 template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const GemmP p) {
   constexpr int NT = WGM * WGN * 64;
