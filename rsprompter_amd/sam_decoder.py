@@ -194,6 +194,12 @@ class SamMaskDecoderHIP(HIPModule):
         R, npts = sparse.shape[0], sparse.shape[1]
         T = 1 + N_MASK_TOKENS + npts
         pe_rows = nhwc_view(image_pe[:1]).reshape(N, C)
+        if (pe_rows.data_ptr(), tuple(pe_rows.shape)) not in self._pe_cache and image_pe.shape[0] > 1:
+            # the image-wide positional embedding is ONE table repeated over the batch (models.py:85-95, 1685); its
+            # projections are folded into broadcast terms below, so a caller with per-image tables must not get a
+            # silently wrong answer (checked once per new table, not per step)
+            if not bool((image_pe == image_pe[:1]).all()):
+                raise NotImplementedError('image_positional_embeddings must be the same table for every batch entry')
         pe_t = self._pe_terms(pe_rows)
         d2, dh2 = HID // 2, (HID // 2) // HEADS
 

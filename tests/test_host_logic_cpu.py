@@ -125,3 +125,45 @@ def test_encoder_window_maps_match_hf(mocked):
             assert _err(a, b) < 1e-4
     finally:
         SAM_ARCH.pop('tiny-test')
+
+
+def test_mask_stage_with_a_partially_empty_batch(mocked):
+    """RSPrompterAnchorRoIPromptHead.predict_mask (models.py:1511-1550) when one image of the batch has no detections:
+    RoI -> image ids, per-image split of the decoder output and the empty result must line up with the oracle."""
+    import warnings
+    import rsprompter_amd as ra
+    from oracle.anchor import AnchorOracle
+    from rsprompter_amd.default_configs import rsprompter_anchor
+    from rsprompter_amd.structures import InstanceData
+    from rsprompter_amd.synth import synth_metas, synth_state_dict
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = ra.build_model(rsprompter_anchor('base', 10))
+    oracle = AnchorOracle('base', 10)
+    sd = synth_state_dict(oracle, 0)
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(9)
+    B, S = 3, 128                                   # 128 px "images": FPN levels 32, 16, 8, 4 (+2), embedding 8x8
+    metas = synth_metas(B, size=(S, S))
+    x = [torch.randn(B, 256, S // s, S // s, generator=g) for s in (4, 8, 16, 32, 64)]
+    emb = torch.randn(B, 256, S // 16, S // 16, generator=g)
+    # the image-wide PE is one table repeated over the batch (models.py:85-95, 1685), the decoder relies on that
+    ipe = torch.randn(1, 256, S // 16, S // 16, generator=g).repeat(B, 1, 1, 1)
+    dets = []
+    for n in (3, 0, 2):                              # the middle image has no detections
+        xy = torch.rand(n, 2, generator=g) * 60
+        dets.append(dict(bboxes=torch.cat([xy, xy + torch.rand(n, 2, generator=g) * 50 + 8], 1),
+                         scores=torch.rand(n, generator=g), labels=torch.randint(0, 10, (n,), generator=g)))
+    with torch.no_grad():
+        ref, _ = oracle.mask_predict(oracle.add_extra_pe(x), dets, metas, emb, ipe, rescale=True)
+    res = [InstanceData(bboxes=d['bboxes'].clone(), scores=d['scores'].clone(), labels=d['labels'].clone()) for d in dets]
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    rh = model.roi_head
+    out = rh.predict_mask([cl(f) for f in x], metas, res, rescale=True, image_embeddings=cl(emb),
+                          image_positional_embeddings=cl(ipe), pes=rh.extra_pe_tables([cl(f) for f in x]))
+    for o, r, n in zip(out, ref, (3, 0, 2)):
+        assert tuple(o.masks.shape) == (n, S, S) and tuple(r['masks'].shape) == (n, S, S)
+        if n:
+            assert float((o.masks != r['masks']).float().mean()) < 2e-3
+            assert _err(o.bboxes, r['bboxes']) < 1e-4

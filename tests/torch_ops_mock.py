@@ -192,3 +192,35 @@ def pool2(x, mode):
     y = x.permute(0, 3, 1, 2)
     y = F.max_pool2d(y, 2, 2) if mode == 0 else F.max_pool2d(y, 1, stride=2)
     return y.permute(0, 2, 3, 1).contiguous()
+
+
+def roi_align(feats_nhwc, pes, rois, P, strides, finest_scale=56):
+    """SingleRoIExtractor + mmcv RoIAlign through the oracle's C restatement; the extra PE is added to the level
+    before sampling (sampling is linear, so this equals sampling feat + PE)."""
+    from oracle import glue
+    levels = []
+    for i, f in enumerate(feats_nhwc):
+        x = f.permute(0, 3, 1, 2).contiguous()
+        if pes is not None and pes[i] is not None:
+            x = x + pes[i].permute(2, 0, 1).unsqueeze(0)
+        levels.append(x)
+    out = glue.roi_extract(levels, rois, P, strides, finest_scale)        # [K, C, P, P]
+    return out.permute(0, 2, 3, 1).contiguous()
+
+
+def mask_post(low_res, batch_input_shape, crop_hw, out_hw, thr, want_prob=False):
+    """models.py:1746-1784: sigmoid -> bilinear to batch_input_shape -> crop -> bilinear to ori_shape -> >= thr"""
+    k = low_res.shape[0]
+    if k == 0:
+        m = torch.zeros((0, out_hw[0], out_hw[1]), dtype=torch.bool)
+        return (m, torch.zeros((0, out_hw[0], out_hw[1]))) if want_prob else m
+    p = torch.sigmoid(low_res)[:, None]
+    p = F.interpolate(p, size=tuple(batch_input_shape), mode='bilinear', align_corners=False)
+    p = p[..., :crop_hw[0], :crop_hw[1]]
+    p = F.interpolate(p, size=tuple(out_hw), mode='bilinear', align_corners=False)[:, 0]
+    m = p >= thr
+    return (m, p) if want_prob else m
+
+
+def div_boxes(boxes, sf4):
+    return boxes / torch.tensor([float(v) for v in sf4])
