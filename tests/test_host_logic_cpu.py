@@ -19,7 +19,8 @@ def mocked(monkeypatch):
     import rsprompter_amd.necks as necks
     import rsprompter_amd.sam_decoder as sd
     import rsprompter_amd.sam_encoder as se
-    for m in (ah, necks, sd, se):
+    import rsprompter_amd.detectors as det
+    for m in (ah, necks, sd, se, det):
         monkeypatch.setattr(m, 'ops', mock)
     return mock
 
@@ -167,3 +168,35 @@ def test_mask_stage_with_a_partially_empty_batch(mocked):
         if n:
             assert float((o.masks != r['masks']).float().mean()) < 2e-3
             assert _err(o.bboxes, r['bboxes']) < 1e-4
+
+
+def test_anchor_pipeline_end_to_end_host_logic(mocked):
+    """The whole RSPrompterAnchor.test_step on one 1024x1024 tile with every native op replaced by its plain-torch /
+    oracle stand-in: data preprocessor, encoder row maps, neck, RPN selection, RoI heads, prompt generation, SAM
+    decoder wiring, mask post-processing and the InstanceData plumbing against the oracle's predict."""
+    import warnings
+    import rsprompter_amd as ra
+    from _match import match_detections
+    from oracle import glue
+    from oracle.anchor import AnchorOracle
+    from rsprompter_amd.default_configs import rsprompter_anchor
+    from rsprompter_amd.structures import DetDataSample
+    from rsprompter_amd.synth import synth_images, synth_metas, synth_state_dict
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = ra.build_model(rsprompter_anchor('base', 10))
+    oracle = AnchorOracle('base', 10)
+    sd = synth_state_dict(oracle, 0)
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd, strict=True)
+    imgs, metas = synth_images(1), synth_metas(1)
+    x = glue.data_preprocess(imgs, [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], True, 32)
+    ref, _ = oracle.predict(x, metas)
+    out = model.test_step(dict(inputs=imgs, data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
+    pi, r = out[0].pred_instances, ref[0]
+    assert pi.masks.dtype == torch.bool and tuple(pi.masks.shape) == tuple(r['masks'].shape)
+    pairs = match_detections(pi.bboxes, pi.scores, pi.labels, r['bboxes'], r['scores'], r['labels'])
+    ii = torch.tensor([i for i, _ in pairs])
+    jj = torch.tensor([j for _, j in pairs])
+    assert len(pairs) >= r['labels'].shape[0] - 2
+    assert float((pi.masks[ii] != r['masks'][jj]).float().mean()) < 1e-3

@@ -224,3 +224,67 @@ def mask_post(low_res, batch_input_shape, crop_hw, out_hw, thr, want_prob=False)
 
 def div_boxes(boxes, sf4):
     return boxes / torch.tensor([float(v) for v in sf4])
+
+
+def preprocess(imgs, mean, std, swap_rb, pad_divisor=1, pad_value=0.0, device=None):
+    from oracle import glue
+    return glue.data_preprocess(list(imgs), list(mean), list(std), bool(swap_rb), pad_divisor, pad_value)
+
+
+def _padded(rows, max_out, B):
+    """per-image lists of (boxes, scores, ids, src) -> the fixed-shape dict the HIP NMS returns"""
+    out = dict(boxes=torch.zeros(B, max_out, 4), scores=torch.zeros(B, max_out), ids=torch.zeros(B, max_out, dtype=torch.int32),
+               src=torch.zeros(B, max_out, dtype=torch.int32), count=torch.zeros(B, dtype=torch.int32))
+    for b, (bx, sc, ids, src) in enumerate(rows):
+        n = bx.shape[0]
+        out['boxes'][b, :n], out['scores'][b, :n] = bx, sc
+        out['ids'][b, :n], out['src'][b, :n] = ids.to(torch.int32), src.to(torch.int32)
+        out['count'][b] = n
+    return out
+
+
+class RpnSelector:
+    """rpn_head.py:134-304 through the oracle's restatement (pinned on the reference's own code)."""
+
+    def __init__(self, base_anchors, strides, nms_pre, max_per_img, iou_thr, min_bbox_size, max_ratio, device):
+        self.base, self.strides = base_anchors.float(), list(strides)
+        self.A = self.base.shape[1]
+        self.nms_pre, self.max_per_img, self.iou_thr, self.min_bbox_size = nms_pre, max_per_img, iou_thr, min_bbox_size
+
+    def __call__(self, heads, sizes, ld, img_hw):
+        from oracle import glue
+        B, A = img_hw.shape[0], self.A
+        priors = []
+        for lvl, (H, W) in enumerate(sizes):            # anchor_generator.py grid_priors: (y, x, a) order
+            s = self.strides[lvl]
+            sx = torch.arange(W, dtype=torch.float32) * s
+            sy = torch.arange(H, dtype=torch.float32) * s
+            yy, xx = torch.meshgrid(sy, sx, indexing='ij')
+            shifts = torch.stack([xx, yy, xx, yy], -1).reshape(-1, 1, 4)
+            priors.append((shifts + self.base[lvl][None]).reshape(-1, 4))
+        rows = []
+        for b in range(B):
+            cls = [h.view(B, H, W, ld)[b, :, :, :A].permute(2, 0, 1) for h, (H, W) in zip(heads, sizes)]
+            reg = [h.view(B, H, W, ld)[b, :, :, A:5 * A].permute(2, 0, 1) for h, (H, W) in zip(heads, sizes)]
+            r = glue.rpn_predict_single(cls, reg, priors, (int(img_hw[b, 0]), int(img_hw[b, 1])), nms_pre=self.nms_pre,
+                                        max_per_img=self.max_per_img, iou_thr=self.iou_thr,
+                                        min_bbox_size=self.min_bbox_size)
+            rows.append((r['bboxes'], r['scores'], r['level_ids'], r['anchor_index']))
+        return _padded(rows, self.max_per_img, B)
+
+
+def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, max_ratio, iou_thr, max_out):
+    from oracle import glue
+    B, nc = img_hw.shape[0], num_classes
+    rows = []
+    for b in range(B):
+        r0, r1 = int(roi_start[b]), int(roi_start[b + 1])
+        if r1 == r0:
+            rows.append((torch.zeros(0, 4), torch.zeros(0), torch.zeros(0, dtype=torch.long), torch.zeros(0, dtype=torch.long)))
+            continue
+        dets, labels, cand = glue.bbox_head_predict_single(rois[r0:r1], head[r0:r1, :nc + 1].contiguous(),
+                                                           head[r0:r1, nc + 1:5 * nc + 1].contiguous(),
+                                                           (int(img_hw[b, 0]), int(img_hw[b, 1])), nc, score_thr, iou_thr,
+                                                           max_out, stds=tuple(stds))
+        rows.append((dets[:, :4], dets[:, 4], labels, cand))
+    return _padded(rows, max_out, B)
