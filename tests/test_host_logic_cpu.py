@@ -20,7 +20,8 @@ def mocked(monkeypatch):
     import rsprompter_amd.sam_decoder as sd
     import rsprompter_amd.sam_encoder as se
     import rsprompter_amd.detectors as det
-    for m in (ah, necks, sd, se, det):
+    import rsprompter_amd.query_heads as qh
+    for m in (ah, necks, sd, se, det, qh):
         monkeypatch.setattr(m, 'ops', mock)
     return mock
 
@@ -200,3 +201,34 @@ def test_anchor_pipeline_end_to_end_host_logic(mocked):
     jj = torch.tensor([j for _, j in pairs])
     assert len(pairs) >= r['labels'].shape[0] - 2
     assert float((pi.masks[ii] != r['masks'][jj]).float().mean()) < 1e-3
+
+
+def test_query_pipeline_end_to_end_host_logic(mocked):
+    """RSPrompterQuery.test_step on one tile through the stand-ins: MSDeformAttn pixel decoder, masked decoder
+    (attention-mask rule, level cycling), point / class heads, SAM mask embedding + single decoder call, lazily
+    upsampled masks and the fusion head against the oracle's predict."""
+    import warnings
+    import rsprompter_amd as ra
+    from oracle import glue
+    from oracle.query import QueryOracle
+    from rsprompter_amd.default_configs import rsprompter_query
+    from rsprompter_amd.structures import DetDataSample
+    from rsprompter_amd.synth import synth_images, synth_metas, synth_state_dict
+    NQ = 20
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = ra.build_model(rsprompter_query('base', 1, prompt_shape=(NQ, 5), max_per_image=10))
+    oracle = QueryOracle('base', 1, num_queries=NQ, max_per_image=10)
+    sd = synth_state_dict(oracle, 0)
+    oracle.load_state_dict(sd)
+    model.load_state_dict(sd, strict=True)
+    imgs, metas = synth_images(1), synth_metas(1)
+    x = glue.data_preprocess(imgs, [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], True, 32)
+    ref, _ = oracle.predict(x, metas)
+    out = model.test_step(dict(inputs=imgs, data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
+    pi, r = out[0].pred_instances, ref[0]
+    assert tuple(pi.masks.shape) == tuple(r['masks'].shape)
+    same = pi.query_indices.long() == r['query_indices']
+    assert int((~same).sum()) <= 2                      # only exact-tie swaps (see tests/_match.py)
+    assert _err(pi.scores[same], r['scores'][same]) < 1e-4
+    assert float((pi.masks[same] != r['masks'][same]).float().mean()) < 1e-3

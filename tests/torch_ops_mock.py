@@ -130,7 +130,7 @@ def to_planes(x, scale_log2=6):
 
 
 def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v_strides, o_strides,
-              kv_batch_map=None, q_batch_map=None, out_planes=None):
+              kv_batch_map=None, q_batch_map=None, out_planes=None, mask=None):
     if out is None:
         out = out_planes
     def view(t, st, T, bmap):
@@ -140,7 +140,10 @@ def attention(q, k, v, out, *, B, nh, dh, Tq, Tk, scale, q_strides, k_strides, v
             tt = tt[bmap.long()]
         return tt.permute(0, 2, 1, 3)
     qq, kk, vv = view(q, q_strides, Tq, q_batch_map), view(k, k_strides, Tk, kv_batch_map), view(v, v_strides, Tk, kv_batch_map)
-    o = ((qq * scale) @ kk.transpose(-1, -2)).softmax(-1) @ vv
+    sc = (qq * scale) @ kk.transpose(-1, -2)
+    if mask is not None:                                    # [B, Tq, Tk] bytes, non-zero = blocked, all heads
+        sc = sc.masked_fill(mask.view(B, 1, Tq, Tk).bool(), float('-inf'))
+    o = sc.softmax(-1) @ vv
     ov = torch.as_strided(out, (B, Tq, nh, dh), (o_strides[0], o_strides[1], o_strides[2], 1))
     ov.copy_(o.permute(0, 2, 1, 3))
     return out
@@ -288,3 +291,87 @@ def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, m
                                                            max_out, stds=tuple(stds))
         rows.append((dets[:, :4], dets[:, 4], labels, cand))
     return _padded(rows, max_out, B)
+
+
+# ----------------------------------------------------------------------------- query prompter ops
+class PlaneWeight:
+    """rows [r0, r0+n) of an activation used as a GEMM weight (planes are plain fp32 tensors in the mock)"""
+
+    def __init__(self, planes, r0=0, n=None):
+        n = planes.shape[0] - r0 if n is None else n
+        self.w = planes.reshape(planes.shape[0], -1)[r0:r0 + n].float()
+        self.N, self.K = self.w.shape
+        self.bias = None
+        self.scale_log2 = 0
+
+
+def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, add=None):
+    B, C = x.shape[0], x.shape[-1]
+    y = F.group_norm(x.reshape(B, -1, C).transpose(1, 2), groups, gamma, beta, eps).transpose(1, 2).reshape(x.shape)
+    if add is not None:
+        y = y + add
+    return F.relu(y) if relu else y
+
+
+def resize_bilinear(x_nhwc, size):
+    y = F.interpolate(x_nhwc.permute(0, 3, 1, 2), size=tuple(size), mode='bilinear', align_corners=False)
+    return y.permute(0, 2, 3, 1).contiguous()
+
+
+def msdeform_attn(value, offs_weights, ref_points, B, Ntok, level_hw):
+    """mmcv MultiScaleDeformableAttention core (8 heads, 4 points) through the oracle's sampling restatement"""
+    from oracle.query import MSDeformAttn
+    H, L, P = 8, len(level_hw), 4
+    v = value.view(B, Ntok, H, -1)
+    off = offs_weights[:, :H * L * P * 2].reshape(B, Ntok, H, L, P, 2)
+    w = offs_weights[:, H * L * P * 2:H * L * P * 3].reshape(B, Ntok, H, L * P).softmax(-1).view(B, Ntok, H, L, P)
+    shapes = torch.tensor([list(hw) for hw in level_hw])
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+    loc = ref_points[None, :, None, None, None, :] + off / norm[None, None, None, :, None, :]
+    return MSDeformAttn._sample(v, shapes, loc, w).reshape(B * Ntok, -1)
+
+
+def query_attn_mask(mask_pred_plus, size):
+    """models.py:381-392 + :439-442 -> uint8 [B, Nq, h*w], 1 = blocked, fully blocked rows cleared"""
+    am = F.interpolate(mask_pred_plus, tuple(size), mode='bilinear', align_corners=False).flatten(2).sigmoid() < 0.5
+    am = am & (am.sum(-1) != am.shape[-1]).unsqueeze(-1)
+    return am.to(torch.uint8)
+
+
+def sam_mask_embed(mask_pred_plus, emb_rows, roi_img, prm, he, we, eps=1e-6):
+    """SamMaskEmbedding (HF:569-601) on mask_pred_plus + the image embedding of the prompt set's image"""
+    R = mask_pred_plus.shape[0]
+    C = emb_rows.shape[-1]
+
+    def ln2d(x, w, b):
+        return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), w, b, eps).permute(0, 3, 1, 2)
+    x = mask_pred_plus[:, None]
+    x = F.gelu(ln2d(F.conv2d(x, prm['conv1_w'], prm['conv1_b'], stride=2), prm['ln1_w'], prm['ln1_b']))
+    x = F.gelu(ln2d(F.conv2d(x, prm['conv2_w'], prm['conv2_b'], stride=2), prm['ln2_w'], prm['ln2_b']))
+    dense = F.conv2d(x, prm['conv3_w'].view(C, 16, 1, 1), prm['conv3_b'])                 # [R, C, he, we]
+    src = emb_rows.view(-1, he * we, C)[roi_img.long()] + dense.permute(0, 2, 3, 1).reshape(R, he * we, C)
+    return src.reshape(R * he * we, C)
+
+
+def query_topk(cls, k):
+    """softmax[:, :-1] -> top-k over (query, class), canonical order (score desc, flat index asc)"""
+    B = cls.shape[0]
+    sc = cls.softmax(-1)[..., :-1].reshape(B, -1)
+    ranked, order = sc.sort(dim=1, descending=True, stable=True)
+    return ranked[:, :k].contiguous(), order[:, :k].to(torch.int32).contiguous()
+
+
+def query_mask_post(low_res, qidx, cls_score, batch_input_shape, crop_hw, out_hw, want_logits=False):
+    """models.py:652-656 + 684-695 + maskformer_fusion_head.py:164-176 for the selected queries of one image"""
+    from oracle.query import mask2bbox
+    m = low_res[qidx.long()][:, None]
+    m = F.interpolate(m, size=tuple(batch_input_shape), mode='bilinear', align_corners=False)
+    m = m[..., :crop_hw[0], :crop_hw[1]]
+    if tuple(out_hw) != tuple(crop_hw):
+        m = F.interpolate(m, size=tuple(out_hw), mode='bilinear', align_corners=False)
+    m = m[:, 0]
+    binary = (m > 0).float()
+    ms = (m.sigmoid() * binary).flatten(1).sum(1) / (binary.flatten(1).sum(1) + 1e-6)
+    masks = binary.bool()
+    out = (masks, cls_score * ms, mask2bbox(masks))
+    return out + (m,) if want_logits else out
