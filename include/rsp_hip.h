@@ -112,7 +112,9 @@ typedef struct RspGemmDesc {
   const uint16_t* res_hi; const uint16_t* res_lo; int32_t res_scale_log2, res_rows;
   const float* hd_hyper; float* hd_out;
   int32_t hd_rows;    /* GEMM rows per RoI (input pixels of the ConvTranspose)                                */
-  int32_t tile_hint;  /* 0 = auto; 1 = 128x128, 2 = 256x128, 3 = 256x256 block tile (plane path; benchmarking) */
+  int32_t tile_hint;  /* 0 = auto (cost model in gemm_dma.hip).  Benchmarking only: 1/2/3 = plain 128x128 / 256x128 / */
+                      /* 256x256, 11-14 = register-pipelined loops, 17-20 = + DMA spread between the MFMA groups    */
+                      /* (17 = 256x256, 18 = 256x128, 20 = 128x128); other values are tuning probes.                */
 } RspGemmDesc;
 
 int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream);
