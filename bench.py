@@ -6,8 +6,11 @@
 
 A "step" is one pass of the whole hot path (DetDataPreprocessor -> SAM ViT encoder -> RSFPN -> RPN ->
 RoI prompter -> SAM mask decoder -> mask post-process -> result all-gather when N > 1) over one batch of
-synthetic 1024x1024 tiles already resident in HBM.  The workload is BASELINE.json configs[1]:
-rsprompter_anchor, SAM ViT-B, batch 8 x 1024 x 1024 per GPU (weak scaling: every rank runs its own batch).
+synthetic 1024x1024 tiles already resident in HBM.  The default workload is the configuration BASELINE.json's
+metric is quoted on ("images/sec (1024x1024, ViT-H)", configs[3]: rsprompter_anchor, SAM ViT-H, 64 tiles over 8
+GPUs): 8 x 1024 x 1024 per GPU per step, weak scaling (every rank runs its own batch of 8), so N=1 is the per-GPU
+slice of configs[3] and N=8 is configs[3] itself.  `--arch base` gives configs[1], `--model query --arch large
+--batch 16` configs[2].  `python bench.py --gpus N` with N > 1 outside torchrun spawns the N ranks itself.
 Weights are seeded synthetic tensors of the reference architecture (there is no checkpoint / dataset).
 Rank 0 prints ONE JSON line.
 """
@@ -39,35 +42,91 @@ def build_model(arch, num_classes, device, kind='anchor'):
     return model.to(device)
 
 
-def cpu_baseline(arch, num_classes):
-    """The reference path restated on the CPU (oracle/) timed on this box's host cores; bounded sample."""
+def cpu_baseline(arch, num_classes, passes=3):
+    """The reference path restated on the CPU (oracle/), timed on this box's host cores: SAME architecture as the
+    GPU line, 1 warm-up + `passes` timed runs per stage (mmdet/utils/benchmark.py:208-244), one tile.
+    Bounded sample: the ViT encoder is timed as patch-embed + ONE windowed layer + ONE global layer + neck and
+    extrapolated by the layer counts (all windowed / all global layers have identical shapes); every other stage
+    (feature aggregator, FPN, RPN, RoI heads, SAM mask decoder, mask post-process) runs in full."""
     from oracle import glue
     from oracle.anchor import AnchorOracle
+    from oracle import hf_sam
     from rsprompter_amd.synth import synth_images, synth_metas, synth_state_dict
-    o = AnchorOracle(arch, num_classes)
-    o.load_state_dict(synth_state_dict(o, seed=0))
-    n = 1
-    x = glue.data_preprocess(synth_images(n), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], True, 32)
-    t = time.perf_counter()
-    o.predict(x, synth_metas(n))
-    dt = time.perf_counter() - t
-    return dict(value=n / dt, unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'{n} x 1024x1024 tile through the full CPU oracle (fp32 PyTorch, HF SAM eager attention), '
-                       f'single timed pass of {dt:.1f} s, no warm-up')
+
+    def timeit(fn):
+        out = fn()                                   # warm-up
+        ts = []
+        for _ in range(passes):
+            t = time.perf_counter()
+            out = fn()
+            ts.append(time.perf_counter() - t)
+        return sum(ts) / len(ts), out
+
+    with torch.no_grad():
+        o = AnchorOracle(arch, num_classes)
+        o.load_state_dict(synth_state_dict(o, seed=0))
+        enc = o.backbone.vision_encoder
+        cfg = hf_sam.ARCH[arch]
+        depth, glob = cfg['num_hidden_layers'], list(cfg['global_attn_indexes'])
+        win = [i for i in range(depth) if i not in glob]
+        n = 1
+        metas = synth_metas(n)
+        x = glue.data_preprocess(synth_images(n), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], True, 32)
+        first = lambda r: r[0] if isinstance(r, (tuple, list)) else r
+        t_patch, h0 = timeit(lambda: enc.patch_embed(x) + enc.pos_embed)
+        t_win, h1 = timeit(lambda: first(enc.layers[win[0]](h0)))
+        t_glob, h2 = timeit(lambda: first(enc.layers[glob[0]](h1)))
+        t_neck, emb = timeit(lambda: enc.neck(h2))
+        t_enc = t_patch + len(win) * t_win + len(glob) * t_glob + t_neck
+        # downstream stages on hidden states of realistic magnitude (the three tensors above, cycled)
+        hidden = tuple([h0] + [(h1, h2)[i % 2] for i in range(depth)])
+        G = o.shared_image_embedding.shared_image_embedding.positional_embedding
+        ipe = glue.image_wide_positional_embeddings(G, emb.shape[-1]).repeat(emb.shape[0], 1, 1, 1)
+        t_agg, feats = timeit(lambda: o.neck.feature_spliter(o.neck.feature_aggregator(hidden)))
+        t_rpn, (props, _) = timeit(lambda: o.rpn_predict(feats, metas))
+        x_pe = o.add_extra_pe(feats)
+        t_box, (dets, _) = timeit(lambda: o.bbox_predict(x_pe, [p['bboxes'] for p in props], metas))
+        t_mask, _ = timeit(lambda: o.mask_predict(x_pe, dets, metas, emb, ipe))
+        n_det = int(sum(d['bboxes'].shape[0] for d in dets))
+    total = t_enc + t_agg + t_rpn + t_box + t_mask
+    return dict(value=round(n / total, 5), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                stages_s=dict(encoder=round(t_enc, 3), encoder_patch=round(t_patch, 3), encoder_window_layer=round(t_win, 3),
+                              encoder_global_layer=round(t_glob, 3), encoder_neck=round(t_neck, 3),
+                              neck=round(t_agg, 3), rpn=round(t_rpn, 3), bbox_head=round(t_box, 3), mask_head=round(t_mask, 3)),
+                sample=f'1 x 1024x1024 tile, CPU oracle (fp32 PyTorch, HF SAM eager attention), SAM-ViT-{arch}; '
+                       f'1 warm-up + {passes} timed passes per stage; encoder = patch + {len(win)} x windowed layer + '
+                       f'{len(glob)} x global layer + neck from one timed layer of each kind; all other stages in full '
+                       f'({n_det} prompt sets through the SAM decoder)')
 
 
-def _pmc_traffic():
+def _pmc_traffic(arch):
     """HBM bytes per launch of the dominant GEMM from the committed rocprofv3 PMC passes (profiles/r1_pmc/,
     FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes); the counters cannot be collected inside this
-    process, so the number is the one measured with tools/pmc_gemm.sh on the kernel's most frequent shape."""
-    f = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r1_pmc', 'gemm_lin1_traffic.json')
-    try:
-        with open(f) as fh:
-            t = json.load(fh)
-        return {'bytes_per_launch': t['traffic_bytes_per_launch'], 'algorithmic_bytes_per_launch': t['algorithmic_bytes_per_launch'],
-                'shape': t['shape'], 'source': 'profiles/r1_pmc/gemm_lin1_traffic.json'}
-    except Exception:
-        return None
+    process, so the number is the one measured with tools/pmc_round2.sh on the kernel's most expensive shape of this
+    architecture; None when no pass exists for it."""
+    root = os.path.dirname(os.path.abspath(__file__))
+    for rel in (f'profiles/r2_pmc/gemm_traffic_{arch}.json', 'profiles/r1_pmc/gemm_lin1_traffic.json'):
+        try:
+            with open(os.path.join(root, rel)) as fh:
+                t = json.load(fh)
+            if arch != 'base' and rel.startswith('profiles/r1_pmc'):
+                return None                      # that pass was taken on the ViT-B shape only
+            return {'bytes_per_launch': t['traffic_bytes_per_launch'], 'algorithmic_bytes_per_launch': t['algorithmic_bytes_per_launch'],
+                    'shape': t['shape'], 'source': rel}
+        except Exception:
+            continue
+    return None
+
+
+def _config_tag(args, B, world):
+    if args.model == 'anchor' and args.arch == 'huge' and B == 8:
+        return (' (BASELINE.json configs[3]: 64 tiles sharded over 8 GPUs)' if world == 8 else
+                f' (the per-GPU slice of BASELINE.json configs[3] on {world} GPU' + ('s)' if world > 1 else ')'))
+    if args.model == 'anchor' and args.arch == 'base' and B == 8 and world == 1:
+        return ' (BASELINE.json configs[1])'
+    if args.model == 'query' and args.arch == 'large' and B == 16 and world == 1:
+        return ' (BASELINE.json configs[2])'
+    return ''
 
 
 def main():
@@ -75,13 +134,30 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
-    ap.add_argument('--arch', default='base')
+    ap.add_argument('--arch', default='huge', choices=['base', 'large', 'huge'])
     ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     ap.add_argument('--model', default='anchor', choices=['anchor', 'query'],
-                    help="prompter variant; the headline line is 'anchor' (BASELINE.json configs[1])")
+                    help="prompter variant; the headline line is 'anchor' (BASELINE.json configs[3])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shapes', action='store_true', help='break the kernel table down by GEMM/attention shape')
     args = ap.parse_args()
+
+    if not torch.cuda.is_available():
+        raise RuntimeError('bench.py needs an MI355X (no CPU fallback)')
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (one process per GPU, RCCL), same flags
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} requested but only {have} GPU(s) are visible')
+        import socket
+        import subprocess
+        sk = socket.socket()
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     from rsprompter_amd import dist as rdist
     from rsprompter_amd import ops
@@ -91,10 +167,8 @@ def main():
 
     rank, local, world = rdist.init_from_env()
     if world != args.gpus:
-        if rank == 0:
-            print(f'warning: --gpus {args.gpus} but WORLD_SIZE={world}', file=sys.stderr)
-    if not torch.cuda.is_available():
-        raise RuntimeError('bench.py needs an MI355X (no CPU fallback)')
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with '
+                         f'--nproc-per-node {args.gpus} (or run plain `python bench.py --gpus {args.gpus}`)')
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     num_classes = 10 if args.model == 'anchor' else 1
@@ -168,13 +242,13 @@ def main():
             'dtype': 'f32 (fp32 in/out; GEMMs and attention as fp16x3 split-precision MFMA with fp32 accumulate)',
             'data': 'synthetic',
             'config': {'workload': f'rsprompter_{args.model} SAM-ViT-{args.arch}, batch {B}x1024x1024 per GPU, '
-                                   f'{num_classes} classes, seeded synthetic weights' + (' (BASELINE.json configs[1])' if args.model == 'anchor' and args.arch == 'base' and B == 8 else ''),
+                                   f'{num_classes} classes, seeded synthetic weights' + _config_tag(args, B, world),
                        'images_per_gpu_per_step': B, 'detections_per_step_rank0': n_dets,
                        'parallelism': f'dp{world} (images sharded by batch, result all-gather)' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'mfma', 'kernel': dom_name, 'launches_per_step': dom['calls'],
                          'ms_per_step': round(dom['ms'], 3), 'achieved': round(achieved, 2),
                          'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
-                         'traffic': (_pmc_traffic() or {}).get('bytes_per_launch'), 'traffic_detail': _pmc_traffic(),
+                         'traffic': (_pmc_traffic(args.arch) or {}).get('bytes_per_launch'), 'traffic_detail': _pmc_traffic(args.arch),
                          'note': 'achieved = algorithmic fp32 FLOPs (2MNK) of all launches of the kernel in one step / '
                                  'their summed HIP-event durations; the kernel issues 3 fp16 MFMA passes per algorithmic '
                                  'FLOP (fp16x3), so its ceiling is peak/3 = 833 TFLOP/s',

@@ -1,0 +1,271 @@
+"""CPU study of the split-precision budget: which matrix products of the SAM ViT
+encoder tolerate fewer than three fp16 MFMA passes?
+
+Every product x @ w of the encoder is emulated on the CPU in one of four operand precisions
+    x3 : a and b carried as fp16 hi+lo pairs (what the shipped kernels do; ~22 bits, emulated as exact fp32 operands)
+    x2a: a = hi+lo, b = fp16            (a_hi*b_hi + a_lo*b_hi)
+    x2b: a = fp16,  b = hi+lo           (a_hi*b_hi + a_hi*b_lo)
+    x1 : a = fp16,  b = fp16            (one pass)
+with the accumulation done in fp32 as the MFMA does (the products themselves are exact in fp32).  The oracle's
+anchor model runs once in fp32 (reference) and once in fp64 (noise floor of the reference itself); then each policy is
+applied to the encoder only and the rest of the path is evaluated on the ORACLE's detections (fixed RoIs), so that
+`low_res_masks` can be compared element-wise; the free-running detection lists are compared too (how many detections
+move).  TEST/STUDY TOOL: imports oracle/, never imported by the product.
+
+  python tools/precision_budget.py [--arch base] [--images 1] [--policies name=spec,...]
+spec = comma-free string of class:prec pairs joined by '+', classes qkv proj lin1 lin2 qk pv, e.g.
+  "qkv:x1+proj:x1+lin1:x1+lin2:x1+qk:x3+pv:x1"
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from transformers.models.sam import modeling_sam as hf  # noqa: E402
+
+CLASSES = ('qkv', 'proj', 'lin1', 'lin2', 'qk', 'pv', 'dec')
+
+
+def r16(x):
+    """round to fp16 with a power-of-two pre-scale that keeps the tensor out of the subnormal range
+    (the kernels pre-scale activations by 2^6 and weights per tensor)."""
+    amax = float(x.abs().max())
+    if amax == 0.0:
+        return x
+    e = 14 - int(torch.frexp(torch.tensor(amax)).exponent)       # bring amax to [2^13, 2^14)
+    s = 2.0 ** e
+    return (x * s).to(torch.float16).to(x.dtype) / s
+
+
+def r8(x):
+    """round to OCP fp8 e4m3 (4 significant bits) with a power-of-two pre-scale putting amax near 2^7"""
+    amax = float(x.abs().max())
+    if amax == 0.0:
+        return x
+    e = 7 - int(torch.frexp(torch.tensor(amax)).exponent)
+    s = 2.0 ** e
+    return (x * s).to(torch.float8_e4m3fn).to(x.dtype) / s
+
+
+def matmul_f8corr(a, bt):
+    """a @ bt with the main product in fp16 and the two correction products in fp8:
+    a_hi b_hi + fp8(a_lo) fp8(b_hi) + fp8(a_hi) fp8(b_lo)   (candidate scheme: fp16 MFMA + two K=64 fp8 MFMAs)"""
+    ah, bh = r16(a), r16(bt)
+    al, bl = a - ah, bt - bh
+    return ah @ bh + r8(al) @ r8(bh) + r8(ah) @ r8(bl)
+
+
+def opnd(a, b, prec):
+    if prec == 'x3':
+        return a, b
+    if prec == 'x2a':
+        return a, r16(b)
+    if prec == 'x2b':
+        return r16(a), b
+    if prec == 'x1':
+        return r16(a), r16(b)
+    raise ValueError(prec)
+
+
+class Policy(dict):
+    @staticmethod
+    def parse(spec):
+        p = Policy({c: 'x3' for c in CLASSES})
+        if spec:
+            for item in spec.split('+'):
+                c, v = item.split(':')
+                if c == 'all':
+                    for k in CLASSES[:6]:
+                        p[k] = v
+                elif c == 'gemm':
+                    for k in ('qkv', 'proj', 'lin1', 'lin2'):
+                        p[k] = v
+                else:
+                    assert c in CLASSES, c
+                    p[c] = v
+        return p
+
+
+@contextlib.contextmanager
+def encoder_precision(policy):
+    """patch HF:803-831 (SamVisionAttention.forward) and HF:132-143 (SamMLPBlock.forward) with precision-emulating twins"""
+    att_fwd, mlp_fwd = hf.SamVisionAttention.forward, hf.SamMLPBlock.forward
+
+    def lin(x, layer, prec):
+        if prec == 'x3f8':
+            return matmul_f8corr(x, layer.weight.t()) + layer.bias
+        a, w = opnd(x, layer.weight, prec)
+        return F.linear(a, w, layer.bias)
+
+    def attention(self, hidden_states, output_attentions=None):
+        B, H, W, _ = hidden_states.shape
+        nh = self.num_attention_heads
+        qkv = lin(hidden_states, self.qkv, policy['qkv']).reshape(B, H * W, 3, nh, -1).permute(2, 0, 3, 1, 4)
+        q, k, v = qkv.reshape(3, B * nh, H * W, -1).unbind(0)
+        if policy['qk'] == 'x3f8':
+            s = matmul_f8corr(q * self.scale, k.transpose(-2, -1))
+        else:
+            qa, kb = opnd(q * self.scale, k, policy['qk'])
+            s = qa @ kb.transpose(-2, -1)
+        if self.use_rel_pos:
+            rel = self.get_decomposed_rel_pos(q, self.rel_pos_h, self.rel_pos_w, (H, W), (H, W))
+            s = s + rel.reshape_as(s)
+        p = torch.softmax(s, dim=-1, dtype=torch.float32).to(q.dtype)
+        if policy['pv'] == 'x3f8':
+            o = matmul_f8corr(p, v)
+        else:
+            pa, vb = opnd(p, v, policy['pv'])
+            o = pa @ vb
+        o = o.reshape(B, nh, H, W, -1).permute(0, 2, 3, 1, 4).reshape(B, H, W, -1)
+        return lin(o, self.proj, policy['proj']), None
+
+    def mlp(self, x):
+        return lin(self.act(lin(x, self.lin1, policy['lin1'])), self.lin2, policy['lin2'])
+
+    hf.SamVisionAttention.forward, hf.SamMLPBlock.forward = attention, mlp
+    try:
+        yield
+    finally:
+        hf.SamVisionAttention.forward, hf.SamMLPBlock.forward = att_fwd, mlp_fwd
+
+
+@contextlib.contextmanager
+def decoder_precision(prec):
+    """every nn.Linear / ConvTranspose2d of the SAM mask decoder (HF:432-543: two-way transformer projections and
+    MLPs, upscaler, hyper-network and IoU heads) with operands rounded per `prec`; the 10-token attention products
+    stay fp32 (they are exact-fp32 VALU kernels in the HIP path)"""
+    if prec == 'x3':
+        yield
+        return
+    lin, ct = F.linear, F.conv_transpose2d
+
+    def linear(x, w, b=None):
+        a, ww = opnd(x, w, prec)
+        return lin(a, ww, b)
+
+    def conv_t(x, w, b=None, *args, **kw):
+        a, ww = opnd(x, w, prec)
+        return ct(a, ww, b, *args, **kw)
+
+    F.linear, F.conv_transpose2d = linear, conv_t
+    torch.nn.functional.linear, torch.nn.functional.conv_transpose2d = linear, conv_t
+    try:
+        yield
+    finally:
+        F.linear, F.conv_transpose2d = lin, ct
+        torch.nn.functional.linear, torch.nn.functional.conv_transpose2d = lin, ct
+
+
+def count_moves(res, ref, box_tol=1e-2):
+    """detections of `ref` without a same-label, same-box counterpart at the same rank / anywhere"""
+    moved = missing = 0
+    for a, b in zip(res, ref):
+        for j in range(b['bboxes'].shape[0]):
+            d = (a['bboxes'] - b['bboxes'][j]).abs().amax(1) if a['bboxes'].shape[0] else torch.zeros(0)
+            d = torch.where(a['labels'] == b['labels'][j], d, torch.full_like(d, float('inf')))
+            if d.numel() == 0 or float(d.min()) > box_tol:
+                missing += 1
+            elif int(d.argmin()) != j:
+                moved += 1
+    return moved, missing
+
+
+DEFAULT = [
+    ('x3 (shipped)', ''),
+    ('all x1', 'all:x1'),
+    ('all x2a (A split, B fp16)', 'all:x2a'),
+    ('all x2b (A fp16, B split)', 'all:x2b'),
+    ('GEMMs x1, attention x3', 'gemm:x1'),
+    ('GEMMs x2a, attention x3', 'gemm:x2a'),
+    ('only lin1+lin2 x1', 'lin1:x1+lin2:x1'),
+    ('only lin1+lin2 x2a', 'lin1:x2a+lin2:x2a'),
+    ('only qkv+proj x1', 'qkv:x1+proj:x1'),
+    ('only qk x1', 'qk:x1'),
+    ('only pv x1', 'pv:x1'),
+    ('only pv x2b (P fp16, V split)', 'pv:x2b'),
+    ('only pv x2a (P split, V fp16)', 'pv:x2a'),
+    ('qk x1 + pv x1', 'qk:x1+pv:x1'),
+    ('GEMMs fp16 + 2 fp8 correction products, attention x3', 'gemm:x3f8'),
+    ('everything fp16 + 2 fp8 correction products', 'all:x3f8'),
+    ('encoder x3, mask head + SAM decoder x1', 'dec:x1'),
+    ('encoder x3, mask head + SAM decoder x2a (A split, W fp16)', 'dec:x2a'),
+    ('encoder x3, mask head + SAM decoder x2b (A fp16, W split)', 'dec:x2b'),
+]
+
+
+@torch.no_grad()
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--arch', default='base')
+    ap.add_argument('--images', type=int, default=1)
+    ap.add_argument('--policies', default=None)
+    ap.add_argument('--no-fp64', action='store_true')
+    ap.add_argument('--out', default=None)
+    args = ap.parse_args()
+    from oracle import glue
+    from oracle.anchor import AnchorOracle
+    from rsprompter_amd.synth import synth_images, synth_metas, synth_state_dict
+    torch.manual_seed(0)
+    o = AnchorOracle(args.arch, 10)
+    o.load_state_dict(synth_state_dict(o, seed=0))
+    n = args.images
+    x = glue.data_preprocess(synth_images(n), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], True, 32)
+    metas = synth_metas(n)
+    t = time.time()
+    ref, tr = o.predict(x, metas)
+    print(f'fp32 reference: {time.time() - t:.1f} s, {sum(r["bboxes"].shape[0] for r in ref)} detections, '
+          f'emb range {float(tr["image_embeddings"].abs().max()):.2f}, '
+          f'mask-logit range {float(tr["low_res_masks"].abs().max()):.2f}', flush=True)
+
+    def evaluate(model, xin, tag, dec='x3'):
+        # encoder + neck in the precision under study; everything downstream in the fp32 oracle
+        feats, emb, ipe, _ = model.extract_feat(xin)
+        feats, emb, ipe = tuple(f.float() for f in feats), emb.float(), ipe.float()
+        model = o
+        props, _ = model.rpn_predict(feats, metas)
+        x_pe = model.add_extra_pe(feats)
+        dets, t2 = model.bbox_predict(x_pe, [p['bboxes'] for p in props], metas)
+        # mask logits on the REFERENCE's detections (same RoIs on both sides -> element-wise comparable)
+        ref_dets = [dict(bboxes=d['bboxes'].to(emb.dtype), scores=d['scores'].to(emb.dtype), labels=d['labels'])
+                    for d in tr['dets']]
+        with decoder_precision(dec):
+            # point_emb (3 Linear layers in front of the decoder) is excluded: restore F.linear around it is not
+            # possible from here, so `dec` variants include it -- it is part of the mask head either way
+            _, t3 = model.mask_predict(x_pe, ref_dets, metas, emb, ipe)
+        moved, missing = count_moves(dets, tr['dets'])
+        # score drift of the reference's detections under this precision (same RoIs through the bbox head)
+        row = dict(policy=tag,
+                   emb_err=float((emb.float() - tr['image_embeddings']).abs().max()),
+                   fpn_err=max(float((a.float() - b).abs().max()) for a, b in zip(feats, tr['fpn'])),
+                   logit_err=float((t3['low_res_masks'].float() - tr['low_res_masks']).abs().max()),
+                   logit_rms=float((t3['low_res_masks'].float() - tr['low_res_masks']).pow(2).mean().sqrt()),
+                   det_moved=moved, det_missing=missing)
+        print(json.dumps(row), flush=True)
+        return row
+
+    rows = []
+    if not args.no_fp64:
+        o64 = AnchorOracle(args.arch, 10).double()
+        o64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in synth_state_dict(o, seed=0).items()})
+        rows.append(evaluate(o64, x.double(), 'fp64 (noise floor of the fp32 reference)'))
+        del o64
+    pols = DEFAULT if args.policies is None else [tuple(s.split('=')) for s in args.policies.split(',')]
+    for name, spec in pols:
+        pol = Policy.parse(spec)
+        with encoder_precision(pol):
+            rows.append(evaluate(o, x, name, pol['dec']))
+    if args.out:
+        with open(args.out, 'w') as f:
+            json.dump(dict(arch=args.arch, images=n, rows=rows), f, indent=1)
+
+
+if __name__ == '__main__':
+    main()
