@@ -32,10 +32,10 @@ class ConvLN(nn.Module):
     """mmcv ConvModule(conv -> norm, act_cfg=None): bias=False because a norm follows
     (App. B); the norm sub-module of a non-torch norm class is named `norm_layer`."""
 
-    def __init__(self, cin, cout, k, padding=0):
+    def __init__(self, cin, cout, k, padding=0, eps=1e-5):
         super().__init__()
         self.conv = nn.Conv2d(cin, cout, k, padding=padding, bias=False)
-        self.norm_layer = LN2d(cout)
+        self.norm_layer = LN2d(cout, eps)
 
     def forward(self, x):
         return self.norm_layer(self.conv(x))
@@ -91,13 +91,15 @@ class PseudoAggregator(nn.Module):
 
 
 class SimpleFPN(nn.Module):
-    """models.py:1278-1363 with norm_cfg=LN2d, act_cfg=None, num_outs=5."""
+    """models.py:1278-1363 with norm_cfg=LN2d, act_cfg=None, num_outs=5.  The LN2d layers are built through mmcv's
+    `build_norm_layer`, which sets eps=1e-5 when the norm_cfg carries none (mmcv/cnn/bricks/norm.py), overriding
+    LN2d's own default of 1e-6 -- pinned by tests/golden/make_golden_forwards.py, which runs the real class."""
 
     def __init__(self, backbone_channel=256, in_channels=(64, 128, 256, 256), out_channels=256, num_outs=5):
         super().__init__()
         c = backbone_channel
         self.num_ins, self.num_outs = len(in_channels), num_outs
-        self.fpn1 = nn.Sequential(nn.ConvTranspose2d(c, c // 2, 2, 2), LN2d(c // 2), nn.GELU(),
+        self.fpn1 = nn.Sequential(nn.ConvTranspose2d(c, c // 2, 2, 2), LN2d(c // 2, 1e-5), nn.GELU(),
                                   nn.ConvTranspose2d(c // 2, c // 4, 2, 2))
         self.fpn2 = nn.Sequential(nn.ConvTranspose2d(c, c // 2, 2, 2))
         self.fpn3 = nn.Sequential(nn.Identity())

@@ -34,8 +34,17 @@ def vision_config(arch, **extra):
     return cfg
 
 
-def build_vision_encoder(arch, **extra):
+def build_vision_encoder(arch, lora=None, **extra):
+    """lora=dict(r=16, alpha=32): every `attn.qkv` becomes peft's eval-mode LoRA Linear and the encoder is wrapped the way
+    `get_peft_model` wraps it (models.py:785-797), so the state_dict carries peft 0.8.2's key layout
+    (`base_model.model.layers.N.attn.qkv.{base_layer,lora_A.default,lora_B.default}`)."""
     m = hf.SamVisionEncoder(vision_config(arch, **extra))
+    if lora:
+        from .vitsam import LoraLinear, PeftWrapped
+        for layer in m.layers:
+            q = layer.attn.qkv
+            layer.attn.qkv = LoraLinear(q.in_features, q.out_features, lora.get('r', 16), lora.get('alpha', 32))
+        m = PeftWrapped(m)
     return m.eval()
 
 
@@ -56,5 +65,7 @@ def build_mask_embedding():
 @torch.no_grad()
 def run_vision_encoder(model, pixel_values):
     """returns (image_embeddings [B,256,g,g], hidden_states tuple of L+1 [B,g,g,D])."""
-    out = model(pixel_values, output_hidden_states=True)
+    from .vitsam import PeftWrapped
+    inner = model.base_model.model if isinstance(model, PeftWrapped) else model      # peft wrapper (lora=...)
+    out = inner(pixel_values, output_hidden_states=True)
     return out.last_hidden_state, tuple(out.hidden_states)

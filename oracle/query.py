@@ -237,7 +237,8 @@ class QueryHead(nn.Module):
         qf = self.query_feat.weight.unsqueeze(0).repeat((bs, 1, 1))
         qe = self.query_embed.weight.unsqueeze(0).repeat((bs, 1, 1))
         trace = dict(mask_features=mask_features, memory=mem, attn_masks=[], query_feats=[qf])
-        _, _, attn_mask, mpp, _ = self._forward_head(qf, mask_features, mem[0].shape[-2:], emb, ipe, False)
+        cls, _, attn_mask, mpp, _ = self._forward_head(qf, mask_features, mem[0].shape[-2:], emb, ipe, False)
+        trace.update(cls_pred_all=[cls], mask_pred_plus_all=[mpp])
         for i in range(6):
             lvl = i % 3
             attn_mask = attn_mask & (attn_mask.sum(-1) != attn_mask.shape[-1]).unsqueeze(-1)   # models.py:439-442
@@ -246,6 +247,8 @@ class QueryHead(nn.Module):
             trace['query_feats'].append(qf)
             cls, mask, attn_mask, mpp, sparse = self._forward_head(
                 qf, mask_features, mem[(i + 1) % 3].shape[-2:], emb, ipe, run_sam=(i == 5))
+            trace['cls_pred_all'].append(cls)
+            trace['mask_pred_plus_all'].append(mpp)
         trace.update(cls_pred=cls, mask_pred=mask, mask_pred_plus=mpp, sparse_embeddings=sparse)
         return cls, mask, trace
 
@@ -300,21 +303,29 @@ def fusion_predict(mask_cls_results, mask_pred_results, metas, num_classes, max_
 class QueryOracle(nn.Module):
     """RSPrompterQuery predict path, configs/rsprompter/_base_/rsprompter_query.py."""
 
-    def __init__(self, arch='base', num_classes=1, num_queries=100, select_layers=None, max_per_image=100):
+    def __init__(self, arch='base', num_classes=1, num_queries=100, select_layers=None, max_per_image=100, lora=None,
+                 peft512=False):
+        """lora=dict(r, alpha): RSSamVisionEncoder(peft_config=...) (models.py:785-797; BASELINE.json configs[4]);
+        peft512=True: the rsprompter_query-nwpu-peft-512.py tree (ViTSAM at 512 px + LoRA + PseudoFeatureAggregator)."""
         super().__init__()
         depth = hf_sam.ARCH[arch]['num_hidden_layers']
         select_layers = list(select_layers) if select_layers is not None else list(range(1, depth + 1, 2))
-        self.num_classes, self.max_per_image = num_classes, max_per_image
-        self.backbone = _Wrap('vision_encoder', hf_sam.build_vision_encoder(arch))
+        self.num_classes, self.max_per_image, self.peft512 = num_classes, max_per_image, peft512
         self.shared_image_embedding = _Wrap('shared_image_embedding', hf_sam.build_positional_embedding(arch))
         self.neck = nn.Module()
-        self.neck.feature_aggregator = FeatureAggregator(arch, 32, 256, select_layers)
+        if peft512:
+            from .anchor import PseudoAggregator
+            from .vitsam import PeftWrapped, ViTSAM
+            self.backbone = _Wrap('vision_encoder', PeftWrapped(ViTSAM(arch, 512, lora=True)))
+            self.neck.feature_aggregator = PseudoAggregator(256, 512, 256)
+        else:
+            self.backbone = _Wrap('vision_encoder', hf_sam.build_vision_encoder(arch, lora=lora))
+            self.neck.feature_aggregator = FeatureAggregator(arch, 32, 256, select_layers)
         self.neck.feature_spliter = SimpleFPN()
         self.panoptic_head = QueryHead(num_classes, num_queries)
         self.eval()
 
     extract_feat = AnchorOracle.extract_feat
-    peft512 = False
 
     @torch.no_grad()
     def predict(self, batch_inputs, metas, rescale=True):

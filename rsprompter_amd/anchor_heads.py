@@ -529,6 +529,24 @@ class RSPrompterAnchorRoIPromptHead(HIPModule):
         return self.mask_head.predict_by_feat(mask_preds, results_list, batch_img_metas, self.test_cfg,
                                               rescale=rescale)
 
+    def forward(self, x, rpn_results_list, batch_data_samples=None, image_embeddings=None,
+                image_positional_embeddings=None):
+        """StandardRoIHead.forward (standard_roi_head.py:60-92): raw `(cls_score, bbox_pred, mask_preds)` over the
+        proposals of the whole batch, mask branch on the first 100 RoIs, with the extra PE of models.py:1566-1574 and
+        the image embeddings the RSPrompter mask head needs (see RSPrompterAnchor._forward)."""
+        pes = self.extra_pe_tables(x)
+        rois = self._rois([r.bboxes for r in rpn_results_list])
+        results = ()
+        if self.with_bbox:
+            n = self.bbox_roi_extractor.num_inputs
+            feats = self.bbox_roi_extractor(x[:n], rois, pes=None if pes is None else pes[:n])
+            cls_score, bbox_pred = self.bbox_head(feats)
+            results = results + (cls_score, bbox_pred)
+        if self.with_mask:
+            mr = self._mask_forward(x, rois[:100].contiguous(), image_embeddings, image_positional_embeddings, pes)
+            results = results + (mr['mask_preds'],)
+        return results
+
     def predict(self, x, rpn_results_list, batch_data_samples, rescale=False, image_embeddings=None,
                 image_positional_embeddings=None):
         """models.py:1553-1593."""

@@ -142,3 +142,30 @@ def rsprompter_query(arch='base', num_classes=1, prompt_shape=(100, 5), pretrain
         test_cfg=dict(panoptic_on=False, semantic_on=False, instance_on=True,
                       max_per_image=prompt_shape[0] if max_per_image is None else max_per_image, iou_thr=0.8,
                       filter_low_score=True))
+
+
+LORA_QKV = dict(peft_type='LORA', r=16, target_modules=['qkv'], lora_alpha=32, lora_dropout=0.05, bias='none')
+
+
+def rsprompter_query_lora(arch='huge', num_classes=1, prompt_shape=(100, 5), pretrain_name=None, ckpt=None,
+                          max_per_image=None):
+    """BASELINE.json configs[4]: the query tree with LoRA(qkv, r16, alpha32) on the 1024-px HF encoder
+    (RSSamVisionEncoder's `peft_config`, models.py:776-797)."""
+    m = rsprompter_query(arch, num_classes, prompt_shape, pretrain_name, ckpt, max_per_image)
+    m['backbone'] = dict(m['backbone'], peft_config=dict(LORA_QKV))
+    return m
+
+
+def rsprompter_query_peft512(arch='base', num_classes=10, prompt_shape=(70, 5), pretrain_name=None, ckpt=None):
+    """configs/rsprompter/rsprompter_query-nwpu-peft-512.py: ViTSAM at 512 px + LoRA(qkv) + PseudoFeatureAggregator."""
+    m = rsprompter_query(arch, num_classes, prompt_shape, pretrain_name, ckpt)
+    name = pretrain_name or f'work_dirs/sam_cache/sam_vit_{arch}'
+    init = dict(type='Pretrained', checkpoint=ckpt or f'{name}/pytorch_model.bin')
+    crop = (512, 512)
+    m['data_preprocessor'] = dict(m['data_preprocessor'])
+    m['data_preprocessor']['batch_augments'] = [dict(m['data_preprocessor']['batch_augments'][0], size=crop)]
+    m['backbone'] = dict(type='MMPretrainSamVisionEncoder', hf_pretrain_name=name, img_size=crop[0], init_cfg=init,
+                         peft_config=dict(LORA_QKV))
+    m['neck'] = dict(m['neck'], feature_aggregator=dict(type='PseudoFeatureAggregator', in_channels=256,
+                                                        hidden_channels=512, out_channels=256))
+    return m

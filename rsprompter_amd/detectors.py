@@ -135,6 +135,7 @@ class RSPrompterAnchor(BaseDetectorHIP):
     def predict(self, batch_inputs, batch_data_samples, rescale=True):
         """models.py:148-170."""
         x, image_embeddings, image_positional_embeddings = self.extract_feat(batch_inputs)
+        self._last_embeddings = image_embeddings       # kept by reference for the parity tests (no copy)
         if batch_data_samples[0].get('proposals', None) is None:
             rpn_results_list = self.rpn_head.predict(x, batch_data_samples, rescale=False)
         else:
@@ -144,5 +145,27 @@ class RSPrompterAnchor(BaseDetectorHIP):
                                              image_positional_embeddings=image_positional_embeddings)
         return self.add_pred_to_datasample(batch_data_samples, results_list)
 
+    @torch.no_grad()
     def _forward(self, batch_inputs, batch_data_samples=None):
-        raise NotImplementedError("mode='tensor' is not on the inference hot path")
+        """`mode='tensor'`: TwoStageDetector._forward (two_stage.py:115-145) -> StandardRoIHead.forward
+        (standard_roi_head.py:60-92): raw head outputs without post-processing, `(cls_score, bbox_pred, mask_preds)` over
+        the RPN proposals of the whole batch, masks for the first 100 RoIs.
+        Reference quirk (not reproduced): RSPrompterAnchor.extract_feat returns a 3-tuple (models.py:97-114) which the
+        inherited `_forward` hands to the RPN as if it were the feature pyramid, and `_mask_forward` is called without
+        the image embeddings -- the reference's own tensor mode raises.  This is the evident intent of those lines with
+        the tuple unpacked and the embeddings passed on."""
+        x, image_embeddings, image_positional_embeddings = self.extract_feat(batch_inputs)
+        if self.with_rpn:
+            samples = batch_data_samples
+            if samples is None:       # `tensor` mode is also what FLOP counters call, without data samples
+                shape = tuple(batch_inputs.shape[-2:])
+                samples = [DetDataSample(metainfo=dict(img_shape=shape, batch_input_shape=shape, pad_shape=shape,
+                                                       ori_shape=shape, scale_factor=(1.0, 1.0)))
+                           for _ in range(batch_inputs.shape[0])]
+            rpn_results_list = self.rpn_head.predict(x, samples, rescale=False)
+        else:
+            assert batch_data_samples[0].get('proposals', None) is not None
+            rpn_results_list = [s.proposals for s in batch_data_samples]
+        roi_outs = self.roi_head.forward(x, rpn_results_list, batch_data_samples, image_embeddings=image_embeddings,
+                                         image_positional_embeddings=image_positional_embeddings)
+        return (roi_outs,)

@@ -198,6 +198,10 @@ class RSSimpleFPN(HIPModule):
         super().__init__()
         assert isinstance(in_channels, (list, tuple))
         c = backbone_channel
+        # every norm here is built by mmcv `build_norm_layer(norm_cfg, ...)` (models.py:1299, ConvModule :1311-1327), which
+        # fills in `eps=1e-5` when the cfg has none (mmcv/cnn/bricks/norm.py: `cfg_.setdefault('eps', 1e-5)`) -- so these
+        # LN2d layers do NOT run with LN2d's own default of 1e-6 (models.py:38).  SURVEY App. D-style quirk: reproduced.
+        self.norm_eps = float((norm_cfg or {}).get('eps', 1e-5))
         self.backbone_channel, self.in_channels = c, list(in_channels)
         self.out_channels, self.num_ins, self.num_outs = out_channels, len(in_channels), num_outs
         add_param(self, 'fpn1.0.weight', (c, c // 2, 2, 2))
@@ -238,7 +242,7 @@ class RSSimpleFPN(HIPModule):
         # intermediates that only feed GEMMs travel as fp16 planes (no fp32 copy, no separate split pass)
         xp = ops.to_planes(x.contiguous())
         t = ops.conv_transpose2x2(xp, *P['t1a'])
-        t = ops.layernorm(t, ln.weight, ln.bias, 1e-6, act=ops.ACT_GELU, planes=True, f32=False)   # models.py:1299-1300
+        t = ops.layernorm(t, ln.weight, ln.bias, self.norm_eps, act=ops.ACT_GELU, planes=True, f32=False)   # models.py:1299-1300
         f1 = ops.conv_transpose2x2(t, *P['t1b'], out_planes=True)
         f2 = ops.conv_transpose2x2(xp, *P['t2'], out_planes=True)
         f4 = ops.pool2(x, 0)
@@ -249,9 +253,9 @@ class RSSimpleFPN(HIPModule):
             b, h, w, ci = xi.shape
             ll, lo = _g(self, f'lateral_convs.{i}.norm_layer'), _g(self, f'fpn_convs.{i}.norm_layer')
             y = ops.gemm(xi.view(b * h * w, ci), P['lat'][i], bias=None)
-            y = ops.layernorm(y, ll.weight, ll.bias, 1e-6, planes=True, f32=False)
+            y = ops.layernorm(y, ll.weight, ll.bias, self.norm_eps, planes=True, f32=False)
             y = ops.gemm(y.view(b, h, w, self.out_channels), P['out'][i], bias=None, conv=(3, 1, 1))
-            y = ops.layernorm(y, lo.weight, lo.bias, 1e-6)
+            y = ops.layernorm(y, lo.weight, lo.bias, self.norm_eps)
             outs.append(y.view(b, h, w, self.out_channels))
         for _ in range(self.num_outs - self.num_ins):
             outs.append(ops.pool2(outs[-1], 1))   # F.max_pool2d(x, 1, stride=2) == subsampling (models.py:1362)

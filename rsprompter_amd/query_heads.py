@@ -476,11 +476,21 @@ class RSPrompterQuery(BaseDetectorHIP):
         x, emb, pe = self.extract_feat(batch_inputs)
         cls, masks = self.panoptic_head.predict(x, batch_data_samples, image_embeddings=emb,
                                                 image_positional_embeddings=pe)
+        self._last_head_out = (cls, masks)             # kept by reference for the parity tests (no copy)
         results = self.panoptic_fusion_head.predict(cls, masks, batch_data_samples, rescale=rescale)
         for s, r in zip(batch_data_samples, results):       # maskformer.py:112-152
             if 'ins_results' in r:
                 s.pred_instances = r['ins_results']
         return batch_data_samples
 
+    @torch.no_grad()
     def _forward(self, batch_inputs, batch_data_samples=None):
-        raise NotImplementedError("mode='tensor' is not on the inference hot path")
+        """`mode='tensor'`: MaskFormer._forward (maskformer.py:153-170) -> panoptic_head.forward: raw head outputs
+        `(cls_pred_list, mask_pred_list)` without post-processing.  The lists hold the LAST decoder stage only: the
+        reference's forward also returns the 7 intermediate SAM-decoder results (models.py:432,456-463), which only
+        the training losses read and which the single-call inference schedule does not compute.
+        Reference quirk (not reproduced): the inherited `_forward` passes extract_feat's 3-tuple to the head as the
+        feature pyramid and no image embeddings, so the reference's own tensor mode raises."""
+        x, emb, pe = self.extract_feat(batch_inputs)
+        cls, mask_pred, trace = self.panoptic_head(x, batch_data_samples, emb, pe)
+        return [cls], [mask_pred], [trace['mask_pred_plus']]

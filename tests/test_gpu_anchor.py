@@ -238,3 +238,22 @@ def test_peft512_variant_end_to_end(dev):
         mism = float((pi.masks.cpu()[ii] != r['masks'][jj]).float().mean())
         print(f'peft512 img {b}: {pi.labels.shape[0]} dets, {len(pairs)} matched, mask mismatch {mism:.2e}')
         assert mism < 1e-3
+
+
+def test_tensor_mode_returns_raw_head_outputs(setup, dev):
+    """`forward(mode='tensor')` (base.py:58-99 -> two_stage.py:115-145 -> standard_roi_head.py:60-92): raw
+    (cls_score, bbox_pred, mask_preds) over the RPN proposals, no post-processing.  Free-running, so rows are compared
+    with the oracle's where the proposal lists coincide (they do except at exact score ties)."""
+    from rsprompter_amd.structures import DetDataSample
+    m, tr = setup['model'], setup['trace']
+    samples = [DetDataSample(metainfo=dict(mm)) for mm in setup['metas']]
+    (roi_outs,) = m(setup['x'].to(dev), samples, mode='tensor')
+    cls, reg, masks = roi_outs
+    assert cls.shape == tr['cls_score'].shape and reg.shape == tr['bbox_pred'].shape
+    assert tuple(masks.shape) == (100, 1, 256, 256)
+    row_err = (cls.cpu() - tr['cls_score']).abs().amax(1)
+    frac = float((row_err < 1e-3).float().mean())
+    print(f'tensor mode: {frac:.4f} of the {cls.shape[0]} proposal rows equal the oracle\'s within 1e-3')
+    assert frac > 0.99
+    with pytest.raises(NotImplementedError):
+        m(setup['x'].to(dev), samples, mode='loss')

@@ -194,3 +194,14 @@ def test_fusion_head_rescale_paths(dev):
         mism = float((res.masks.cpu() != ref['masks']).float().mean())
         assert mism < 1e-5, mism
         assert float((res.bboxes.cpu() - ref['bboxes']).abs().max()) <= 1.0       # a flipped boundary pixel moves a box edge by 1
+
+
+def test_tensor_mode_returns_raw_head_outputs(setup, dev):
+    """`forward(mode='tensor')` (maskformer.py:153-170): raw head outputs of the last decoder stage."""
+    from rsprompter_amd.structures import DetDataSample
+    m, tr = setup['model'], setup['trace']
+    samples = [DetDataSample(metainfo=dict(mm)) for mm in setup['metas']]
+    cls_list, mask_list, mpp_list = m(setup['x'].to(dev), samples, mode='tensor')
+    assert len(cls_list) == len(mask_list) == 1
+    assert _maxerr(cls_list[0], tr['cls_pred']) < 1e-3 and _maxerr(mask_list[0], tr['mask_pred']) < 1e-3
+    assert _maxerr(mpp_list[0], tr['mask_pred_plus']) < 2e-3

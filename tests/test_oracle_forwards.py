@@ -1,0 +1,120 @@
+"""CPU: the oracle's module forwards against the REAL reference classes executed in the build container
+(tests/golden/make_golden_forwards.py -> golden/reference_vectors_forwards.pt): RSSimpleFPN, PseudoFeatureAggregator
+(+ RSFPN), RSPrompterAnchorMaskHead, RSMask2FormerHead (incl. MSDeformAttnPixelDecoder and the Mask2Former decoder
+layers) and ViTSAM.  Weights and inputs are pure functions of (seed, key, shape) on both sides, so each test also pins
+the oracle's `state_dict` key layout (names AND shapes AND order) to the real class's."""
+import os
+
+import pytest
+import torch
+from torch import nn
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'reference_vectors_forwards.pt')
+TOL = 2e-5          # fp32 re-association noise between two CPU evaluations of the same network
+
+
+@pytest.fixture(scope='module')
+def gold():
+    return torch.load(GOLD, weights_only=False)
+
+
+def rnd(spec):
+    seed, shape = spec
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def load(m, g):
+    from rsprompter_amd.synth import synth_state_dict
+    got = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    assert sorted(got) == sorted(g['keys']), (set(got) ^ set(g['keys']))
+    m.load_state_dict(synth_state_dict(m, g['seed']), strict=True)
+    return m.eval()
+
+
+def err(a, b):
+    return float((a - b).abs().max())
+
+
+@torch.no_grad()
+def test_simple_fpn_matches_real_class(gold):
+    from oracle.anchor import SimpleFPN
+    g = gold['simple_fpn']
+    assert g['eps'] == [1e-5, 1e-5, 1e-5]      # mmcv build_norm_layer's eps default reaches LN2d (not LN2d's own 1e-6)
+    m = load(SimpleFPN(), g)
+    outs = m(rnd(g['x']))
+    assert len(outs) == len(g['outs']) == 5
+    for a, b in zip(outs, g['outs']):
+        assert a[:, ::8].shape == b.shape and err(a[:, ::8], b) < TOL
+
+
+@torch.no_grad()
+def test_pseudo_aggregator_neck_matches_real_class(gold):
+    from oracle.anchor import PseudoAggregator, SimpleFPN
+    g = gold['pseudo_neck']
+    neck = nn.Module()
+    neck.feature_aggregator, neck.feature_spliter = PseudoAggregator(256, 512, 256), SimpleFPN()
+    load(neck, g)
+    x = rnd(g['x'])
+    agg = neck.feature_aggregator((x,))
+    assert err(agg, g['agg']) < TOL
+    for a, b in zip(neck.feature_spliter(agg), g['outs']):
+        assert err(a[:, ::8], b) < TOL
+
+
+@torch.no_grad()
+def test_anchor_mask_head_matches_real_class(gold):
+    from oracle.anchor import MaskHead
+    g = gold['anchor_mask_head']
+    m = load(MaskHead(), g)
+    emb = rnd(g['emb'])
+    pe = rnd(g['pe']).repeat(emb.shape[0], 1, 1, 1)
+    low, iou, _ = m(rnd(g['feats']), emb, pe, g['roi_img'])
+    assert low.shape == g['low_res_masks'].shape
+    assert err(low, g['low_res_masks']) < 1e-4 and err(iou, g['iou']) < 1e-4
+
+
+@torch.no_grad()
+def test_query_head_matches_real_class(gold):
+    from oracle.query import QueryHead
+    g = gold['query_head']
+    m = load(QueryHead(g['num_classes'], g['num_queries']), g)
+    xs = [rnd(s) for s in g['xs']]
+    emb = rnd(g['emb'])
+    pe = rnd(g['pe']).repeat(g['batch'], 1, 1, 1)
+    # pixel decoder (msdeformattn_pixel_decoder.py:144-246)
+    mf, mem = m.pixel_decoder(xs)
+    assert err(mf[:, ::4, ::4, ::4], g['mask_features']) < 1e-4
+    for a, b in zip(mem, g['memories']):
+        assert err(a[:, ::2], b) < 1e-4
+    # the whole head: all 7 class predictions and auxiliary masks, the last SAM-decoder result
+    cls, mask, tr = m(xs, emb, pe)
+    assert len(tr['cls_pred_all']) == len(g['cls_pred_all']) == 7
+    for a, b in zip(tr['cls_pred_all'], g['cls_pred_all']):
+        assert err(a, b) < 1e-4
+    for a, b in zip(tr['mask_pred_plus_all'], g['mask_pred_plus_all']):
+        assert err(a[:, :, ::4, ::4], b) < 2e-4
+    assert err(cls, g['cls_pred']) < 1e-4
+    assert err(mask[:, :, ::2, ::2], g['mask_pred']) < 2e-4
+    assert err(tr['mask_pred_plus'][:, :, ::2, ::2], g['mask_pred_plus']) < 2e-4
+    # the FIRST `_forward_head` call's SAM result (the oracle skips it at inference: models.py:644-646 only reads the last)
+    qf = m.query_feat.weight.unsqueeze(0).repeat((g['batch'], 1, 1))
+    _, first, _, _, _ = m._forward_head(qf, mf, mem[0].shape[-2:], emb, pe, True)
+    assert err(first[:, :, ::4, ::4], g['mask_pred_first']) < 2e-4
+    # one decoder layer on its own (mask2former_layers.py:73-135)
+    d = g['dec_layer']
+    lay = m.transformer_decoder.layers[d['index']]
+    kv = rnd(d['kv'])
+    mask_b = rnd(d['mask']) < 0.0
+    mask_b[:, :, 0] = False
+    out = lay(rnd(d['q']), kv, kv, rnd(d['qpos']), rnd(d['kpos']), mask_b)
+    assert err(out, d['out']) < 1e-4
+
+
+@torch.no_grad()
+def test_vitsam_forward_matches_real_class(gold):
+    from oracle.vitsam import ViTSAM
+    g = gold['vitsam']
+    m = load(ViTSAM('base', g['img_size'], lora=False), g)
+    y = m(rnd(g['x']))
+    assert isinstance(y, tuple) and len(y) == 1
+    assert err(y[0][:, ::2], g['out']) < 1e-4
