@@ -177,15 +177,26 @@ def main():
     imgs = [im.to(dev) for im in synth_images(B, seed=1234 + 1000 * rank)]
     metas = synth_metas(B)
 
+    # N > 1: the result exchange (records + COCO RLE of every instance, rsprompter_amd/dist.py::gather_results) of
+    # step i is queued on a side stream and finished on the host after step i + 1 has been launched, so the collective
+    # overlaps the next step's kernels; every exchange is collected inside the timed region (sync() drains the last).
+    side = torch.cuda.Stream(device=dev) if world > 1 else None
+    pending = [None]
+
     def step():
         samples = [DetDataSample(metainfo=dict(m)) for m in metas]
         out = model.test_step(dict(inputs=imgs, data_samples=samples))
         res = [o.pred_instances for o in out]
         if world > 1:
-            rdist.all_gather_results(res)
+            if pending[0] is not None:
+                pending[0].collect()
+            pending[0] = rdist.gather_results(res, dataset_size=world * B, stream=side)
         return res
 
     def sync():
+        if pending[0] is not None:
+            pending[0].collect()
+            pending[0] = None
         if world > 1:
             tdist.barrier()
         torch.cuda.synchronize()
@@ -203,6 +214,7 @@ def main():
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         elapsed = float(t.item())
     n_dets = sum(len(r.bboxes) for r in step())
+    sync()
 
     result = None
     # ---- roofline leg: one extra instrumented step, per-kernel HIP events on the launch stream.  Every rank runs
@@ -212,6 +224,7 @@ def main():
         prof.shapes = args.shapes
         ops.set_profiler(prof)
     step()
+    sync()
     ops.set_profiler(None)
     if rank == 0:
         agg = prof.summary()

@@ -329,6 +329,16 @@ int rsp_preprocess(const void* src, int32_t src_is_u8, float* dst, int32_t H, in
                    int32_t Hp, int32_t Wp, const float* mean3, const float* std3,
                    int32_t swap_rb, float pad_value, rsp_stream_t stream);
 
+/* Test-pipeline front end: `Resize(scale, keep_ratio=True)` + `Pad(size, pad_val)`                       */
+/* (configs/rsprompter/_base_/rsprompter_anchor.py:231-241; mmdet/datasets/transforms/transforms.py:134-247 */
+/* and :704-786 over mmcv.imrescale / cv2.resize INTER_LINEAR and mmcv.impad), optionally fused with the     */
+/* DetDataPreprocessor arithmetic (data_preprocessor.py:110-149).  src: one decoded HWC image (uint8 or      */
+/* fp32, 3 interleaved channels); dst: [3, Hp, Wp] fp32; (Hn, Wn) = resized size inside the padded canvas.   */
+/* pad3 / mean3 / std3 are HOST pointers.                                                                    */
+int rsp_resize_pad(const void* src, int32_t src_is_u8, float* dst, int32_t H, int32_t W, int32_t Hn, int32_t Wn,
+                   int32_t Hp, int32_t Wp, const float* pad3, int32_t normalise, int32_t swap_rb,
+                   const float* mean3, const float* std3, rsp_stream_t stream);
+
 /* im2col of the 16x16/s16 patch-embedding conv (HF:116-128): NCHW image ->   */
 /* [B*gh*gw, C*p*p] rows, k = (c, ky, kx) (the conv weight's own flattening). */
 int rsp_patchify(const float* img, float* out, int32_t B, int32_t C, int32_t H, int32_t W,

@@ -94,6 +94,9 @@ PROTOTYPES = {
     "rsp_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rsp_preprocess": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_float, c_void_p]),
+    "rsp_resize_pad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                               ctypes.POINTER(c_float), c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
+                               c_void_p]),
     "rsp_patchify": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rsp_attention": (c_int, [ctypes.POINTER(RspAttnDesc), c_void_p]),
     "rsp_mask_rle": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
@@ -146,6 +149,19 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m rsprompter_amd.build` "
             "(hipcc --offload-arch=gfx950). There is no fallback path.")
+    # a library left over from older sources would be loaded silently and its struct layouts (RspGemmDesc, ...) would
+    # no longer match this file: compare the source digest recorded at build time; rebuild when hipcc is here, else fail
+    from . import build as _build
+    try:
+        stale = (not os.path.exists(_build.STAMP)) or open(_build.STAMP).read().strip() != _build._digest()
+    except OSError:
+        stale = True
+    if stale:
+        if os.path.exists(_build.HIPCC) and os.access(os.path.dirname(LIB_PATH), os.W_OK):
+            _build.build(verbose=False)
+        else:
+            raise RuntimeError(f"{LIB_PATH} was built from different sources than the ones in this tree "
+                               "(digest mismatch) and hipcc is not available to rebuild it")
     lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

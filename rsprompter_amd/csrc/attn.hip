@@ -375,7 +375,7 @@ __global__ __launch_bounds__(448) void attn_window_kernel(const AttnP p) {
   constexpr int DSTEPS = DH / 16;
   constexpr int DBLK = (DH + 31) / 32;
   constexpr int K_LD = DH + 8;                 // halves per K row
-  constexpr int V_LD = KP + 4;                 // halves per V^T row (114 dwords: conflict-free b64 reads)
+  constexpr int V_LD = KP + 8;                 // halves per V^T row: 464 B = 29 x 16 (16-byte aligned, conflict-free b128 reads)
   constexpr int DCH = DH / 4;
   extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
   half_t* sK0 = reinterpret_cast<half_t*>(wsm);            // [KP][K_LD] hi
@@ -424,7 +424,10 @@ __global__ __launch_bounds__(448) void attn_window_kernel(const AttnP p) {
         half4_t hi, lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) { half_t a, b; rsp_split1(vr[j][c] * vs, a, b); hi[j] = a; lo[j] = b; }
-        const int off = (dc * 4 + c) * V_LD + kg * 4;
+        // key order inside every 16-key group: [0-3, 8-11, 4-7, 12-15] (4-key groups 1 and 2 swapped), so that the 8
+        // keys one half wave multiplies per MFMA are one 16-byte chunk (see attn_global.hip)
+        const int kgp = (kg & ~3) | ((kg & 1) << 1) | ((kg & 2) >> 1);
+        const int off = (dc * 4 + c) * V_LD + kgp * 4;
         *reinterpret_cast<half4_t*>(sV0 + off) = hi;
         *reinterpret_cast<half4_t*>(sV1 + off) = lo;
       }
@@ -533,14 +536,9 @@ __global__ __launch_bounds__(448) void attn_window_kernel(const AttnP p) {
       for (int db = 0; db < DBLK; ++db) {
         int row = db * 32 + l31;
         if (DBLK * 32 > DH && row >= DH) row = DH - 1;       // rows >= DH feed output rows nobody stores
-        const int off = row * V_LD + 64 * tile + 16 * s + 4 * hh;
-        half8_t vh8, vl8;
-        const half4_t a0 = *reinterpret_cast<const half4_t*>(sV0 + off);
-        const half4_t a1 = *reinterpret_cast<const half4_t*>(sV0 + off + 8);
-        const half4_t b0 = *reinterpret_cast<const half4_t*>(sV1 + off);
-        const half4_t b1 = *reinterpret_cast<const half4_t*>(sV1 + off + 8);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { vh8[t] = a0[t]; vh8[4 + t] = a1[t]; vl8[t] = b0[t]; vl8[4 + t] = b1[t]; }
+        const int off = row * V_LD + 64 * tile + 16 * s + 8 * hh;
+        const half8_t vh8 = *reinterpret_cast<const half8_t*>(sV0 + off);
+        const half8_t vl8 = *reinterpret_cast<const half8_t*>(sV1 + off);
         acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph, acc_o[db], 0, 0, 0);
         acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl, acc_o[db], 0, 0, 0);
         acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph, acc_o[db], 0, 0, 0);
@@ -579,7 +577,7 @@ __global__ __launch_bounds__(448) void attn_window_kernel(const AttnP p) {
 template <int DH>
 static int launch_attn_window(const AttnP& p, int B, hipStream_t s) {
   constexpr int KP = 224;
-  const size_t smem = (size_t)2 * (KP * (DH + 8) + DH * (KP + 4)) * sizeof(half_t);
+  const size_t smem = (size_t)2 * (KP * (DH + 8) + DH * (KP + 8)) * sizeof(half_t);
   static bool configured = false;
   if (!configured) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_window_kernel<DH>),

@@ -7,14 +7,21 @@
 //   2. attn_global_kernel streams 64-key K / V^T tiles HBM -> LDS with global_load_lds_dwordx4 into a 2-deep ring
 //      (one barrier per tile, no staging registers, no conversion), XOR-swizzled 128-byte rows (K rows of dh = 80
 //      are pitched to 176 bytes through dummy chunks instead) so that the ds_read_b128 / b64 fragment reads are
-//      conflict-free.  Arithmetic is unchanged: S^T = K Q^T and O^T += V^T P^T as fp16x3 MFMA, fp32 online softmax,
-//      decomposed rel-pos bias from registers (rel_w) and one scalar per key tile (rel_h).
+//      conflict-free.  Arithmetic: S^T = K Q^T and O^T += V^T P^T as fp16x3 MFMA, fp32 online softmax, decomposed
+//      rel-pos bias from registers (rel_w) and one scalar per key tile (rel_h).  (A 2-pass PV with P or V as ONE fp16
+//      was measured and rejected: its error is 2^-12 max|V| per layer whenever the softmax is sharp -- 1.2e-3 on the
+//      ViT-H + LoRA fixture against the 1e-3 budget)
+//   3. The keys of every 16-key group of V^T are stored in the order [0-3, 8-11, 4-7, 12-15]: the 8 keys a half wave
+//      multiplies in one MFMA (those of its P registers) are then ONE 16-byte chunk -> a single conflict-free
+//      ds_read_b128 per plane instead of two 2-way conflicting ds_read_b64 (PMC r2 base: 37 % LDS conflict cycles).
+//   4. dh = 80 (ViT-H): the 90 KB ring allows one block per CU, so the block is 8 waves (256 queries, 2 waves / SIMD)
+//      instead of 4; blocks are numbered so that all query blocks of an (image, head) run on the SAME XCD and share
+//      its L2 (K / V of one head = 2.6 MB; round-robin placement re-fetched them 9x from the memory side).
 #include "rsp_common.h"
 
 namespace {
 
 constexpr int KT = 64;                 // keys per tile
-constexpr int QB = 128;                // queries per block (4 waves x 32)
 constexpr int EQ = 6, EK = 6, EV = 6;  // power-of-two operand scales (same as attn.hip)
 constexpr float P_SCALE = 16384.0f;
 constexpr float LOG2E_C = 1.4426950408889634f;
@@ -63,8 +70,9 @@ __global__ __launch_bounds__(256) void vit_kv_split_kernel(const float* __restri
     for (int c = 0; c < 4; ++c) {
       half_t a, b;
       rsp_split1(vv[c] * vs, a, b);
-      sV[0][dc * 4 + c][key] = a;
-      sV[1][dc * 4 + c][key] = b;
+      const int kp = (key & ~12) | ((key & 4) << 1) | ((key & 8) >> 1);     // swap key bits 2 and 3 (see header, 3.)
+      sV[0][dc * 4 + c][kp] = a;
+      sV[1][dc * 4 + c][kp] = b;
     }
   }
   __syncthreads();
@@ -87,8 +95,17 @@ struct AttnGP {
   float scale;
 };
 
-template <int DH>
-__global__ __launch_bounds__(256) void attn_global_kernel(const AttnGP p) {
+// XCD-aware numbering (block b runs on XCD b % 8): every XCD gets a contiguous range of the logical order
+__device__ __forceinline__ unsigned xcd_contig(unsigned bid, unsigned nblk) {
+  const unsigned q = nblk >> 3, r = nblk & 7u;
+  const unsigned xcd = bid & 7u, idx = bid >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+template <int DH, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_global_kernel(const AttnGP p) {
+  constexpr int NT = NW * 64;
+  constexpr int QB = NW * 32;                         // queries per block
   constexpr int DSTEPS = DH / 16;
   constexpr int DBLK = (DH + 31) / 32;
   constexpr int KCH = DH / 8;                         // real 16-byte chunks per K row
@@ -97,17 +114,20 @@ __global__ __launch_bounds__(256) void attn_global_kernel(const AttnGP p) {
   constexpr int K_UNITS = KT * KCPR;                  // 16-byte units per K plane tile
   constexpr int V_UNITS = DH * 8;                     // V^T tile: DH rows x 128 bytes
   constexpr int TILE_UNITS = 2 * K_UNITS + 2 * V_UNITS;
-  constexpr int NDMA = (TILE_UNITS + 255) / 256;      // DMA instructions per thread per tile
-  constexpr int BUF_BYTES = NDMA * 256 * 16;
+  constexpr int NDMA = (TILE_UNITS + NT - 1) / NT;    // DMA instructions per thread per tile
+  constexpr int BUF_BYTES = NDMA * NT * 16;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2][BUF_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hh = lane >> 5, l31 = lane & 31;
-  const int bp = blockIdx.z, h = blockIdx.y;
-  const int q0 = blockIdx.x * QB;
-  const int q = q0 + wave * 32 + l31;
   const int T = p.T, S = p.S, nh = p.nh;
+  const int nqb = T / QB;
+  const unsigned lb = xcd_contig(blockIdx.x, gridDim.x);      // logical order: query block fastest, then head, image
+  const int bp = (int)(lb / (unsigned)(nqb * nh));
+  const int h = (int)(lb / (unsigned)nqb) - bp * nh;
+  const int q0 = (int)(lb % (unsigned)nqb) * QB;
+  const int q = q0 + wave * 32 + l31;
   const int64_t bh = (int64_t)bp * nh + h;
   const float* q_b = p.q + (int64_t)bp * p.q_bs + (int64_t)h * p.q_hs;
   const float* rel_b = p.rel + bh * T * (2 * S);
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(256) void attn_global_kernel(const AttnGP p) {
   int dstep[NDMA];                    // byte advance per key tile
 #pragma unroll
   for (int i = 0; i < NDMA; ++i) {
-    const int u = i * 256 + tid;
+    const int u = i * NT + tid;
     dsrc[i] = reinterpret_cast<const unsigned char*>(g_zero16);
     dstep[i] = 0;
     if (u < 2 * K_UNITS) {
@@ -144,7 +164,7 @@ __global__ __launch_bounds__(256) void attn_global_kernel(const AttnGP p) {
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
       const unsigned char* src = dsrc[i] + (int64_t)kt * dstep[i];
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (i * 256 + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (i * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
 
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(256) void attn_global_kernel(const AttnGP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
 
-    // ---- O^T += V^T P^T ----
+    // ---- O^T += V^T P^T as fp16x3 (P hi + lo straight from the score registers, V hi + lo) ----
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       float pf[8];
@@ -275,17 +295,10 @@ __global__ __launch_bounds__(256) void attn_global_kernel(const AttnGP p) {
       for (int db = 0; db < DBLK; ++db) {
         int row = db * 32 + l31;
         if (DBLK * 32 > DH && row >= DH) row = DH - 1;       // rows >= DH feed output rows nobody stores
-        const int sw = (row >> 1) & 7;
-        // keys 16s + 4hh + {0..3} and 16s + 8 + 4hh + {0..3}: chunks 2s and 2s + 1, 8-byte half hh
-        const int o0 = row * 64 + (((2 * s) ^ sw) << 3) + 4 * hh;
-        const int o1 = row * 64 + (((2 * s + 1) ^ sw) << 3) + 4 * hh;
-        half8_t vh8, vl8;
-        const half4_t a0 = *reinterpret_cast<const half4_t*>(sV0 + o0);
-        const half4_t a1 = *reinterpret_cast<const half4_t*>(sV0 + o1);
-        const half4_t b0 = *reinterpret_cast<const half4_t*>(sV1 + o0);
-        const half4_t b1 = *reinterpret_cast<const half4_t*>(sV1 + o1);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) { vh8[t] = a0[t]; vh8[4 + t] = a1[t]; vl8[t] = b0[t]; vl8[4 + t] = b1[t]; }
+        // the 8 keys of this half wave (16s + 4hh + {0..3}, 16s + 8 + 4hh + {0..3}) are chunk 2s + hh of the row
+        const int off = row * 64 + (((2 * s + hh) ^ ((row >> 1) & 7)) << 3);
+        const half8_t vh8 = *reinterpret_cast<const half8_t*>(sV0 + off);
+        const half8_t vl8 = *reinterpret_cast<const half8_t*>(sV1 + off);
         acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl8, ph, acc_o[db], 0, 0, 0);
         acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, pl, acc_o[db], 0, 0, 0);
         acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh8, ph, acc_o[db], 0, 0, 0);
@@ -343,7 +356,10 @@ int launch_global(const float* qkv, const float* rel, void* ws, float* out, uint
   p.q_bs = (int64_t)T * 3 * D; p.q_ts = 3 * D; p.q_hs = DH;
   p.o_bs = (int64_t)T * D; p.o_ts = D; p.o_hs = DH;
   p.T = T; p.S = S; p.nh = nh; p.scale = scale;
-  hipLaunchKernelGGL((attn_global_kernel<DH>), dim3(T / QB, nh, Bp), dim3(256), 0, s, p);
+  // dh = 80: the ring is 90 KB -> one block per CU, so make it 8 waves; dh = 64: 64 KB -> two 4-wave blocks per CU
+  constexpr int NW = (DH > 64) ? 8 : 4;
+  if (T % (NW * 32)) return RSP_EINVAL;
+  hipLaunchKernelGGL((attn_global_kernel<DH, NW>), dim3((unsigned)(T / (NW * 32)) * nh * Bp), dim3(NW * 64), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
@@ -360,7 +376,7 @@ extern "C" int rsp_vit_attention_global(const float* qkv, const float* rel, void
   if (!qkv || !rel || !workspace || Bp <= 0 || nh <= 0) return RSP_EINVAL;
   if (!out && !(out_hi && out_lo)) return RSP_EINVAL;
   if ((out_hi == nullptr) != (out_lo == nullptr)) return RSP_EINVAL;
-  if (!(S == 64 || S == 32)) return RSP_EINVAL;          // T % 128 == 0 and whole key rows per 32-key block
+  if (!(S == 64 || S == 32)) return RSP_EINVAL;          // T % 256 == 0 and whole key rows per 32-key block
   if (out_hi && ((nh * dh) & 31)) return RSP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   if (dh == 64) return launch_global<64>(qkv, rel, workspace, out, out_hi, out_lo, out_scale_log2, Bp, S, nh, scale, s);

@@ -249,3 +249,81 @@ extern "C" int rsp_pack_bits(const uint8_t* src, uint8_t* dst, int64_t n_bits, r
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Test-pipeline front end: `Resize(scale, keep_ratio=True)` + `Pad(size, pad_val)` of
+// configs/rsprompter/_base_/rsprompter_anchor.py:231-241 (mmcv.imrescale -> cv2.resize INTER_LINEAR on the float32
+// image, mmcv.impad constant border) and, optionally fused, the DetDataPreprocessor arithmetic (BGR->RGB,
+// (x - mean) / std, data_preprocessor.py:110-149).  src: one decoded image, HWC interleaved (what cv2 / PIL hand
+// over), uint8 or fp32;  dst: [3, Hp, Wp] planar fp32.  Pixel (y, x) of the resized [Hn, Wn] region is cv2's
+//   fx = (x + 0.5) * (W / Wn) - 0.5, sx = floor(fx), fx -= sx; sx < 0 -> (0, 0); sx >= W - 1 -> (W - 1, 0)
+// (same for y) blended in fp32 horizontally first, then vertically -- cv2's resizeGeneric_ order; everything right of /
+// below the resized region is the per-channel pad value.  normalise = 0: dst keeps the source channel order and
+// range (what PackDetInputs hands to the model); 1: dst channel c = (src[swap ? 2 - c : c] - mean[c]) / std[c] and
+// the padding is normalised the same way (what the data preprocessor would make of it).
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void resize_pad_kernel(const T* __restrict__ src, float* __restrict__ dst, int H,
+                                                         int W, int Hn, int Wn, int Hp, int Wp, float p0, float p1,
+                                                         float p2, int normalise, int swap_rb, float m0, float m1,
+                                                         float m2, float s0, float s1, float s2) {
+  const double sx_scale = (double)W / (double)Wn, sy_scale = (double)H / (double)Hn;   // cv2: double scales
+  const int64_t total = (int64_t)Hp * Wp;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wp), y = (int)(i / Wp);
+    float v[3] = {p0, p1, p2};
+    if (y < Hn && x < Wn) {
+      float fx = (float)(((double)x + 0.5) * sx_scale - 0.5);
+      int x0 = (int)floorf(fx);
+      fx -= (float)x0;
+      if (x0 < 0) { x0 = 0; fx = 0.f; }
+      if (x0 >= W - 1) { x0 = W - 1; fx = 0.f; }
+      float fy = (float)(((double)y + 0.5) * sy_scale - 0.5);
+      int y0 = (int)floorf(fy);
+      fy -= (float)y0;
+      if (y0 < 0) { y0 = 0; fy = 0.f; }
+      if (y0 >= H - 1) { y0 = H - 1; fy = 0.f; }
+      const int x1 = x0 + 1 < W ? x0 + 1 : W - 1, y1 = y0 + 1 < H ? y0 + 1 : H - 1;
+      const T* r0 = src + ((int64_t)y0 * W) * 3;
+      const T* r1 = src + ((int64_t)y1 * W) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float top = (float)r0[x0 * 3 + c] * (1.f - fx) + (float)r0[x1 * 3 + c] * fx;
+        const float bot = (float)r1[x0 * 3 + c] * (1.f - fx) + (float)r1[x1 * 3 + c] * fx;
+        v[c] = top * (1.f - fy) + bot * fy;
+      }
+    }
+    if (normalise) {
+      const float a = swap_rb ? v[2] : v[0], b = v[1], c2 = swap_rb ? v[0] : v[2];
+      v[0] = (a - m0) / s0; v[1] = (b - m1) / s1; v[2] = (c2 - m2) / s2;
+    }
+    dst[i] = v[0];
+    dst[total + i] = v[1];
+    dst[2 * total + i] = v[2];
+  }
+}
+
+}  // namespace
+
+extern "C" int rsp_resize_pad(const void* src, int32_t src_is_u8, float* dst, int32_t H, int32_t W, int32_t Hn,
+                              int32_t Wn, int32_t Hp, int32_t Wp, const float* pad3, int32_t normalise,
+                              int32_t swap_rb, const float* mean3, const float* std3, rsp_stream_t stream) {
+  if (!src || !dst || !pad3 || H <= 0 || W <= 0 || Hn <= 0 || Wn <= 0 || Hp < Hn || Wp < Wn) return RSP_EINVAL;
+  if (normalise && (!mean3 || !std3)) return RSP_EINVAL;
+  const float m0 = normalise ? mean3[0] : 0.f, m1 = normalise ? mean3[1] : 0.f, m2 = normalise ? mean3[2] : 0.f;
+  const float s0 = normalise ? std3[0] : 1.f, s1 = normalise ? std3[1] : 1.f, s2 = normalise ? std3[2] : 1.f;
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t total = (int64_t)Hp * Wp;
+  if (src_is_u8) {
+    hipLaunchKernelGGL((resize_pad_kernel<uint8_t>), dim3(grid_for(total)), dim3(256), 0, s, (const uint8_t*)src, dst,
+                       H, W, Hn, Wn, Hp, Wp, pad3[0], pad3[1], pad3[2], normalise, swap_rb, m0, m1, m2, s0, s1, s2);
+  } else {
+    hipLaunchKernelGGL((resize_pad_kernel<float>), dim3(grid_for(total)), dim3(256), 0, s, (const float*)src, dst, H,
+                       W, Hn, Wn, Hp, Wp, pad3[0], pad3[1], pad3[2], normalise, swap_rb, m0, m1, m2, s0, s1, s2);
+  }
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}

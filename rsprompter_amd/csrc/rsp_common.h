@@ -21,9 +21,15 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // x = hi + lo with hi, lo fp16 (round-to-nearest-even both times).  The fp32
 // remainder x - hi is exact, so hi+lo carries ~22 significant bits of x.
+// SATURATING: |x| beyond the fp16 range does not produce inf / -inf planes (whose MFMA products are NaN for the whole
+// output row): hi clamps at +-65504 and lo carries the remainder (11 bits of it) up to |x| = 131008, beyond that the
+// pair saturates.  One v_med3_f32 per plane; callers pick the pre-scale so that this is the outlier path only.
+constexpr float RSP_F16_MAX = 65504.0f;
 __device__ __forceinline__ void rsp_split1(float x, half_t& hi, half_t& lo) {
-  hi = (half_t)x;
-  lo = (half_t)(x - (float)hi);
+  const float xh = __builtin_fminf(__builtin_fmaxf(x, -RSP_F16_MAX), RSP_F16_MAX);
+  hi = (half_t)xh;
+  const float r = x - (float)hi;
+  lo = (half_t)__builtin_fminf(__builtin_fmaxf(r, -RSP_F16_MAX), RSP_F16_MAX);
 }
 
 // exact-erf GELU (nn.GELU default, HF "gelu").  erf through Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7 absolute,

@@ -61,28 +61,10 @@ def nchw_view(x_nhwc):
 
 
 def load_checkpoint_into(module, path, revise_keys=(), strict=False, prefix=None):
-    """mmengine.load_checkpoint stand-in: torch.load + regex key rewrites
-    (reference call sites: models.py:777-783, 836-852)."""
-    if path is None:
-        return False
-    path = os.path.expanduser(str(path))
-    if not os.path.exists(path):
-        warnings.warn(f'checkpoint {path} not found; keeping current weights')
-        return False
-    sd = torch.load(path, map_location='cpu')
-    if isinstance(sd, dict) and 'state_dict' in sd:
-        sd = sd['state_dict']
-    out = {}
-    for k, v in sd.items():
-        for pat, rep in revise_keys:
-            k = re.sub(pat, rep, k)
-        out[k] = v
-    if prefix is not None:
-        out = {k[len(prefix):]: v for k, v in out.items() if k.startswith(prefix)}
-    own = module.state_dict()
-    filtered = {k: v for k, v in out.items() if k in own}
-    module.load_state_dict(filtered, strict=strict)
-    return True
+    """see rsprompter_amd/checkpoint.py (formats: HF .bin / .safetensors (+ sharded index), mmengine .pth, DeepSpeed
+    zero_to_fp32 output; ConvModule norm-name aliases)."""
+    from .checkpoint import load_checkpoint_into as _load
+    return _load(module, path, revise_keys=revise_keys, strict=strict, prefix=prefix)
 
 
 class HIPModule(nn.Module):

@@ -8,7 +8,13 @@ import torch
 from . import _lib as _lib_real
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
-DEFAULT_A_SCALE_LOG2 = 6
+# Power-of-two pre-scale of activation planes (x * 2^e is what gets split into fp16 hi + lo).  e = 2 keeps |x| < 16376
+# exactly representable (the split saturates beyond, rsp_common.h) -- headroom for the outlier activations of real SAM
+# checkpoints (MLP hidden layer, residual stream) and for the RSFeatureAggregator's running sum over 16 layers, which
+# passed 1023 (the old e = 6 limit) on the ViT-H fixture and turned whole rows into NaN.  The price is that `lo` goes
+# subnormal for |x| < 0.03: an absolute error floor of 7.5e-9 per element, invisible next to the 1e-5 fp32 noise floor.
+DEFAULT_A_SCALE_LOG2 = 2
+DEBUG_FINITE = bool(int(__import__('os').environ.get('RSP_DEBUG_FINITE', '0')))
 
 
 class Profiler:
@@ -315,6 +321,8 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     _timed(f'{kname}<{tile}>', 2.0 * m * n * w.K, 4.0 * (m * w.K + m * n) + 4.0 * n * w.K,
            lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm"),
            detail=f'M={m} N={n} K={w.K}' + (' conv' if conv is not None else ''))
+    if DEBUG_FINITE and out is not None and not bool(torch.isfinite(out).all()):
+        raise FloatingPointError(f'rsp_gemm produced non-finite values (M={m} N={n} K={w.K})')
     if out_planes:
         return (out, pl) if out_f32 else pl
     return out
@@ -421,6 +429,34 @@ def preprocess(imgs, mean, std, swap_rb, pad_divisor=1, pad_value=0.0, device=No
         _lib.check(lib.rsp_preprocess(im.data_ptr(), is_u8, out[b].data_ptr(), int(im.shape[1]),
                                       int(im.shape[2]), Hp, Wp, m3, s3, 1 if swap_rb else 0,
                                       float(pad_value), _stream()), "rsp_preprocess")
+    return out
+
+
+def resize_pad(img_hwc, new_hw, pad_hw, pad_val=(0.0, 0.0, 0.0), out=None, normalise=None):
+    """Resize(keep_ratio) + Pad of the test pipeline on one decoded HWC image (uint8 / fp32, device tensor) ->
+    fp32 [3, Hp, Wp] (see rsp_resize_pad).  normalise = (mean3, std3, swap_rb) fuses the DetDataPreprocessor step."""
+    import ctypes
+    lib = _lib.load()
+    if img_hwc.dim() != 3 or img_hwc.shape[2] != 3 or not img_hwc.is_cuda:
+        raise ValueError('resize_pad expects an [H, W, 3] device tensor')
+    im = img_hwc.contiguous()
+    if im.dtype != torch.uint8:
+        im = im.to(torch.float32)
+    H, W = int(im.shape[0]), int(im.shape[1])
+    Hn, Wn = int(new_hw[0]), int(new_hw[1])
+    Hp, Wp = int(pad_hw[0]), int(pad_hw[1])
+    if out is None:
+        out = torch.empty((3, Hp, Wp), dtype=torch.float32, device=im.device)
+    p3 = (ctypes.c_float * 3)(*[float(v) for v in pad_val])
+    if normalise is None:
+        m3 = s3 = None
+        nrm, swap = 0, 0
+    else:
+        m3 = (ctypes.c_float * 3)(*[float(v) for v in normalise[0]])
+        s3 = (ctypes.c_float * 3)(*[float(v) for v in normalise[1]])
+        nrm, swap = 1, 1 if normalise[2] else 0
+    _lib.check(lib.rsp_resize_pad(im.data_ptr(), 1 if im.dtype == torch.uint8 else 0, out.data_ptr(), H, W, Hn, Wn,
+                                  Hp, Wp, p3, nrm, swap, m3, s3, _stream()), "rsp_resize_pad")
     return out
 
 
@@ -727,6 +763,10 @@ def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, m
     B = img_hw.shape[0]
     n_max = int((roi_start[1:] - roi_start[:-1]).max()) if roi_start.numel() > 1 else 0
     cap = max(n_max * num_classes, 1)
+    if cap > 16384:
+        raise ValueError(f'bbox_post: {n_max} RoIs x {num_classes} classes = {cap} NMS candidates per image exceeds the '
+                         '16384 the single-pass sort of rsp_batched_nms holds (det.hip NMS_MAXW); lower '
+                         'test_cfg.rpn.max_per_img or split the classes')
     cand = _cand_buffers(B, cap, dev)
     std4 = (ctypes.c_float * 4)(*[float(s) for s in stds])
     rs = roi_start.to(device=dev, dtype=torch.int32)

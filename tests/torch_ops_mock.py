@@ -375,3 +375,16 @@ def query_mask_post(low_res, qidx, cls_score, batch_input_shape, crop_hw, out_hw
     masks = binary.bool()
     out = (masks, cls_score * ms, mask2bbox(masks))
     return out + (m,) if want_logits else out
+
+
+def resize_pad(img_hwc, new_hw, pad_hw, pad_val=(0.0, 0.0, 0.0), out=None, normalise=None):
+    """stand-in of ops.resize_pad through the oracle's cv2 / mmcv restatement (oracle/pipeline.py)."""
+    import numpy as np
+    from oracle import pipeline as op
+    assert normalise is None
+    img = img_hwc.cpu().numpy().astype(np.float32)
+    res = op.cv2_resize_linear_f32(img, int(new_hw[1]), int(new_hw[0]))
+    canvas = np.empty((int(pad_hw[0]), int(pad_hw[1]), 3), dtype=np.float32)
+    canvas[...] = np.asarray(pad_val, dtype=np.float32)
+    canvas[:res.shape[0], :res.shape[1]] = res
+    return torch.from_numpy(np.ascontiguousarray(canvas.transpose(2, 0, 1)))
