@@ -50,6 +50,7 @@ static FastDiv make_fastdiv(int dv) {
 struct GemmP {
   RspGemmDesc d;
   FastDiv fd_ctw, fd_resmod, fd_resb, fd_hd;   // ct_W, res_mod, res_brows, hd_rows
+  int group_m;                                 // > 1: grouped tile order (see the kernel)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -86,7 +87,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 // EPI: reserved (0); the fused LayerNorm / hyper-network epilogues are run-time modes of the generic epilogue.
 // PIPE: 0 = plain ring, 1 = register-pipelined loop, 2 = 1 + DMA instructions spread between the MFMA groups.
 // CONV: implicit-GEMM 3x3 convolution loader (A addresses from (pixel, tap)).
-template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false>
+// ORD: 0 = the three products of an accumulator back to back; 1 = pass-major (all a_lo b_hi, then all a_hi b_lo, then all
+// a_hi b_hi: dependent MFMAs TM*TN issue slots apart) -- tuning variant.
+template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false, int ORD = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const GemmP p) {
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
@@ -110,7 +113,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   const int M = d.M, N = d.N, K = d.K;
   const int nbn = (N + BN - 1) / BN;
   const unsigned lbid = xcd_remap(blockIdx.x, gridDim.x);
-  const int m0 = (int)(lbid / nbn) * BM, n0 = (int)(lbid % nbn) * BN;
+  int mb = (int)(lbid / nbn), nb_ = (int)(lbid % nbn);
+  if (p.group_m > 1) {
+    // grouped order inside the XCD's contiguous range: group_m M-blocks x all N-blocks, M fastest -- the ~32 tiles an
+    // XCD runs at once then cover a (group_m x 32/group_m) patch of the output, i.e. group_m A panels + 32/group_m W
+    // panels per K step in its 4 MB L2 instead of ~2 A panels + every W panel (PMC r2: W re-fetched 10x per XCD)
+    const int nbm = (M + BM - 1) / BM;
+    const int per = p.group_m * nbn;
+    const int grp = (int)(lbid / (unsigned)per), rem = (int)(lbid % (unsigned)per);
+    const int first = grp * p.group_m;
+    const int gsz = min(nbm - first, p.group_m);
+    mb = first + rem % gsz;
+    nb_ = rem / gsz;
+  }
+  const int m0 = mb * BM, n0 = nb_ * BN;
   const unsigned char* zero = reinterpret_cast<const unsigned char*>(g_zero_page);
 
   // ---- per-thread DMA slots.  A unit u = i*256 + tid: plane = u / (BM*4), row = (u % (BM*4)) / 4,
@@ -249,6 +265,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
     }
   };
   auto mfma_frags = [&](const Frags& f) {
+    if constexpr (ORD == 1 && ABL != 2) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -270,6 +301,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
     const TileK t = tile_k(k0);
     unsigned char* lbase = &smem[buf][0];
     constexpr int G = TM * TN;
+    if constexpr (ORD == 1) {
+      // pass-major: 3 G MFMAs in (pass, i, j) order, the DMA slots spread over the 3 G positions
+      static_for<0, 3 * G>([&](auto gc) {
+        constexpr int q = decltype(gc)::value, ps = q / G, g = q % G, i = g / TN, j = g % TN;
+        if constexpr (ps == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        else if constexpr (ps == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        if constexpr ((q + 1) * LPT / (3 * G) > q * LPT / (3 * G)) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (do_issue) static_for<q * LPT / (3 * G), (q + 1) * LPT / (3 * G)>([&](auto sc) { issue_slot(sc, t, lbase); });
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      });
+      return;
+    }
     static_for<0, G>([&](auto gc) {
       constexpr int g = decltype(gc)::value, i = g / TN, j = g % TN;
       {
@@ -540,14 +586,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false>
+template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false, int ORD = 0>
 int launch_dma(const RspGemmDesc& d, hipStream_t s) {
   GemmP p; p.d = d;
+  p.group_m = (d.tile_hint >> 8) & 0xff;      // tuning field: tile_hint = tile | group_m << 8
+  if (p.group_m == 0 && BM == 256 && BN == 256 && !CONV) p.group_m = 8;   // default for the big tile (1-4 % on the ViT-H shapes)
   p.fd_ctw = make_fastdiv(d.ct_W); p.fd_resmod = make_fastdiv(d.res_mod);
   p.fd_resb = make_fastdiv(d.res_brows); p.fd_hd = make_fastdiv(d.hd_rows);
   const long long nblk = (long long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
   if (nblk > 0x7fffffffLL) return RSP_EINVAL;
-  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF, ABL, EPI, PIPE, CONV>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
+  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF, ABL, EPI, PIPE, CONV, ORD>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
@@ -571,13 +619,13 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   // Tile rule (tools/gemm_sweep.py on MI355X; run-to-run spread is a few %): the register-pipelined loops win
   // everywhere; 256x256 needs >= 4 rounds of blocks over the 256 CUs, 256x128 >= 2, else 128x128 (2 blocks/CU).
   if (d.conv_k != 0) {   // implicit-GEMM convolutions: CONV instantiations of the same kernels
-    if (d.N > 128 && (d.tile_hint == 17 || (d.tile_hint == 0 && nblk(256, 256) >= 1024)))
+    if (d.N > 128 && ((d.tile_hint & 0xff) == 17 || ((d.tile_hint & 0xff) == 0 && nblk(256, 256) >= 1024)))
       return launch_dma<256, 256, 2, 4, 2, 0, 0, 2, true>(d, s);
     if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 0, 0, 1, true>(d, s);
     if (d.N > 32) return launch_dma<128, 64, 2, 2, 3, 0, 0, 0, true>(d, s);
     return launch_dma<128, 32, 4, 1, 3, 0, 0, 0, true>(d, s);
   }
-  int tile = d.tile_hint;
+  int tile = d.tile_hint & 0xff;
   if (tile == 0) {
     // short K (<= 8 K tiles): the block is mostly prologue + epilogue, two 128x128 blocks per CU overlap them
     if (d.K <= 256) tile = 14;
@@ -593,6 +641,10 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
       tile = 14;
       if (d.N > 64) { const double c = cost(256, 128, 1, 0.96); if (c < best) { best = c; tile = 18; } }
       if (d.N > 128) { const double c = cost(256, 256, 1, 1.0); if (c <= best) { best = c; tile = 17; } }
+      // round 2 (tools/gemm_exp.py, ViT-H shapes): from two full rounds of 256x256 tiles on, the big tile wins even
+      // with a ragged last round (blocks do not run in lockstep): qkv 350 vs 322 TFLOP/s, lin2 368 vs 352
+      // (K = 1280 with only 3 rounds -- the proj shape -- stays with the small tile: 279 vs 252)
+      if (d.N > 128 && (nblk(256, 256) >= 1024 || (nblk(256, 256) >= 512 && d.K >= 2048))) tile = 17;
     }
   }
   switch (tile) {   // hints >= 4 are benchmarking variants of the same arithmetic
@@ -615,6 +667,8 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
     case 20: if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 0, 0, 2>(d, s); break;
     case 21: return launch_dma<128, 64, 2, 2, 3, 0, 0, 1>(d, s);                         // narrow tile, 3-deep ring
     case 22: return launch_dma<128, 64, 2, 2, 4, 0, 0, 1>(d, s);
+    case 31: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 0, 0, 2, false, 1>(d, s); break;   // pass-major MFMA order
+    case 32: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2, 0, 0, 2, false, 1>(d, s); break;
     case 15: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 1, 0, 1>(d, s); break;   // ... without the DMA
     case 16: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2, 1, 0, 1>(d, s); break;
     default: break;

@@ -221,9 +221,10 @@ def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30):
     """Mirror of the tile choice in rsp_gemm_dma_dispatch (gemm_dma.hip) - profiler labels only."""
     nblk = lambda bm, bn: -(-n // bn) * -(-m // bm)
     small = '128x128' if n > 64 else ('128x64' if n > 32 else '128x32')
-    if hint in (3, 9, 10, 11, 15, 17):
+    hint &= 0xff
+    if hint in (3, 9, 10, 11, 15, 17, 31):
         return '256x256'
-    if hint in (2, 4, 12, 13, 16, 18, 19):
+    if hint in (2, 4, 12, 13, 16, 18, 19, 32):
         return '256x128'
     if hint != 0:
         return small
@@ -236,7 +237,7 @@ def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30):
     c = cost(256, 128, 1, 0.96)
     if c < best:
         best, name = c, '256x128'
-    if n > 128 and cost(256, 256, 1, 1.0) <= best:
+    if n > 128 and (cost(256, 256, 1, 1.0) <= best or nblk(256, 256) >= 1024 or (nblk(256, 256) >= 512 and k >= 2048)):
         name = '256x256'
     return name
 
