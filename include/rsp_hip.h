@@ -112,6 +112,11 @@ typedef struct RspGemmDesc {
   const uint16_t* res_hi; const uint16_t* res_lo; int32_t res_scale_log2, res_rows;
   const float* hd_hyper; float* hd_out;
   int32_t hd_rows;    /* GEMM rows per RoI (input pixels of the ConvTranspose)                                */
+  /* column-range outputs (plane path, plain GEMMs): fp32 C is written only for columns < c_ncols (0 = all, same ldc),  */
+  /* the planes Chi/Clo only for columns >= pl_col0 (pl_col0 % 32 == 0) as a [c_rows, N - pl_col0] KB32 tensor.          */
+  /* The SAM ViT qkv projection uses c_ncols = pl_col0 = D: q leaves as fp32 (rel-pos + attention Q operand), K | V      */
+  /* as the fp16 planes the attention kernel DMAs (rsp_vit_attention_planes) -- no fp32 K / V tensor is ever written.    */
+  int32_t c_ncols, pl_col0;
   int32_t tile_hint;  /* 0 = auto (cost model in gemm_dma.hip).  Benchmarking only: 1/2/3 = plain 128x128 / 256x128 / */
                       /* 256x256, 11-14 = register-pipelined loops, 17-20 = + DMA spread between the MFMA groups    */
                       /* (17 = 256x256, 18 = 256x128, 20 = 128x128); other values are tuning probes.                */
@@ -156,6 +161,16 @@ int rsp_vit_attention_ex(const float* qkv, const float* rel, float* out, uint16_
                          uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t S,
                          int32_t nh, int32_t dh, float scale, rsp_stream_t stream);
 /* Global-attention layers (S == 64 or 32): K and V of every (image, head) are split once into fp16 hi/lo planes   */
+/* rsp_vit_attention_planes: the same attention with K | V given as the KB32 fp16 planes [2D/32][kv_rows][32] of the  */
+/* qkv GEMM (value * 2^kv_scale_log2) and q as fp32 rows of stride q_ld: DMA-fed key tiles, transposing LDS reads for  */
+/* V (csrc/attn_stream.hip).  S = 14 (windows), 32, 64; dh = 64 / 80.  Outputs as rsp_vit_attention_ex.                */
+int rsp_vit_attention_planes(const float* q, int64_t q_ld, const uint16_t* kv_hi, const uint16_t* kv_lo,
+                             int64_t kv_rows, int32_t kv_scale_log2, const float* rel, float* out, uint16_t* out_hi,
+                             uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t S, int32_t nh, int32_t dh,
+                             float scale, rsp_stream_t stream);
+/* rsp_vit_relpos with an explicit token stride of q (q rows of [Bp*T, q_ld], head h at column h*dh)                   */
+int rsp_vit_relpos_q(const float* q, int64_t q_ld, const float* rel_pos_h, const float* rel_pos_w, float* rel,
+                     int32_t Bp, int32_t S, int32_t nh, int32_t dh, rsp_stream_t stream);
 /* (K as [key][dh], V transposed) inside `workspace` (rsp_vit_attention_global_ws_bytes) and the attention kernel   */
 /* streams them HBM -> LDS with the DMA engine.  Same semantics and outputs as rsp_vit_attention_ex.                */
 int64_t rsp_vit_attention_global_ws_bytes(int32_t Bp, int32_t S, int32_t nh, int32_t dh);

@@ -30,8 +30,19 @@ Pinning status:
     not stable).
   * COCO RLE (oracle/rle.py, pycocotools restated): pinned on the compressed RLE strings of the reference's
     tests/data/vis_sample.json (tests/golden/coco_rle_strings.json).
+  * module FORWARDS the reference wires out of mmcv bricks -- RSSimpleFPN, PseudoFeatureAggregator (+ RSFPN),
+    RSPrompterAnchorMaskHead.forward, RSMask2FormerHead.{_forward_head, forward} (incl. MSDeformAttnPixelDecoder.forward,
+    Mask2FormerTransformerEncoder / Decoder layers, MlvlPointGenerator, SinePositionalEncoding) and ViTSAM.forward --
+    are checked against the REAL classes executed in the build container on torch stand-ins for the mmcv leaves
+    (tests/golden/make_golden_forwards.py + mmcv_standins.py -> tests/test_oracle_forwards.py), weights and inputs
+    drawn from (seed, key, shape) on both sides, so the `state_dict` key layout (names, shapes) is pinned too.
+    That run established that the LN2d layers of RSSimpleFPN carry eps = 1e-5 (mmcv `build_norm_layer` default), not
+    LN2d's own 1e-6.
+  * test pipeline front end (Resize keep_ratio + Pad, oracle/pipeline.py): restated from mmcv 2.1 / OpenCV documented
+    behaviour, cross-checked against torch's independent bilinear; cv2 itself is not available: UNPINNED.
   * SAM encoder / mask decoder: HF modules themselves (the reference's dependency).
-  * mmcv RoIAlign / nms / batched_nms / MultiScaleDeformableAttention / MultiheadAttention / FFN and peft's LoRA
-    wrapping: source not in /root/reference -> restated from documented semantics:
-    PARITY UNPINNED at that boundary.
+  * mmcv LEAF ops -- RoIAlign, nms / batched_nms, MultiScaleDeformableAttention, MultiheadAttention, FFN -- and peft's
+    LoRA wrapping: source not in /root/reference -> restated from documented semantics and checked
+    by hand-derivable known-answer vectors (tests/test_oracle_golden.py::test_mmcv_leaf_known_answers):
+    PARITY UNPINNED at that boundary only.
 """

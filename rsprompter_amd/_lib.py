@@ -33,6 +33,7 @@ class RspGemmDesc(ctypes.Structure):
         ("ln_gamma", c_void_p), ("ln_beta", c_void_p), ("ln_eps", c_float),
         ("res_hi", c_void_p), ("res_lo", c_void_p), ("res_scale_log2", c_int), ("res_rows", c_int),
         ("hd_hyper", c_void_p), ("hd_out", c_void_p), ("hd_rows", c_int),
+        ("c_ncols", c_int), ("pl_col0", c_int),
         ("tile_hint", c_int),
     ]
 
@@ -91,6 +92,9 @@ PROTOTYPES = {
     "rsp_vit_attention_global_ws_bytes": (ctypes.c_int64, [c_int, c_int, c_int, c_int]),
     "rsp_vit_attention_global": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                          c_int, c_int, c_float, c_void_p]),
+    "rsp_vit_attention_planes": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "rsp_vit_relpos_q": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "rsp_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rsp_preprocess": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_float, c_void_p]),

@@ -40,7 +40,7 @@ def _digest():
     for p in sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")] + [
             os.path.join(HERE, "..", "include", "rsp_hip.h")]:
         with open(p, "rb") as f:
-            h.update(p.encode())
+            h.update(os.path.basename(p).encode())      # names, not absolute paths: the tree moves (gpurun snapshot)
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()

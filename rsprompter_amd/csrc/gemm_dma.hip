@@ -553,16 +553,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
             for (int e = 0; e < nv; ++e) v[e] += rp[e];
           }
         }
-        if (d.C) {
+        if (d.C && (d.c_ncols <= 0 || col < d.c_ncols)) {
           float* cp = d.C + (int64_t)crow * d.ldc + ccol;
           if (vec) *reinterpret_cast<f32x4*>(cp) = v;
           else for (int e = 0; e < nv; ++e) cp[e] = v[e];
         }
-        if (d.Chi) {
-          // KB32 planes of the [c_rows, N] result; for a ConvTranspose the planes are those of the NHWC output
-          // [.., ct_c]: the sub-pixel dx folds into the row index
+        if (d.Chi && col >= d.pl_col0) {
+          // KB32 planes of the [c_rows, N - pl_col0] result (columns from pl_col0 on); for a ConvTranspose the planes
+          // are those of the NHWC output [.., ct_c]: the sub-pixel dx folds into the row index
           int64_t prow = crow;
-          int pch = col;
+          int pch = col - d.pl_col0;
           if (ct) { const int dx = ccol >= ct_c; pch = ccol - dx * ct_c; prow = (int64_t)crow * 2 + dx; }
           half4_t h4, l4;
 #pragma unroll
@@ -615,6 +615,8 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
                      d.c_rowmap || d.hd_out))
     return RSP_EINVAL;
   if (d.hd_out && (d.C || d.Chi || d.res || d.c_rowmap)) return RSP_EINVAL;
+  if ((d.pl_col0 || d.c_ncols) && (d.ct_W > 0 || (d.pl_col0 & 31) || (d.c_ncols & 3) || d.pl_col0 < 0 || (d.N & 3)))
+    return RSP_EINVAL;   // column-range outputs: plain GEMMs only, plane range on a 32-column boundary
   auto nblk = [&](int bm, int bn) { return (long long)((d.N + bn - 1) / bn) * ((d.M + bm - 1) / bm); };
   // Tile rule (tools/gemm_sweep.py on MI355X; run-to-run spread is a few %): the register-pipelined loops win
   // everywhere; 256x256 needs >= 4 rounds of blocks over the 256 CUs, 256x128 >= 2, else 128x128 (2 blocks/CU).

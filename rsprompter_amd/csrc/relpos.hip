@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
                                                          const float* __restrict__ rph,
                                                          const float* __restrict__ rpw,
                                                          float* __restrict__ rel, int T, int S,
-                                                         int nh, int64_t rows_total) {
+                                                         int nh, int64_t rows_total, int64_t tok_stride) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int LD = DH + 4;
   const int nrow = 2 * S - 1;
@@ -36,7 +36,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
   const int bp = qok ? (int)(g / T) : 0;
   const int q = qok ? (int)(g - (int64_t)bp * T) : 0;
   const int part = tid >> 6;                      // wave-uniform: 0,1 -> rel_h halves, 2,3 -> rel_w halves
-  const int64_t tok_stride = (int64_t)3 * nh * DH;
   f32x4 qv[DH / 4];
   {
     const float* src = qkv + ((int64_t)bp * T + q) * tok_stride + (int64_t)h * DH;
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(256) void vit_relpos_win_kernel(const float* __rest
                                                              const float* __restrict__ rph,
                                                              const float* __restrict__ rpw,
                                                              float* __restrict__ rel, int T, int S, int nh,
-                                                             int64_t rows_total) {
+                                                             int64_t rows_total, int64_t tok_stride) {
   constexpr int DSTEPS = DH / 16;
   constexpr int LDT = DH + 8;                                  // halves per table row (conflict-free b128 reads)
   __shared__ __attribute__((aligned(16))) half_t sT[2][2][32 * LDT];   // [table][hi/lo][idx][d]
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(256) void vit_relpos_win_kernel(const float* __rest
   half8_t qh[DSTEPS], ql[DSTEPS];
   {
     const float qs = ldexpf(1.0f, RQ);
-    const float* src = qkv + gg * ((int64_t)3 * nh * DH) + (int64_t)h * DH;
+    const float* src = qkv + gg * tok_stride + (int64_t)h * DH;
 #pragma unroll
     for (int st = 0; st < DSTEPS; ++st) {
       const f32x4 a = *reinterpret_cast<const f32x4*>(src + st * 16 + hh * 8);
@@ -206,9 +205,10 @@ __global__ __launch_bounds__(256) void vit_relpos_win_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const float* rel_pos_w,
-                              float* rel, int32_t Bp, int32_t S, int32_t nh, int32_t dh,
-                              rsp_stream_t stream) {
+extern "C" int rsp_vit_relpos_q(const float* qkv, int64_t q_ld, const float* rel_pos_h, const float* rel_pos_w,
+                                float* rel, int32_t Bp, int32_t S, int32_t nh, int32_t dh, rsp_stream_t stream) {
+  const int64_t tok_stride = q_ld;
+  if ((q_ld & 3) || q_ld < (int64_t)nh * dh) return RSP_EINVAL;
   if (!qkv || !rel_pos_h || !rel_pos_w || !rel || Bp <= 0 || S <= 0 || S > 64 || nh <= 0)
     return RSP_EINVAL;
   const int T = S * S;
@@ -216,9 +216,9 @@ extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const fl
   if (S <= 16 && (dh == 64 || dh == 80)) {   // windowed layers: MFMA form
     dim3 g2((unsigned)((rows_total + 127) / 128), nh, 1);
     if (dh == 64)
-      hipLaunchKernelGGL((vit_relpos_win_kernel<64>), g2, dim3(256), 0, (hipStream_t)stream, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total);
+      hipLaunchKernelGGL((vit_relpos_win_kernel<64>), g2, dim3(256), 0, (hipStream_t)stream, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total, tok_stride);
     else
-      hipLaunchKernelGGL((vit_relpos_win_kernel<80>), g2, dim3(256), 0, (hipStream_t)stream, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total);
+      hipLaunchKernelGGL((vit_relpos_win_kernel<80>), g2, dim3(256), 0, (hipStream_t)stream, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total, tok_stride);
     RSP_CHECK_LAUNCH();
     return RSP_OK;
   }
@@ -228,11 +228,11 @@ extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const fl
   if (dh == 64) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_relpos_kernel<64>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((vit_relpos_kernel<64>), grid, dim3(256), smem, s, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total);
+    hipLaunchKernelGGL((vit_relpos_kernel<64>), grid, dim3(256), smem, s, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total, tok_stride);
   } else if (dh == 80) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_relpos_kernel<80>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    hipLaunchKernelGGL((vit_relpos_kernel<80>), grid, dim3(256), smem, s, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total);
+    hipLaunchKernelGGL((vit_relpos_kernel<80>), grid, dim3(256), smem, s, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total, tok_stride);
   } else {
     return RSP_EINVAL;
   }
@@ -240,3 +240,9 @@ extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const fl
   return RSP_OK;
 }
 
+
+extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const float* rel_pos_w,
+                              float* rel, int32_t Bp, int32_t S, int32_t nh, int32_t dh,
+                              rsp_stream_t stream) {
+  return rsp_vit_relpos_q(qkv, (int64_t)3 * nh * dh, rel_pos_h, rel_pos_w, rel, Bp, S, nh, dh, stream);
+}

@@ -244,7 +244,7 @@ def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30):
 
 def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, c_rowmap=None,
          M=None, out_rows=None, res_mod=0, a_scale_log2=DEFAULT_A_SCALE_LOG2, conv=None,
-         res_bmap=None, res_brows=0, out_planes=False, out_f32=True, dma="auto", tile_hint=0):
+         res_bmap=None, res_brows=0, out_planes=False, out_f32=True, dma="auto", tile_hint=0, c_ncols=0, pl_col0=0):
     """C = act(A @ W^T + bias) + res   (see RspGemmDesc in include/rsp_hip.h).
 
     a: [rows, K] fp32 (row stride = a.stride(0)) or, with conv=(k, stride, pad),
@@ -284,11 +284,14 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     n = w.N
     rows = m if out_rows is None else out_rows
     pl = None
+    if (c_ncols or pl_col0) and not (is_planes and out_planes):
+        raise ValueError('column-range outputs (c_ncols / pl_col0) belong to the plane path with out_planes=True')
     if out_planes:
-        pl = empty_planes((rows, n), a.device)
+        pl = empty_planes((rows, n - pl_col0), a.device)
         d.Chi, d.Clo, d.c_scale_log2, d.c_rows = pl.hi.data_ptr(), pl.lo.data_ptr(), pl.scale_log2, rows
+    d.c_ncols, d.pl_col0 = c_ncols, pl_col0
     if out is None and out_f32:
-        out = torch.empty((rows, n), dtype=torch.float32, device=a.device)
+        out = torch.empty((rows, c_ncols or n), dtype=torch.float32, device=a.device)
     if out is not None:
         _chk_f32(out, "out")
     if bias == "auto":
@@ -353,13 +356,35 @@ def layernorm(x, gamma, beta, eps=1e-6, act=ACT_NONE, out=None, planes=False, f3
     return out
 
 
-def vit_relpos(qkv, rel_pos_h, rel_pos_w, Bp, S, nh, dh):
+def vit_relpos(qkv, rel_pos_h, rel_pos_w, Bp, S, nh, dh, q_ld=None):
+    """q_ld: row stride of the tensor holding q in its first nh*dh columns (default: the [.., 3, nh, dh] qkv matrix)."""
     lib = _lib.load()
     rel = torch.empty((Bp * nh, S * S, 2 * S), dtype=torch.float32, device=qkv.device)
+    q_ld = 3 * nh * dh if q_ld is None else q_ld
     _timed('vit_relpos_kernel', 2.0 * Bp * nh * S * S * 2 * S * dh, 0,
-           lambda: _lib.check(lib.rsp_vit_relpos(qkv.data_ptr(), rel_pos_h.data_ptr(), rel_pos_w.data_ptr(),
-                                                 rel.data_ptr(), Bp, S, nh, dh, _stream()), "rsp_vit_relpos"))
+           lambda: _lib.check(lib.rsp_vit_relpos_q(qkv.data_ptr(), q_ld, rel_pos_h.data_ptr(), rel_pos_w.data_ptr(),
+                                                   rel.data_ptr(), Bp, S, nh, dh, _stream()), "rsp_vit_relpos_q"))
     return rel
+
+
+def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False):
+    """SAM ViT attention with q as fp32 rows [Bp*T, nh*dh] and K | V as the fp16 Planes [Bp*T, 2*nh*dh] the qkv GEMM
+    wrote (gemm(..., out_planes=True, c_ncols=D, pl_col0=D)).  planes=True: the output only as Planes."""
+    lib = _lib.load()
+    T, D = S * S, nh * dh
+    if not isinstance(kv, Planes) or kv.shape[-1] != 2 * D or kv.rows < Bp * T:
+        raise ValueError('kv must be the K | V planes of the qkv GEMM')
+    _chk_f32(q, 'q')
+    out = None if planes else torch.empty((Bp * T, D), dtype=torch.float32, device=q.device)
+    pl = empty_planes((Bp * T, D), q.device) if planes else None
+    hi, lo, e = (pl.hi.data_ptr(), pl.lo.data_ptr(), pl.scale_log2) if planes else (0, 0, 0)
+    kind = 'global' if T >= 1024 else 'window'
+    _timed('attn_global_kernel<vit>' if kind == 'global' else 'attn_kernel<vit,window>', 4.0 * Bp * nh * T * T * dh, 0,
+           lambda: _lib.check(lib.rsp_vit_attention_planes(q.data_ptr(), q.stride(0), kv.hi.data_ptr(), kv.lo.data_ptr(),
+                                                           kv.rows, kv.scale_log2, rel.data_ptr(), _ptr(out), hi, lo, e,
+                                                           Bp, S, nh, dh, scale, _stream()),
+                              "rsp_vit_attention_planes"))
+    return pl if planes else out
 
 
 _attn_ws = {}

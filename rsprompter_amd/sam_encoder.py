@@ -192,15 +192,18 @@ class SamVisionEncoderHIP(HIPModule):
             S = L['S']
             # GEMM A operands travel as fp16 (hi, lo) planes: LN / attention / GELU epilogues emit them
             xn = ops.layernorm(x, L['ln1'][0], L['ln1'][1], self.eps, planes=True, f32=False)
+            # qkv projection: q leaves as fp32 (rel-pos + the attention's Q operand), K | V as the fp16 planes the
+            # attention kernel DMAs -- no fp32 K / V tensor, no split pass, no transposed V (csrc/attn_stream.hip)
             if S == g:  # global attention layer
-                qkv = ops.gemm(xn, L['qkv'])
+                q, kv = ops.gemm(xn, L['qkv'], out_planes=True, c_ncols=D, pl_col0=D)
                 Bp, rowmap = B, None
             else:       # windowed: partition is a row gather in the qkv GEMM (pad rows -> bias only, HF:913-915)
                 rowmap, nw = self._window_map(B, x.device)
                 Bp = B * nw * nw
-                qkv = ops.gemm(xn, L['qkv'], a_rowmap=rowmap, M=Bp * S * S)
-            rel = ops.vit_relpos(qkv, L['rph'], L['rpw'], Bp, S, nh, dh)
-            att = ops.vit_attention(qkv, rel, Bp, S, nh, dh, scale, planes=True)
+                q, kv = ops.gemm(xn, L['qkv'], a_rowmap=rowmap, M=Bp * S * S, out_planes=True, c_ncols=D, pl_col0=D)
+            rel = ops.vit_relpos(q, L['rph'], L['rpw'], Bp, S, nh, dh, q_ld=D)
+            att = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=True)
+            qkv = (q, kv)
             # proj + window_unpartition + crop + residual (HF:830, 924-952, 969)
             x1 = ops.gemm(att, L['proj'], res=x, c_rowmap=rowmap, out_rows=B * T)
             del qkv, rel, att, xn

@@ -150,6 +150,51 @@ def test_vit_attention(dev, S, nh, dh, Bp):
     assert err < 2e-5          # both products fp16x3: fp32-class
 
 
+@pytest.mark.parametrize('S,nh,dh,Bp', [(14, 3, 64, 5), (64, 2, 64, 1), (14, 2, 80, 3), (64, 2, 80, 1), (32, 2, 64, 2),
+                                        (32, 2, 80, 2), (64, 4, 64, 2), (14, 16, 80, 9)])
+def test_vit_attention_planes(dev, S, nh, dh, Bp):
+    """the plane-fed attention (csrc/attn_stream.hip): q fp32 [Bp*T, D], K | V as the KB32 fp16 planes of [Bp*T, 2D]
+    (DMA key tiles, transposing LDS reads for V) against the fp64 restatement of HF:803-831."""
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(50 + S + dh)
+    T, D = S * S, nh * dh
+    qkv = torch.randn(Bp, T, 3, nh, dh, generator=g)
+    qkv[:, :, 0] *= 2.0   # sharper softmax
+    rph = torch.randn(2 * S - 1, dh, generator=g) * 0.2
+    rpw = torch.randn(2 * S - 1, dh, generator=g) * 0.2
+    scale = dh ** -0.5
+    ref, ref_rel = _ref_vit_attention(qkv, rph, rpw, S, nh, dh, scale)
+    q = qkv[:, :, 0].reshape(Bp * T, D).contiguous().to(dev)
+    kv = ops.to_planes(qkv[:, :, 1:].reshape(Bp * T, 2 * D).contiguous().to(dev))
+    rel = ops.vit_relpos(q, rph.to(dev), rpw.to(dev), Bp, S, nh, dh, q_ld=D)
+    assert float((rel.cpu().double() - ref_rel).abs().max()) < 2e-5
+    out = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale).view(Bp, T, D)
+    err = float((out.cpu().double() - ref).abs().max())
+    print('vit_attention_planes', S, nh, dh, Bp, 'max abs err', err)
+    assert err < 2e-5
+    pl = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=True)
+    assert float((_planes_to_f32(pl).view(Bp, T, D) - ref).abs().max()) < 2e-5
+
+
+def test_gemm_column_range_outputs(dev):
+    """rsp_gemm c_ncols / pl_col0 (the qkv projection's split hand-off): fp32 for the first D columns only, planes for
+    the rest, with a row-gather map and padded rows like the windowed layers."""
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(9)
+    M, K, D = 700, 256, 160
+    a = torch.randn(500, K, generator=g)
+    w = torch.randn(3 * D, K, generator=g) / K ** 0.5
+    b = torch.randn(3 * D, generator=g)
+    rowmap = torch.randint(-1, 500, (M,), generator=g, dtype=torch.int32)
+    src = torch.where((rowmap >= 0)[:, None], a[rowmap.clamp(min=0).long()], torch.zeros(1))
+    ref = src.double() @ w.double().t() + b.double()
+    pw = ops.PackedWeight(w, b, device=dev)
+    q, kv = ops.gemm(ops.to_planes(a.to(dev)), pw, a_rowmap=rowmap.to(dev), M=M, out_planes=True, c_ncols=D, pl_col0=D)
+    assert tuple(q.shape) == (M, D) and kv.shape == (M, 2 * D)
+    assert float((q.cpu().double() - ref[:, :D]).abs().max()) < 1e-5
+    assert float((_planes_to_f32(kv) - ref[:, D:]).abs().max()) < 1e-5
+
+
 def test_patchify_preprocess(dev):
     from rsprompter_amd import ops
     g = torch.Generator().manual_seed(6)

@@ -246,3 +246,77 @@ def test_detection_glue_restatements_match_reference_vectors():
         assert torch.equal(labels, c['labels'])
     m = d['map_roi_levels']
     assert torch.equal(glue.map_roi_levels(m['rois'], m['num_levels'], m['finest_scale']), m['out'])
+
+
+def test_mmcv_leaf_known_answers():
+    """Hand-derivable known-answer vectors for the mmcv LEAF ops whose source is not under /root/reference
+    (SURVEY.md App. B): the C / torch restatements (oracle/mmcv_ops.c, oracle/query.py) are checked by something other
+    than themselves.  Every expected value below follows from the operator's published definition by hand."""
+    import torch.nn as nn
+    from oracle import cops, glue
+    from oracle.query import FFN, MHA, MSDeformAttn
+
+    # ---- RoIAlign(aligned=True, sampling_ratio=0, avg) -------------------------------------------------------------
+    H = W = 16
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing='ij')
+    const = torch.full((1, 1, H, W), 3.25)
+    ramp = (2.0 * xs + 0.5 * ys)[None, None]                       # bilinear interpolation of a linear map is exact
+    feat = torch.cat([const, ramp], 1)
+    roi = torch.tensor([[0., 4., 8., 20., 24.]])                   # scale 0.5 -> x in [1.5, 9.5], y in [3.5, 11.5]
+    out = cops.roi_align(feat, roi, 2, 0.5, 0, True)
+    assert torch.allclose(out[0, 0], torch.full((2, 2), 3.25))
+    # the samples of a bin are symmetric about its centre, so the bin average of a linear map is its centre value
+    xc, yc = torch.tensor([3.5, 7.5]), torch.tensor([5.5, 9.5])
+    assert torch.allclose(out[0, 1], 2.0 * xc[None, :] + 0.5 * yc[:, None], atol=1e-5)
+    # a RoI hanging over the left border: samples with x < -1 contribute 0, samples in [-1, 0] are clamped to x = 0
+    roi2 = torch.tensor([[0., -8., 0., 0., 4.]])                   # scale 1: x in [-8.5, -0.5], one 1x1 bin, 8x4 samples
+    o2 = cops.roi_align(torch.ones(1, 1, H, W), roi2, 1, 1.0, 0, True)
+    assert abs(float(o2) - 1.0 / 8.0) < 1e-6                       # only the sample column x = -1.0 survives: 4 of 32
+    # ---- nms (offset 0, IoU > thr suppresses, strict) and batched_nms ----------------------------------------------
+    boxes = torch.tensor([[0., 0., 10., 10.], [1., 1., 11., 11.], [20., 20., 30., 30.], [0., 0., 10., 5.]])
+    scores = torch.tensor([0.9, 0.8, 0.7, 0.6])
+    # IoU(0,1) = 81 / 119 = 0.6807;  IoU(0,3) = 50 / 100 = 0.5 EXACTLY;  IoU(1,3) = 36 / 114
+    assert cops.nms(boxes, scores, 0.7)[1].tolist() == [0, 1, 2, 3]
+    assert cops.nms(boxes, scores, 0.6)[1].tolist() == [0, 2, 3]                 # box 1 goes (0.6807 > 0.6)
+    assert cops.nms(boxes, scores, 0.5)[1].tolist() == [0, 2, 3]                 # 0.5 is NOT > 0.5: box 3 stays
+    assert cops.nms(boxes, scores, 0.49)[1].tolist() == [0, 2]
+    tie = torch.tensor([0.5, 0.5, 0.5, 0.5])
+    assert cops.nms(boxes, tie, 0.6)[1].tolist() == [0, 2, 3]                    # stable order on exact ties
+    _, keep = glue.batched_nms(boxes, scores, torch.tensor([0, 1, 0, 1]), 0.35)  # same-id pair (1, 3): IoU 36/114 = 0.316
+    assert sorted(keep.tolist()) == [0, 1, 2, 3]                                 # different ids never suppress each other
+    _, keep = glue.batched_nms(boxes, scores, torch.tensor([0, 0, 0, 0]), 0.35)
+    assert sorted(keep.tolist()) == [0, 2]
+    # ---- MultiScaleDeformableAttention: zero offsets + uniform weights + identity projections ----------------------
+    torch.manual_seed(0)
+    m = MSDeformAttn(dim=8, heads=2, levels=2, points=2)
+    with torch.no_grad():
+        for lin in (m.sampling_offsets, m.attention_weights):
+            lin.weight.zero_(); lin.bias.zero_()                  # offsets 0, logits 0 -> softmax = 1 / (L * P)
+        for lin in (m.value_proj, m.output_proj):
+            lin.weight.copy_(torch.eye(8)); lin.bias.zero_()
+    shapes = torch.tensor([[2, 2], [1, 1]])
+    q = torch.arange(5 * 8, dtype=torch.float32).view(1, 5, 8) / 10.0             # tokens: 4 of level 0, 1 of level 1
+    # reference point = centre of pixel (y=1, x=0) of the 2x2 level == centre region of the 1x1 level
+    ref = torch.tensor([0.25, 0.75]).view(1, 1, 1, 2).repeat(1, 5, 2, 1)
+    out = m(q, torch.zeros_like(q), ref, shapes)
+    # sampling AT a pixel centre returns that pixel: level 0 -> token 2 (row 1, col 0); level 1: (0.25, 0.75) of a 1x1 map
+    # is bilinear between the pixel (weight 0.75 * 0.75) and the zero padding -> 0.5625 * token 4
+    want = q + 0.5 * (q[:, 2:3] + 0.5625 * q[:, 4:5])
+    assert torch.allclose(out, want, atol=1e-6)
+    # ---- MultiheadAttention wrapper: q = query + query_pos, k = key + key_pos, v = value, + identity ----------------
+    a = MHA(dim=8, heads=2)
+    with torch.no_grad():
+        a.attn.in_proj_weight.copy_(torch.cat([torch.eye(8)] * 3)); a.attn.in_proj_bias.zero_()
+        a.attn.out_proj.weight.copy_(torch.eye(8)); a.attn.out_proj.bias.zero_()
+    qq, kk = torch.randn(1, 3, 8), torch.randn(1, 4, 8)
+    mask = torch.ones(2, 3, 4, dtype=torch.bool)
+    mask[:, :, 1] = False                                          # every query may only see key 1
+    got = a(qq, kk, kk * 2.0, torch.randn(1, 3, 8), torch.randn(1, 4, 8), mask)
+    assert torch.allclose(got, qq + (kk * 2.0)[:, 1:2].expand(1, 3, 8), atol=1e-6)   # the VALUE has no positional term
+    # ---- FFN: x + Linear(ReLU(Linear(x))) --------------------------------------------------------------------------
+    f = FFN(4, 6)
+    x = torch.randn(2, 4)
+    with torch.no_grad():
+        w0, b0 = f.layers[0][0].weight, f.layers[0][0].bias
+        w1, b1 = f.layers[1].weight, f.layers[1].bias
+        assert torch.allclose(f(x), x + torch.relu(x @ w0.t() + b0) @ w1.t() + b1, atol=1e-6)

@@ -31,7 +31,7 @@ class PackedWeight:
 
 def gemm(a, w, *, out=None, bias='auto', res=None, act=0, a_rowmap=None, c_rowmap=None, M=None, out_rows=None,
          res_mod=0, a_scale_log2=6, conv=None, res_bmap=None, res_brows=0, out_planes=False, out_f32=True,
-         dma='auto'):
+         dma='auto', tile_hint=0, c_ncols=0, pl_col0=0):
     if conv is not None:
         k, s, p = conv
         B, H, W, C = a.shape
@@ -63,6 +63,8 @@ def gemm(a, w, *, out=None, bias='auto', res=None, act=0, a_rowmap=None, c_rowma
             rr = res_bmap.long()[rr // res_brows] * res_brows + rr % res_brows
         y = y + res[rr]
     out[crow[keep]] = y[keep]
+    if c_ncols or pl_col0:       # column-range outputs: fp32 = first c_ncols columns, "planes" = columns from pl_col0 on
+        return out[:, :c_ncols].contiguous(), out[:, pl_col0:].contiguous()
     return (out, out) if (out_planes and out_f32) else out
 
 
@@ -72,9 +74,12 @@ def layernorm(x, gamma, beta, eps=1e-6, act=0, out=None, planes=False, f32=True)
     return (y, y) if (planes and f32) else y
 
 
-def vit_relpos(qkv, rph, rpw, Bp, S, nh, dh):
+def vit_relpos(qkv, rph, rpw, Bp, S, nh, dh, q_ld=None):
     T = S * S
-    q = qkv.view(Bp, T, 3, nh, dh)[:, :, 0].permute(0, 2, 1, 3).reshape(Bp * nh, S, S, dh)
+    if q_ld is not None and q_ld == nh * dh:
+        q = qkv.view(Bp, T, nh, dh).permute(0, 2, 1, 3).reshape(Bp * nh, S, S, dh)
+    else:
+        q = qkv.view(Bp, T, 3, nh, dh)[:, :, 0].permute(0, 2, 1, 3).reshape(Bp * nh, S, S, dh)
     idx = torch.arange(S)[:, None] - torch.arange(S)[None, :] + (S - 1)
     rh = torch.einsum('bhwc,hkc->bhwk', q, rph[idx])
     rw = torch.einsum('bhwc,wkc->bhwk', q, rpw[idx])
@@ -88,6 +93,12 @@ def vit_attention(qkv, rel, Bp, S, nh, dh, scale, planes=False):
     bias = rel[..., :S].reshape(-1, T, S, 1) + rel[..., S:].reshape(-1, T, 1, S)
     attn = (attn.view(-1, T, S, S) + bias).view(-1, T, T).softmax(-1)
     return (attn @ v).view(Bp, nh, T, dh).permute(0, 2, 1, 3).reshape(Bp * T, nh * dh)
+
+
+def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False):
+    T = S * S
+    qkv = torch.cat([q.view(Bp * T, 1, nh * dh), kv.view(Bp * T, 2, nh * dh)], 1)
+    return vit_attention(qkv.reshape(Bp * T, 3 * nh * dh), rel, Bp, S, nh, dh, scale)
 
 
 def patchify(img, patch):

@@ -70,18 +70,19 @@ def main():
     if 'attn' in what:
         for name, Bp, S in (('attn_global', B, 64), ('attn_window', B * 25, 14)):
             Tt = S * S
-            qkv = torch.randn(Bp * Tt, 3 * D, device=dev)
+            q = torch.randn(Bp * Tt, D, device=dev)
+            kv = ops.to_planes(torch.randn(Bp * Tt, 2 * D, device=dev))
             rph = torch.randn(2 * S - 1, dh, device=dev) * 0.05
             rpw = torch.randn(2 * S - 1, dh, device=dev) * 0.05
 
-            def fn():
-                rel = ops.vit_relpos(qkv, rph, rpw, Bp, S, nh, dh)
-                return ops.vit_attention(qkv, rel, Bp, S, nh, dh, dh ** -0.5, planes=True)
+            def fn():      # the encoder's sequence: rel-pos terms, then the plane-fed attention (csrc/attn_stream.hip)
+                rel = ops.vit_relpos(q, rph, rpw, Bp, S, nh, dh, q_ld=D)
+                return ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, dh ** -0.5, planes=True)
             ms = timed(fn, args.iters)
             fl = 4.0 * Bp * nh * Tt * Tt * dh
             print(json.dumps(dict(group=name, Bp=Bp, S=S, nh=nh, dh=dh, ms_with_relpos=round(ms, 4),
                                   tflops_with_relpos=round(fl / ms / 1e9, 1), launches=args.iters + 1)), flush=True)
-            del qkv
+            del q, kv
     if 'ln' in what:
         x = torch.randn(Mg, D, device=dev)
         g, b = torch.ones(D, device=dev), torch.zeros(D, device=dev)
