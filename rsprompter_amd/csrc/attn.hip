@@ -15,7 +15,6 @@
 // (P^T) of the PV MFMA for k-step s, provided the A operand (V^T) is read with
 // the same key permutation  slot t<4 -> key 16s+4hh+t, t>=4 -> key 16s+8+4hh+t-4.
 // No LDS round trip and no cross-lane traffic for P.
-#include <cstdlib>
 #include <type_traits>
 #include "rsp_common.h"
 
@@ -49,7 +48,6 @@ struct AttnP {
   int64_t o_bs, o_ts, o_hs;
   int Tq, Tk, S, nh;
   float scale;
-  int skew;                     // tuning probe: s_sleep units for the second wave of every SIMD (window kernel)
 };
 
 // REL: decomposed rel-pos bias (ViT; requires Tq == Tk == S*S): 0 = none, 1 = S == 64 (a key tile is one key row:
@@ -467,9 +465,6 @@ __global__ __launch_bounds__(448) void attn_window_kernel(const AttnP p) {
     }
   }
   __syncthreads();                      // the only barrier: K / V^T are complete
-  if (p.skew > 0 && wave >= 4) {        // probe: put the second wave of a SIMD half a tile out of phase
-    for (int i = 0; i < p.skew; ++i) __builtin_amdgcn_s_sleep(8);
-  }
 
   f32x16 acc_o[DBLK];
 #pragma unroll
@@ -636,7 +631,6 @@ extern "C" int rsp_vit_attention_ex(const float* qkv, const float* rel, float* o
   p.q_hs = p.k_hs = p.v_hs = dh;
   p.o_bs = (int64_t)T * D; p.o_ts = D; p.o_hs = dh;
   p.Tq = T; p.Tk = T; p.S = S; p.nh = nh; p.scale = scale;
-  { const char* e = getenv("RSP_ATTN_SKEW"); p.skew = e ? atoi(e) : 0; }
   hipStream_t s = (hipStream_t)stream;
   if (S == 14) {   // the SAM window size: whole-window-resident kernel
     if (dh == 64) return launch_attn_window<64>(p, Bp, s);
@@ -668,7 +662,7 @@ extern "C" int rsp_attention(const RspAttnDesc* d, rsp_stream_t stream) {
   p.k_bs = d->k_bs; p.k_ts = d->k_ts; p.k_hs = d->k_hs;
   p.v_bs = d->v_bs; p.v_ts = d->v_ts; p.v_hs = d->v_hs;
   p.o_bs = d->o_bs; p.o_ts = d->o_ts; p.o_hs = d->o_hs;
-  p.Tq = d->Tq; p.Tk = d->Tk; p.S = 0; p.nh = d->nh; p.scale = d->scale; p.skew = 0;
+  p.Tq = d->Tq; p.Tk = d->Tk; p.S = 0; p.nh = d->nh; p.scale = d->scale;
   hipStream_t s = (hipStream_t)stream;
   switch (d->dh) {
     case 16: return p.mask ? launch_attn<16, 0, true>(p, d->B, s) : launch_attn<16, 0, false>(p, d->B, s);
