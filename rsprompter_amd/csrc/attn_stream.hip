@@ -22,6 +22,12 @@
 //     LDS: 3 x 23.5 KB -> two blocks per CU, so one block's prologue (q fragments, first tile) hides under the other's
 //     matrix work.  The old kernel staged the whole window (153 KB, one block per CU) through registers with a split pass.
 //   * global layers (KT = 64, 8 waves): same structure as attn_global.hip minus the split pass and its HBM round trip.
+//   * What bounds it (round 2, measured): VALU ISSUE.  The loop carries 6.3 (global) / 10.9 (windows) VALU instructions
+//     per MFMA -- bias fma, max, exponent shift, exp2, row sum, the 3-instruction P split, accumulator rescale -- and a
+//     SIMD fits about 5 beside a 32-cycle MFMA.  Three restructurings that do NOT touch that count changed nothing:
+//     register-pipelined LDS fragment reads (kept), a software-pipelined tile loop with QK^T of tile t + 1 interleaved
+//     into the softmax of tile t by sched_group_barrier (ISA showed the interleave; 3.26 vs 3.13 ms, removed), and
+//     de-phasing the two waves of a SIMD (no change).  The remaining lever is fewer VALU instructions per score.
 #include <type_traits>
 #include "rsp_common.h"
 
@@ -36,6 +42,11 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef short v4s __attribute__((ext_vector_type(4)));
 
 __device__ uint4 g_zero16s[4];                // zero page: padded V chunks, keys beyond the window
+// dh = 80 leaves V^T rows 80..95 of the third 32-row block unused: the chunk behind the real ones carries 1.0 at d = 80
+// and d = 84 (hi plane), so accumulator register 8 of that block is sum_k P[k] for the lane's query in BOTH half waves --
+// the softmax denominator comes out of the PV MFMAs (rescaled with the rest) instead of 16-32 VALU adds per tile.
+__device__ const _Float16 g_ones16s[8] = {(_Float16)1.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f,
+                                          (_Float16)1.0f, (_Float16)0.0f, (_Float16)0.0f, (_Float16)0.0f};
 
 __device__ __forceinline__ void split8s(const float* x, half8_t& hi, half8_t& lo) {
 #pragma unroll
@@ -100,6 +111,7 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   constexpr int NDMA = (TILE_UNITS + NT - 1) / NT;
   constexpr int BUF_BYTES = (TILE_UNITS * 16 + 1023) / 1024 * 1024;   // lanes past the image are masked off the DMA
   constexpr int WT = 196, WS = 14;                    // window tokens / side
+  constexpr bool LSUM_MFMA = (DH % 32) != 0;          // spare V^T rows exist: row sums through the MFMA (see g_ones16s)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF][BUF_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -145,6 +157,10 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
       colbase = p.D;
       real = c < KCH;
     }
+    if (LSUM_MFMA && u >= 2 * K_UNITS && u < 2 * K_UNITS + V_UNITS && !real && c == KCH) {
+      dsrc[i] = reinterpret_cast<const unsigned char*>(g_ones16s);      // hi plane, first padding chunk: the ones
+      drow[i] = -2;                                                     // constant source, valid for every tile
+    }
     if (real) {
       const int col = colbase + h * DH + c * 8;
       const half_t* base = pl == 0 ? p.kv_hi : p.kv_lo;
@@ -157,7 +173,7 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
       const bool ok = drow[i] >= 0 && (!WINDOW || kt * KT + drow[i] < WT);
-      const unsigned char* src = ok ? dsrc[i] + (int64_t)kt * (KT * 64) : zero;
+      const unsigned char* src = ok ? dsrc[i] + (int64_t)kt * (KT * 64) : (drow[i] == -2 ? dsrc[i] : zero);
       if ((i + 1) * NT <= TILE_UNITS || i * NT + tid < TILE_UNITS)     // the last instruction may be partly masked
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (i * NT + wave * 64) * 16), 16, 0, 0);
     }
@@ -186,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   // ---- rel-pos bias in the log2 domain ----
   // window: 14 + 14 scalars per query; global: rel_w of this lane's key columns (tile invariant) + one rel_h per key row
   float bHw[WINDOW ? WS : 1], bWw[WINDOW ? WS : 1];
-  float bw[NBLK][16];
+  float bw[2][16];                                    // rel_w of key columns 0..31 and 32..63 (mod S) for this lane
   const float* rq = rel_b + (int64_t)(qv ? q : 0) * (2 * S);
   if constexpr (WINDOW) {
 #pragma unroll
@@ -197,7 +213,7 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
     }
   } else {
 #pragma unroll
-    for (int blk = 0; blk < NBLK; ++blk)
+    for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int kl = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -246,23 +262,32 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
     const unsigned char* sV0 = sb + 2 * K_UNITS * 16;
     const unsigned char* sV1 = sb + (2 * K_UNITS + V_UNITS) * 16;
 
-    // ---- S^T = K Q^T ----
+    // ---- S^T = K Q^T, register-pipelined: the K fragments of step i + 1 are read from LDS before the three MFMAs of
+    // step i are issued (with 1-2 waves per SIMD nothing else hides the ~130-cycle LDS latency; PMC r2: 39 % issue stalls)
     f32x16 sc[NBLK];
 #pragma unroll
-    for (int blk = 0; blk < NBLK; ++blk) {
+    for (int blk = 0; blk < NBLK; ++blk)
 #pragma unroll
       for (int r = 0; r < 16; ++r) sc[blk][r] = 0.f;
-      const int row = blk * 32 + l31;
-#pragma unroll
-      for (int st = 0; st < DSTEPS; ++st) {
+    {
+      half8_t kfh[2], kfl[2];
+      auto kread = [&](int blk, int st, half8_t& h8, half8_t& l8) {
+        const int row = blk * 32 + l31;
         const int c = st * 2 + hh;
         const int off = row * (KCPR * 8) + ((KSWZ ? (c ^ ((row >> 1) & 7)) : c) << 3);     // halves
-        const half8_t kh8 = *reinterpret_cast<const half8_t*>(sK0 + off);
-        const half8_t kl8 = *reinterpret_cast<const half8_t*>(sK1 + off);
-        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl8, qh[st], sc[blk], 0, 0, 0);
-        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qlo[st], sc[blk], 0, 0, 0);
-        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh8, qh[st], sc[blk], 0, 0, 0);
-      }
+        h8 = *reinterpret_cast<const half8_t*>(sK0 + off);
+        l8 = *reinterpret_cast<const half8_t*>(sK1 + off);
+      };
+      kread(0, 0, kfh[0], kfl[0]);
+      static_for_s<0, NBLK * DSTEPS>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, blk = i / DSTEPS, st = i % DSTEPS, cur = i & 1;
+        if constexpr (i + 1 < NBLK * DSTEPS) kread((i + 1) / DSTEPS, (i + 1) % DSTEPS, kfh[cur ^ 1], kfl[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);        // keep the next step's reads AHEAD of this step's matrix work
+        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[cur], qh[st], sc[blk], 0, 0, 0);
+        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], qlo[st], sc[blk], 0, 0, 0);
+        sc[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], qh[st], sc[blk], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      });
     }
 
     // ---- bias + online softmax in the log2 domain (per-lane query column) ----
@@ -309,10 +334,10 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
       for (int r = 0; r < 16; ++r) {
         const float pv = __builtin_amdgcn_exp2f(sc[blk][r] + kk);
         sc[blk][r] = pv;
-        psum += pv;
+        if constexpr (!LSUM_MFMA) psum += pv;
       }
     }
-    l_run = l_run * alpha + psum;
+    if constexpr (!LSUM_MFMA) l_run = l_run * alpha + psum;
     m_run = m_new;
     if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {   // no lane saw a new maximum: skip the 16 DBLK multiplies
 #pragma unroll
@@ -321,28 +346,39 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
         for (int r = 0; r < 16; ++r) acc_o[db][r] *= alpha;
     }
 
-    // ---- O^T += V^T P^T : V^T fragments through the transposing LDS read ----
-#pragma unroll
-    for (int s = 0; s < KT / 16; ++s) {
-      float pf[8];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) pf[t] = sc[s >> 1][8 * (s & 1) + t];
+    // ---- O^T += V^T P^T : V^T fragments through the transposing LDS read, register-pipelined like the K reads:
+    // the four reads of step (s, db) + 1 are issued before the MFMAs of step (s, db); the P split of 16-key step s is
+    // VALU work that runs while the first reads of that step are in flight
+    {
+      typedef __attribute__((address_space(3))) v4s* lv4;
+      v4s va[2][4];                                        // [buffer][hi k0..3, hi k8..11, lo k0..3, lo k8..11]
+      auto vread = [&](int s_, int db, v4s* f) {
+        const int off = v_lane_off + (16 * s_) * (VCPR * 16) + db * 64;      // bytes: key 16 s (+ 8), d block db
+        f[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sV0 + off));
+        f[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sV0 + off + 8 * (VCPR * 16)));
+        f[2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sV1 + off));
+        f[3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sV1 + off + 8 * (VCPR * 16)));
+      };
+      constexpr int NS = KT / 16, NSTEP = NS * DBLK;
+      vread(0, 0, va[0]);
       half8_t ph, pl;
-      split8_fast(pf, ph, pl);
+      static_for_s<0, NSTEP>([&](auto ic) {
+        constexpr int i = decltype(ic)::value, s_ = i / DBLK, db = i % DBLK, cur = i & 1;
+        if constexpr (db == 0) {
+          float pf[8];
 #pragma unroll
-      for (int db = 0; db < DBLK; ++db) {
-        const int off = v_lane_off + (16 * s) * (VCPR * 16) + db * 64;      // bytes: key 16 s (+ 8), d block db
-        typedef __attribute__((address_space(3))) v4s* lv4;
-        const v4s a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sV0 + off));
-        const v4s a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sV0 + off + 8 * (VCPR * 16)));
-        const v4s b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sV1 + off));
-        const v4s b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sV1 + off + 8 * (VCPR * 16)));
+          for (int t = 0; t < 8; ++t) pf[t] = sc[s_ >> 1][8 * (s_ & 1) + t];
+          split8_fast(pf, ph, pl);
+        }
+        if constexpr (i + 1 < NSTEP) vread((i + 1) / DBLK, (i + 1) % DBLK, va[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
         union { v4s s4[2]; half8_t h8; } uh, ul;
-        uh.s4[0] = a0; uh.s4[1] = a1; ul.s4[0] = b0; ul.s4[1] = b1;
+        uh.s4[0] = va[cur][0]; uh.s4[1] = va[cur][1]; ul.s4[0] = va[cur][2]; ul.s4[1] = va[cur][3];
         acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul.h8, ph, acc_o[db], 0, 0, 0);
         acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh.h8, pl, acc_o[db], 0, 0, 0);
         acc_o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh.h8, ph, acc_o[db], 0, 0, 0);
-      }
+        __builtin_amdgcn_sched_barrier(0);
+      });
     }
   };
 
@@ -360,7 +396,8 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   }
 
   // ---- normalise and store: lane holds O[q][d], d = db*32 + (r&3) + 8*(r>>2) + 4*hh ----
-  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  // denominator: per-lane partial sums (both half waves hold half of the keys) or the MFMA row sum (all keys already)
+  const float l_tot = LSUM_MFMA ? acc_o[DBLK - 1][8] : l_run + __shfl_xor(l_run, 32, 64);
   if (qv) {
     const float inv = ldexpf(1.0f, -p.kv_e) / l_tot;
     float* dst = p.out ? p.out + (row0 + q) * p.D + (int64_t)h * DH : nullptr;
