@@ -344,6 +344,12 @@ int rsp_preprocess(const void* src, int32_t src_is_u8, float* dst, int32_t H, in
                    int32_t Hp, int32_t Wp, const float* mean3, const float* std3,
                    int32_t swap_rb, float pad_value, rsp_stream_t stream);
 
+/* FCNMaskHead._predict_by_feat_single + _do_paste_mask (fcn_mask_head.py:276-480; the mask post-process of the       */
+/* SAMSegMaskRCNN sibling model, models.py:1219-1244): logits [k, Hm, Wm, C] NHWC, labels [k] (NULL / C == 1: class   */
+/* agnostic), boxes [k, 4] in output-image coordinates -> out bool [k, img_h, img_w] (sigmoid, bilinear paste, >= thr). */
+int rsp_paste_masks(const float* logits, const int32_t* labels, const float* boxes, int32_t k, int32_t Hm, int32_t Wm,
+                    int32_t C, int32_t img_h, int32_t img_w, float thr, uint8_t* out, rsp_stream_t stream);
+
 /* Test-pipeline front end: `Resize(scale, keep_ratio=True)` + `Pad(size, pad_val)`                       */
 /* (configs/rsprompter/_base_/rsprompter_anchor.py:231-241; mmdet/datasets/transforms/transforms.py:134-247 */
 /* and :704-786 over mmcv.imrescale / cv2.resize INTER_LINEAR and mmcv.impad), optionally fused with the     */

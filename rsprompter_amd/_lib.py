@@ -98,6 +98,8 @@ PROTOTYPES = {
     "rsp_vit_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "rsp_preprocess": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int,
                                ctypes.POINTER(c_float), ctypes.POINTER(c_float), c_int, c_float, c_void_p]),
+    "rsp_paste_masks": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p,
+                                c_void_p]),
     "rsp_resize_pad": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                ctypes.POINTER(c_float), c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
                                c_void_p]),

@@ -570,3 +570,111 @@ class RSPrompterAnchorRoIPromptHead(HIPModule):
             results = self.predict_mask(x, metas, results, rescale=rescale, image_embeddings=image_embeddings,
                                         image_positional_embeddings=image_positional_embeddings, pes=pes)
         return results
+
+
+# ----------------------------------------------------------------------------- SAMSeg sibling model
+@MODELS.register_module()
+class FCNMaskHead(HIPModule):
+    """mmdet/models/roi_heads/mask_heads/fcn_mask_head.py:27-150 (the mask head of configs/rsprompter/_base_/
+    samseg-maskrcnn.py:117-124): num_convs x (3x3 conv + ReLU) -> ConvTranspose2d(k2, s2) + ReLU -> 1x1 conv to
+    num_classes logits at 2 x roi_feat_size; `_predict_by_feat_single` pastes them into the image (:276-420)."""
+
+    def __init__(self, num_convs=4, roi_feat_size=14, in_channels=256, conv_kernel_size=3, conv_out_channels=256,
+                 num_classes=80, class_agnostic=False, upsample_cfg=None, conv_cfg=None, norm_cfg=None,
+                 predictor_cfg=None, loss_mask=None, init_cfg=None):
+        super().__init__()
+        up = dict(upsample_cfg or dict(type='deconv', scale_factor=2))
+        if up.get('type') != 'deconv' or up.get('scale_factor', 2) != 2 or conv_kernel_size != 3 or norm_cfg is not None:
+            raise NotImplementedError('FCNMaskHead: 3x3 convs without norm + deconv x2 (the SAMSeg configuration)')
+        self.num_convs, self.in_channels, self.conv_out_channels = num_convs, in_channels, conv_out_channels
+        self.num_classes, self.class_agnostic = num_classes, class_agnostic
+        c = conv_out_channels
+        for i in range(num_convs):
+            add_param(self, f'convs.{i}.conv.weight', (c, in_channels if i == 0 else c, 3, 3))
+            add_param(self, f'convs.{i}.conv.bias', (c,))
+        add_param(self, 'upsample.weight', (c if num_convs > 0 else in_channels, c, 2, 2))
+        add_param(self, 'upsample.bias', (c,))
+        nout = 1 if class_agnostic else num_classes
+        add_param(self, 'conv_logits.weight', (nout, c, 1, 1))
+        add_param(self, 'conv_logits.bias', (nout,))
+
+    def _pack(self):
+        from .necks import conv3x3_weight, convt_weights
+        P = dict(convs=[])
+        for i in range(self.num_convs):
+            cv = _get(self, f'convs.{i}.conv')
+            P['convs'].append(ops.PackedWeight(conv3x3_weight(cv.weight.detach()), cv.bias))
+        P['up'] = convt_weights(self.upsample.weight, self.upsample.bias)
+        nout = self.conv_logits.weight.shape[0]
+        P['logits'] = ops.PackedWeight(self.conv_logits.weight.detach().reshape(nout, -1), self.conv_logits.bias)
+        self._packed = P
+
+    def forward(self, x):
+        """[K, C, s, s] (channels-last) -> mask logits [K, nc, 2s, 2s] (a channels-last view of [K, 2s, 2s, nc])."""
+        if self._packed is None:
+            self._pack()
+        P = self._packed
+        y = nhwc_view(x)
+        K, h, w, _ = y.shape
+        for pw in P['convs']:
+            y = ops.gemm(y, pw, act=ops.ACT_RELU, conv=(3, 1, 1)).view(K, h, w, -1)
+        y = ops.conv_transpose2x2(y, P['up'][0], P['up'][1], act=ops.ACT_RELU)
+        lg = ops.gemm(y.reshape(K * 4 * h * w, -1), P['logits'])
+        return nchw_view(lg.view(K, 2 * h, 2 * w, -1))
+
+    def predict_by_feat(self, mask_preds, results_list, batch_img_metas, rcnn_test_cfg, rescale=False,
+                        activate_map=False):
+        """fcn_mask_head.py:218-276."""
+        assert len(mask_preds) == len(results_list) == len(batch_img_metas) and not activate_map
+        for mp, results, meta in zip(mask_preds, results_list, batch_img_metas):
+            if results.bboxes.shape[0] == 0:
+                h, w = meta['ori_shape'][:2]
+                if not rescale:
+                    sf_w, sf_h = meta['scale_factor']
+                    h, w = int(np.round(h * np.float32(sf_h))), int(np.round(w * np.float32(sf_w)))
+                results.masks = torch.zeros((0, h, w), dtype=torch.bool, device=results.bboxes.device)
+                continue
+            results.masks = self._predict_by_feat_single(mp, results, meta, rcnn_test_cfg, rescale)
+        return results_list
+
+    def _predict_by_feat_single(self, mask_preds, results, img_meta, rcnn_test_cfg, rescale=False):
+        """fcn_mask_head.py:276-420: boxes to the output image's coordinates (in place, like the reference), then
+        sigmoid + per-box bilinear paste + threshold in one kernel."""
+        sf_w, sf_h = img_meta['scale_factor']
+        img_h, img_w = img_meta['ori_shape'][:2]
+        if rescale:
+            results.bboxes = ops.div_boxes(results.bboxes, (sf_w, sf_h, sf_w, sf_h))
+        else:
+            img_h = int(np.round(img_h * np.float32(sf_h)))
+            img_w = int(np.round(img_w * np.float32(sf_w)))
+        thr = rcnn_test_cfg['mask_thr_binary'] if isinstance(rcnn_test_cfg, dict) else rcnn_test_cfg.mask_thr_binary
+        if thr < 0:
+            raise NotImplementedError('mask_thr_binary < 0 (uint8 soft masks) is not used by the RSPrompter configs')
+        lg = nhwc_view(mask_preds)
+        labels = None if self.class_agnostic else results.labels
+        return ops.paste_masks(lg, labels, results.bboxes, (img_h, img_w), float(thr))
+
+
+def _get(root, dotted):
+    for part in dotted.split('.'):
+        root = getattr(root, part)
+    return root
+
+
+@MODELS.register_module()
+class StandardRoIHead(RSPrompterAnchorRoIPromptHead):
+    """mmdet/models/roi_heads/standard_roi_head.py:19-424 (inference): the RSPrompter RoI head without the extra
+    positional encoding and with a mask head that consumes RoI features only (FCNMaskHead)."""
+
+    def __init__(self, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None,
+                 shared_head=None, train_cfg=None, test_cfg=None, init_cfg=None):
+        super().__init__(with_extra_pe=False, bbox_roi_extractor=bbox_roi_extractor, bbox_head=bbox_head,
+                         mask_roi_extractor=mask_roi_extractor, mask_head=mask_head, shared_head=shared_head,
+                         train_cfg=train_cfg, test_cfg=test_cfg, init_cfg=init_cfg)
+
+    def _mask_forward(self, x, rois, image_embeddings=None, image_positional_embeddings=None, pes=None):
+        """standard_roi_head.py:257-291."""
+        ext = self.mask_roi_extractor if self.mask_roi_extractor is not None else self.bbox_roi_extractor
+        n = ext.num_inputs
+        mask_feats = ext(x[:n], rois)
+        return dict(mask_preds=self.mask_head(mask_feats), mask_feats=mask_feats)

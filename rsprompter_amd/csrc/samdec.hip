@@ -145,3 +145,75 @@ extern "C" int rsp_mask_post(const float* low_res, float* sig_ws, int32_t k, int
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// FCNMaskHead._predict_by_feat_single + _do_paste_mask (mmdet/models/roi_heads/mask_heads/fcn_mask_head.py:276-480),
+// the mask post-processing of the standard Mask R-CNN head the SAMSeg sibling models use (models.py:1219-1244):
+// sigmoid of the (class-selected) 28x28 logits, F.grid_sample(bilinear, zeros, align_corners=False) of the probability
+// map at every pixel centre of the image with the box as the sampling window, >= thr.  One thread per 4 output pixels.
+namespace {
+
+__global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restrict__ logits, const int32_t* __restrict__ labels,
+                                                          const float* __restrict__ boxes, int Hm, int Wm, int C,
+                                                          int img_h, int img_w, float thr, uint8_t* __restrict__ out) {
+  const int n = blockIdx.y;
+  const int cls = (labels && C > 1) ? labels[n] : 0;
+  const float x0 = boxes[n * 4 + 0], y0 = boxes[n * 4 + 1], x1 = boxes[n * 4 + 2], y1 = boxes[n * 4 + 3];
+  const float* m = logits + (int64_t)n * Hm * Wm * C + cls;          // NHWC: pixel stride C
+  // the reference's CPU path pastes one instance per chunk with skip_empty=True (:390-404, :452-461): only the region
+  // [floor(x0) - 1, ceil(x1) + 1) x [floor(y0) - 1, ceil(y1) + 1), clamped to the image, is written (the rest stays 0)
+  const int rx0 = (int)fmaxf(floorf(x0) - 1.0f, 0.0f), ry0 = (int)fmaxf(floorf(y0) - 1.0f, 0.0f);
+  const int rx1 = (int)fminf(ceilf(x1) + 1.0f, (float)img_w), ry1 = (int)fminf(ceilf(y1) + 1.0f, (float)img_h);
+  const int64_t npix4 = ((int64_t)img_h * img_w + 3) / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < npix4; i += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t pix = i * 4 + e;
+      if (pix >= (int64_t)img_h * img_w) break;
+      const int py = (int)(pix / img_w), px = (int)(pix - (int64_t)py * img_w);
+      if (px < rx0 || px >= rx1 || py < ry0 || py >= ry1) continue;
+      // normalised coordinates exactly as the reference forms them: (p + 0.5 - lo) / (hi - lo) * 2 - 1, inf -> 0
+      float gx = ((float)px + 0.5f - x0) / (x1 - x0) * 2.0f - 1.0f;
+      float gy = ((float)py + 0.5f - y0) / (y1 - y0) * 2.0f - 1.0f;
+      if (isinf(gx)) gx = 0.f;
+      if (isinf(gy)) gy = 0.f;
+      const float ix = ((gx + 1.0f) * (float)Wm - 1.0f) / 2.0f, iy = ((gy + 1.0f) * (float)Hm - 1.0f) / 2.0f;
+      const float fx = floorf(ix), fy = floorf(iy);
+      const int xw = (int)fx, yn = (int)fy;
+      const float wx1 = ix - fx, wy1 = iy - fy, wx0 = 1.0f - wx1, wy0 = 1.0f - wy1;
+      auto prob = [&](int yy, int xx) -> float {
+        if (xx < 0 || xx >= Wm || yy < 0 || yy >= Hm) return 0.f;
+        const float l = m[((int64_t)yy * Wm + xx) * C];
+        return 1.0f / (1.0f + expf(-l));
+      };
+      float v = prob(yn, xw) * (wx0 * wy0);
+      v += prob(yn, xw + 1) * (wx1 * wy0);
+      v += prob(yn + 1, xw) * (wx0 * wy1);
+      v += prob(yn + 1, xw + 1) * (wx1 * wy1);
+      if (v >= thr) word |= 1u << (8 * e);
+    }
+    uint8_t* o = out + (int64_t)n * img_h * img_w + i * 4;
+    if (i * 4 + 3 < (int64_t)img_h * img_w && ((((int64_t)n * img_h * img_w) & 3) == 0)) {
+      *reinterpret_cast<uint32_t*>(o) = word;
+    } else {
+      for (int e = 0; e < 4 && i * 4 + e < (int64_t)img_h * img_w; ++e) o[e] = (word >> (8 * e)) & 1u;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int rsp_paste_masks(const float* logits, const int32_t* labels, const float* boxes, int32_t k, int32_t Hm,
+                               int32_t Wm, int32_t C, int32_t img_h, int32_t img_w, float thr, uint8_t* out,
+                               rsp_stream_t stream) {
+  if (!logits || !boxes || !out || k < 0 || Hm <= 0 || Wm <= 0 || C <= 0 || img_h <= 0 || img_w <= 0) return RSP_EINVAL;
+  if (k == 0) return RSP_OK;
+  const int64_t npix4 = ((int64_t)img_h * img_w + 3) / 4;
+  const unsigned gx = (unsigned)((npix4 + 255) / 256 > 1024 ? 1024 : (npix4 + 255) / 256);
+  hipLaunchKernelGGL(paste_masks_kernel, dim3(gx, (unsigned)k), dim3(256), 0, (hipStream_t)stream, logits, labels, boxes, Hm, Wm,
+                     C, img_h, img_w, thr, out);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}

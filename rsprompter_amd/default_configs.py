@@ -4,6 +4,7 @@ Used by bench.py / tests on machines where /root/reference is absent; tests/test
 checks them field by field against the real config files when those are present.
 """
 
+import copy
 SELECT_LAYERS = {'base': range(1, 13, 2), 'large': range(1, 25, 2), 'huge': range(1, 33, 2)}
 MEAN = [0.485 * 255, 0.456 * 255, 0.406 * 255]
 STD = [0.229 * 255, 0.224 * 255, 0.225 * 255]
@@ -169,3 +170,22 @@ def rsprompter_query_peft512(arch='base', num_classes=10, prompt_shape=(70, 5), 
     m['neck'] = dict(m['neck'], feature_aggregator=dict(type='PseudoFeatureAggregator', in_channels=256,
                                                         hidden_channels=512, out_channels=256))
     return m
+
+
+def samseg_maskrcnn(arch='huge', num_classes=10, pretrain_name=None, ckpt=None):
+    """configs/rsprompter/_base_/samseg-maskrcnn.py:57-170 merged with samseg-maskrcnn-<dataset>.py."""
+    a = rsprompter_anchor(arch, num_classes, (100, 5), pretrain_name, ckpt)
+    rpn = copy.deepcopy(a['rpn_head'])
+    rpn['anchor_generator'] = dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0], strides=[4, 8, 16, 32, 64])
+    roi = a['roi_head']
+    train_cfg = copy.deepcopy(a['train_cfg'])
+    train_cfg['rcnn']['sampler']['num'] = 512
+    train_cfg['rcnn']['mask_size'] = 28
+    return dict(
+        type='SAMSegMaskRCNN', data_preprocessor=a['data_preprocessor'], backbone=a['backbone'], neck=a['neck'], rpn_head=rpn,
+        roi_head=dict(type='StandardRoIHead', bbox_roi_extractor=roi['bbox_roi_extractor'], bbox_head=roi['bbox_head'],
+                      mask_roi_extractor=roi['mask_roi_extractor'],
+                      mask_head=dict(type='FCNMaskHead', num_convs=4, in_channels=256, conv_out_channels=256,
+                                     num_classes=num_classes,
+                                     loss_mask=dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0))),
+        train_cfg=train_cfg, test_cfg=a['test_cfg'])

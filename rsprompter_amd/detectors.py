@@ -169,3 +169,60 @@ class RSPrompterAnchor(BaseDetectorHIP):
         roi_outs = self.roi_head.forward(x, rpn_results_list, batch_data_samples, image_embeddings=image_embeddings,
                                          image_positional_embeddings=image_positional_embeddings)
         return (roi_outs,)
+
+
+@MODELS.register_module()
+class SAMSegMaskRCNN(RSPrompterAnchor):
+    """mmdet/rsprompter/models.py:1219-1244: Mask R-CNN on the SAM encoder + RSFPN (configs/rsprompter/_base_/
+    samseg-maskrcnn.py) -- the same backbone / neck / RPN / bbox-head kernels as RSPrompterAnchor with the standard
+    `StandardRoIHead` + `FCNMaskHead`; no prompt generator, no SAM mask decoder, no image-wide PE."""
+
+    def __init__(self, backbone=None, neck=None, rpn_head=None, roi_head=None, train_cfg=None, test_cfg=None,
+                 data_preprocessor=None, init_cfg=None):
+        BaseDetectorHIP.__init__(self)
+        self.data_preprocessor = MODELS.build(data_preprocessor or dict(type='DetDataPreprocessor'))
+        self.backbone = MODELS.build(backbone)
+        self.neck = MODELS.build(neck) if neck is not None else None
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        rpn_head_ = copy.deepcopy(dict(rpn_head))
+        rpn_head_.update(train_cfg=(train_cfg or {}).get('rpn'), test_cfg=test_cfg['rpn'])
+        if rpn_head_.get('num_classes') is None:
+            rpn_head_.update(num_classes=1)
+        self.rpn_head = MODELS.build(rpn_head_)
+        roi_head_ = copy.deepcopy(dict(roi_head))
+        roi_head_.update(train_cfg=(train_cfg or {}).get('rcnn'), test_cfg=test_cfg['rcnn'])
+        self.roi_head = MODELS.build(roi_head_)
+        self.eval()
+
+    def extract_feat(self, batch_inputs):
+        """models.py:1233-1244: hidden states -> neck; only the pyramid is returned."""
+        vo = self.backbone(batch_inputs)
+        if hasattr(vo, 'hidden_states') and vo.hidden_states is not None:
+            hs = vo[1]
+        elif isinstance(vo, tuple):
+            hs = vo
+        else:
+            raise NotImplementedError
+        return self.neck(hs)
+
+    @torch.no_grad()
+    def predict(self, batch_inputs, batch_data_samples, rescale=True):
+        """TwoStageDetector.predict (two_stage.py:147-195)."""
+        x = self.extract_feat(batch_inputs)
+        if batch_data_samples[0].get('proposals', None) is None:
+            rpn_results_list = self.rpn_head.predict(x, batch_data_samples, rescale=False)
+        else:
+            rpn_results_list = [s.proposals for s in batch_data_samples]
+        results_list = self.roi_head.predict(x, rpn_results_list, batch_data_samples, rescale=rescale)
+        return self.add_pred_to_datasample(batch_data_samples, results_list)
+
+    @torch.no_grad()
+    def _forward(self, batch_inputs, batch_data_samples=None):
+        x = self.extract_feat(batch_inputs)
+        shape = tuple(batch_inputs.shape[-2:])
+        samples = batch_data_samples or [DetDataSample(metainfo=dict(img_shape=shape, batch_input_shape=shape,
+                                                                      pad_shape=shape, ori_shape=shape,
+                                                                      scale_factor=(1.0, 1.0)))
+                                         for _ in range(batch_inputs.shape[0])]
+        rpn_results_list = self.rpn_head.predict(x, samples, rescale=False)
+        return (self.roi_head.forward(x, rpn_results_list, samples),)

@@ -458,6 +458,20 @@ def preprocess(imgs, mean, std, swap_rb, pad_divisor=1, pad_value=0.0, device=No
     return out
 
 
+def paste_masks(logits_nhwc, labels, boxes, img_hw, thr=0.5):
+    """FCNMaskHead mask paste: logits [k, Hm, Wm, C] (NHWC), labels int [k] or None, boxes [k, 4] -> bool [k, H, W]."""
+    lib = _lib.load()
+    _chk_f32(logits_nhwc, 'logits')
+    k, Hm, Wm, C = logits_nhwc.shape
+    H, W = int(img_hw[0]), int(img_hw[1])
+    out = torch.empty((k, H, W), dtype=torch.bool, device=logits_nhwc.device)
+    if k:
+        lab = None if labels is None else labels.to(torch.int32).contiguous()
+        _lib.check(lib.rsp_paste_masks(logits_nhwc.contiguous().data_ptr(), _ptr(lab), boxes.contiguous().data_ptr(), k, Hm, Wm,
+                                       C, H, W, float(thr), out.data_ptr(), _stream()), "rsp_paste_masks")
+    return out
+
+
 def resize_pad(img_hwc, new_hw, pad_hw, pad_val=(0.0, 0.0, 0.0), out=None, normalise=None):
     """Resize(keep_ratio) + Pad of the test pipeline on one decoded HWC image (uint8 / fp32, device tensor) ->
     fp32 [3, Hp, Wp] (see rsp_resize_pad).  normalise = (mean3, std3, swap_rb) fuses the DetDataPreprocessor step."""

@@ -99,3 +99,23 @@ def test_config_loader_base_and_delete():
     assert 'extra_config' not in cfg.model.backbone
     assert cfg.model.neck.feature_aggregator.type == 'PseudoFeatureAggregator'
     assert cfg.model.rpn_head.anchor_generator.strides == [4, 8, 16, 32, 64]   # inherited from _base_
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
+@pytest.mark.parametrize('fname,nc', [('samseg-maskrcnn-nwpu.py', 10), ('samseg-maskrcnn-ssdd.py', 1), ('samseg-maskrcnn-whu.py', 1)])
+def test_reference_samseg_maskrcnn_configs_build(fname, nc):
+    """the SAMSegMaskRCNN sibling model builds from the reference's config files unchanged."""
+    import rsprompter_amd as ra
+    from rsprompter_amd.default_configs import samseg_maskrcnn
+    cfg = ra.Config.fromfile(os.path.join(REF, fname))
+    assert _norm(cfg.model) == _norm(samseg_maskrcnn('base', nc))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = ra.build_model(cfg)
+    assert type(m).__name__ == 'SAMSegMaskRCNN' and type(m.roi_head).__name__ == 'StandardRoIHead'
+    assert m.rpn_head.num_base_priors == 3 and m.roi_head.mask_head.num_classes == nc
+    keys = set(m.state_dict())
+    for k in ['roi_head.mask_head.convs.3.conv.weight', 'roi_head.mask_head.upsample.weight',
+              'roi_head.mask_head.conv_logits.bias', 'roi_head.bbox_head.fc_reg.weight', 'rpn_head.rpn_cls.weight']:
+        assert k in keys, k
+    assert not any('mask_decoder' in k or 'shared_image_embedding' in k for k in keys)

@@ -118,3 +118,20 @@ def test_vitsam_forward_matches_real_class(gold):
     y = m(rnd(g['x']))
     assert isinstance(y, tuple) and len(y) == 1
     assert err(y[0][:, ::2], g['out']) < 1e-4
+
+
+# ----------------------------------------------------------------------------- SAMSeg sibling model (mask branch)
+@torch.no_grad()
+def test_fcn_mask_head_and_paste_match_real_file():
+    from oracle import samseg
+    g = torch.load(os.path.join(os.path.dirname(GOLD), 'reference_vectors_samseg.pt'), weights_only=False)
+    h = g['fcn_head']
+    m = load(samseg.FCNMaskHead(num_classes=10), h)
+    assert err(m(rnd(h['x'])), h['out']) < 1e-4
+    p = g['paste']
+    got = samseg.paste_masks(p['probs'], p['boxes'], *p['img_hw'])
+    assert err(got, p['out']) < 1e-6
+    for c in g['predict_single']:
+        masks, bb, _ = samseg.fcn_predict_single(c['logits'], c['boxes'].clone(), c['labels'], c['meta'], 0.5, c['rescale'])
+        assert masks.shape == c['masks'].shape and torch.equal(masks, c['masks'])
+        assert torch.allclose(bb, c['boxes_out'])

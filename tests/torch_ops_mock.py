@@ -399,3 +399,13 @@ def resize_pad(img_hwc, new_hw, pad_hw, pad_val=(0.0, 0.0, 0.0), out=None, norma
     canvas[...] = np.asarray(pad_val, dtype=np.float32)
     canvas[:res.shape[0], :res.shape[1]] = res
     return torch.from_numpy(np.ascontiguousarray(canvas.transpose(2, 0, 1)))
+
+
+def paste_masks(logits_nhwc, labels, boxes, img_hw, thr=0.5):
+    from oracle import samseg
+    k = logits_nhwc.shape[0]
+    lg = logits_nhwc.permute(0, 3, 1, 2)
+    if labels is not None and lg.shape[1] > 1:
+        lg = lg[range(k), labels.long()][:, None]
+    meta = dict(ori_shape=(int(img_hw[0]), int(img_hw[1])), scale_factor=(1.0, 1.0))
+    return samseg.fcn_predict_single(lg, boxes, None, meta, thr, rescale=True, class_agnostic=True)[0]
