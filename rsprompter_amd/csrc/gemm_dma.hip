@@ -630,7 +630,9 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   int tile = d.tile_hint & 0xff;
   if (tile == 0) {
     // short K (<= 8 K tiles): the block is mostly prologue + epilogue, two 128x128 blocks per CU overlap them
-    if (d.K <= 256) tile = 14;
+    // (round 2, tools/gemm_sweep.py on the SAM-decoder shapes M = 3.3 M rows: with N = 256 the 256x256 tile reads every A
+    // row once instead of twice and is 7-14 % faster even at 4-8 K tiles; N = 128 stays with 128x128)
+    if (d.K <= 256) tile = (d.N > 128 && nblk(256, 256) >= 1024) ? 17 : 14;
     else {
       // cost = rounds over the 256 CUs x tile area / relative efficiency (tools/gemm_sweep.py: 256x256 1.0,
       // 256x128 0.96, 128x128 0.88 with its two blocks per CU sharing the matrix pipe): the partially filled last

@@ -230,7 +230,9 @@ def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30):
         return small
     if conv:
         return '256x256' if n > 128 and nblk(256, 256) >= 1024 else small
-    if k <= 256 or n <= 64:
+    if k <= 256:
+        return '256x256' if n > 128 and nblk(256, 256) >= 1024 else small
+    if n <= 64:
         return small
     cost = lambda bm, bn, bpc, eff: -(-nblk(bm, bn) // (256 * bpc)) * bm * bn * bpc / eff
     best, name = cost(128, 128, 2, 0.88), '128x128'

@@ -12,7 +12,8 @@ dev = torch.device('cuda:0')
 SHAPES = [(3276800, 256, 128, 1), (3276800, 256, 256, 0), (3276800, 128, 256, 0),
           (32768, 3072, 768, 0), (32768, 768, 3072, 1), (39200, 2304, 768, 0), (39200, 768, 768, 1),
           (32768, 768, 768, 1)]
-HINTS = [(0, 'auto'), (14, 'P128x128'), (18, 'Q256x128'), (21, 'P128x64 nbuf3'), (22, 'P128x64 nbuf4')]
+HINTS = [(0, 'auto'), (14, 'P128x128'), (18, 'Q256x128'), (17, 'Q256x256'), (17 | 8 << 8, 'Q256x256 g8'), (21, 'P128x64 nbuf3'),
+         (22, 'P128x64 nbuf4')]
 
 
 def run(M, N, K, with_res, iters=5):
@@ -23,7 +24,7 @@ def run(M, N, K, with_res, iters=5):
     line = f'M={M} N={N} K={K} res={with_res}:'
     ref = None
     for hint, name in HINTS:
-        if hint in (2, 4, 12, 13, 16, 18, 19) and N <= 64 or hint in (3, 9, 11, 15, 17) and N <= 128:
+        if (hint & 0xff) in (2, 4, 12, 13, 16, 18, 19) and N <= 64 or (hint & 0xff) in (3, 9, 11, 15, 17) and N <= 128:
             continue
         out.zero_()
         ops.gemm(a, w, out=out, res=res, tile_hint=hint)
