@@ -308,6 +308,11 @@ int rsp_resize_bilinear_nhwc(const float* x, float* y, int32_t B, int32_t H, int
 int rsp_msdeform_attn(const float* value, const float* offs_weights, int32_t ld_ow, const float* ref_points,
                       float* out, int32_t B, int32_t Ntok, int32_t num_levels, const int32_t* level_hw,
                       rsp_stream_t stream);
+/* the same with head_dim 16 | 32 (value / out rows of 8*head_dim): head_dim 32 is the embed_dims=256 pixel decoder of  */
+/* the standard Mask2FormerHead (configs/rsprompter/_base_/samseg-mask2former.py:101-118)                             */
+int rsp_msdeform_attn_ex(const float* value, const float* offs_weights, int32_t ld_ow, const float* ref_points,
+                         float* out, int32_t B, int32_t Ntok, int32_t num_levels, const int32_t* level_hw,
+                         int32_t head_dim, rsp_stream_t stream);
 /* mask[row, k] = sigmoid(bilinear(mask_pred_plus[row], (h,w)))[k] < 0.5, fully-blocked rows cleared        */
 /* (models.py:386-391, 439-442); rows = B*Nq maps of size Hs x Ws.                                          */
 int rsp_query_attn_mask(const float* mask_pred_plus, uint8_t* mask, int64_t rows, int32_t Hs, int32_t Ws,

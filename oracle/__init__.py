@@ -36,6 +36,8 @@ Pinning status:
     are checked against the REAL classes executed in the build container on torch stand-ins for the mmcv leaves
     (tests/golden/make_golden_forwards.py + mmcv_standins.py -> tests/test_oracle_forwards.py), weights and inputs
     drawn from (seed, key, shape) on both sides, so the `state_dict` key layout (names, shapes) is pinned too.
+    The standard Mask2FormerHead of SAMSegMask2Former (oracle/samseg.py) is pinned the same way on the real
+    mmdet/models/dense_heads/mask2former_head.py (tests/golden/make_golden_samseg.py), FCNMaskHead + mask paste too.
     That run established that the LN2d layers of RSSimpleFPN carry eps = 1e-5 (mmcv `build_norm_layer` default), not
     LN2d's own 1e-6.
   * test pipeline front end (Resize keep_ratio + Pad, oracle/pipeline.py): restated from mmcv 2.1 / OpenCV documented

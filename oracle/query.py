@@ -103,11 +103,11 @@ class MHA(nn.Module):
 class EncLayer(nn.Module):
     """DeformableDetrTransformerEncoderLayer: detr_layers.py:213-238, deformable_detr_layers.py:237-249."""
 
-    def __init__(self):
+    def __init__(self, dim=128, ffn=512):
         super().__init__()
-        self.self_attn = MSDeformAttn()
-        self.ffn = FFN(128, 512)
-        self.norms = nn.ModuleList([nn.LayerNorm(128), nn.LayerNorm(128)])
+        self.self_attn = MSDeformAttn(dim)
+        self.ffn = FFN(dim, ffn)
+        self.norms = nn.ModuleList([nn.LayerNorm(dim), nn.LayerNorm(dim)])
 
     def forward(self, q, pos, ref, shapes):
         q = self.norms[0](self.self_attn(q, pos, ref, shapes))
@@ -117,12 +117,12 @@ class EncLayer(nn.Module):
 class PixelDecoder(nn.Module):
     """MSDeformAttnPixelDecoder: msdeformattn_pixel_decoder.py:21-246 (5 inputs, 3 encoder levels)."""
 
-    def __init__(self, feat=128, out=256, strides=(4, 8, 16, 32, 64)):
+    def __init__(self, feat=128, out=256, strides=(4, 8, 16, 32, 64), ffn=512, enc_layers=3):
         super().__init__()
-        self.strides, self.n_in, self.n_enc = list(strides), 5, 3
+        self.strides, self.n_in, self.n_enc, self.pe_feats = list(strides), 5, 3, feat // 2
         self.input_convs = nn.ModuleList([ConvGN(256, feat, 1, True, False) for _ in range(3)])
         self.encoder = nn.Module()
-        self.encoder.layers = nn.ModuleList([EncLayer() for _ in range(3)])
+        self.encoder.layers = nn.ModuleList([EncLayer(feat, ffn) for _ in range(enc_layers)])
         self.level_encoding = nn.Embedding(3, feat)
         self.lateral_convs = nn.ModuleList([ConvGN(256, feat, 1, False, False) for _ in range(2)])
         self.output_convs = nn.ModuleList([ConvGN(feat, feat, 3, False, True) for _ in range(2)])
@@ -136,7 +136,7 @@ class PixelDecoder(nn.Module):
             f = feats[lvl]
             h, w = f.shape[-2:]
             proj = self.input_convs[i](f)
-            pe = glue.sine_positional_encoding(bs, h, w, num_feats=64)
+            pe = glue.sine_positional_encoding(bs, h, w, num_feats=self.pe_feats)
             pos = self.level_encoding.weight[i].view(1, -1, 1, 1) + pe
             # MlvlPointGenerator(offset=0.5) / (W, H) * stride -> ((x+.5)/W, (y+.5)/H)   (:177-182)
             s = self.strides[lvl]
@@ -168,11 +168,11 @@ class PixelDecoder(nn.Module):
 class DecLayer(nn.Module):
     """Mask2FormerTransformerDecoderLayer: mask2former_layers.py:73-135."""
 
-    def __init__(self):
+    def __init__(self, dim=128, ffn=512):
         super().__init__()
-        self.self_attn, self.cross_attn = MHA(), MHA()
-        self.ffn = FFN(128, 512)
-        self.norms = nn.ModuleList([nn.LayerNorm(128) for _ in range(3)])
+        self.self_attn, self.cross_attn = MHA(dim), MHA(dim)
+        self.ffn = FFN(dim, ffn)
+        self.norms = nn.ModuleList([nn.LayerNorm(dim) for _ in range(3)])
 
     def forward(self, query, key, value, query_pos, key_pos, cross_attn_mask):
         query = self.norms[0](self.cross_attn(query, key, value, query_pos, key_pos, cross_attn_mask))

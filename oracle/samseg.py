@@ -142,3 +142,98 @@ class SAMSegMaskRCNNOracle(nn.Module):
             start += n
             results.append(dict(bboxes=bb, scores=d['scores'], labels=d['labels'], masks=masks))
         return results, trace
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# SAMSegMask2Former (models.py:1247-1274): SAM encoder -> RSFPN -> the STANDARD mmdet Mask2FormerHead / fusion head
+# ----------------------------------------------------------------------------------------------------------------------
+class Mask2FormerHead(nn.Module):
+    """mmdet Mask2FormerHead (mask2former_head.py:62-156 ctor, :340-380 `_forward_head`, :382-460 `forward`) with the
+    configuration of configs/rsprompter/_base_/samseg-mask2former.py:88-150: feat 256, 8 heads, 3-layer deformable
+    encoder (FFN 1024), 9 decoder layers (FFN 2048), sine PE num_feats 128, single-Linear class head."""
+
+    def __init__(self, num_classes, num_queries, feat=256, out=256, dec_layers=9, dec_ffn=2048, enc_ffn=1024):
+        super().__init__()
+        from .query import DecLayer, PixelDecoder
+        self.num_classes, self.num_queries, self.num_heads, self.n_dec = num_classes, num_queries, 8, dec_layers
+        self.pe_feats = 128
+        self.pixel_decoder = PixelDecoder(feat, out, ffn=enc_ffn, enc_layers=3)
+        self.pixel_decoder.pe_feats = 128
+        self.transformer_decoder = nn.Module()
+        self.transformer_decoder.layers = nn.ModuleList([DecLayer(feat, dec_ffn) for _ in range(dec_layers)])
+        self.transformer_decoder.post_norm = nn.LayerNorm(feat)
+        self.query_embed = nn.Embedding(num_queries, feat)
+        self.query_feat = nn.Embedding(num_queries, feat)
+        self.level_embed = nn.Embedding(3, feat)
+        self.cls_embed = nn.Linear(feat, num_classes + 1)
+        self.mask_embed = nn.Sequential(nn.Linear(feat, feat), nn.ReLU(inplace=True), nn.Linear(feat, feat),
+                                        nn.ReLU(inplace=True), nn.Linear(feat, out))
+
+    def _forward_head(self, decoder_out, mask_feature, attn_size):
+        decoder_out = self.transformer_decoder.post_norm(decoder_out)
+        cls_pred = self.cls_embed(decoder_out)
+        mask_pred = torch.einsum('bqc,bchw->bqhw', self.mask_embed(decoder_out), mask_feature)
+        attn_mask = F.interpolate(mask_pred, attn_size, mode='bilinear', align_corners=False)
+        attn_mask = attn_mask.flatten(2).unsqueeze(1).repeat((1, self.num_heads, 1, 1)).flatten(0, 1)
+        return cls_pred, mask_pred, attn_mask.sigmoid() < 0.5
+
+    @torch.no_grad()
+    def forward(self, x):
+        bs = x[0].shape[0]
+        mask_features, mem = self.pixel_decoder(x)
+        dec_in, dec_pos = [], []
+        for i in range(3):
+            dec_in.append(mem[i].flatten(2).permute(0, 2, 1) + self.level_embed.weight[i].view(1, 1, -1))
+            pe = glue.sine_positional_encoding(bs, mem[i].shape[-2], mem[i].shape[-1], num_feats=self.pe_feats)
+            dec_pos.append(pe.flatten(2).permute(0, 2, 1))
+        qf = self.query_feat.weight.unsqueeze(0).repeat((bs, 1, 1))
+        qe = self.query_embed.weight.unsqueeze(0).repeat((bs, 1, 1))
+        cls, mask, attn_mask = self._forward_head(qf, mask_features, mem[0].shape[-2:])
+        trace = dict(mask_features=mask_features, memory=mem, attn_masks=[], query_feats=[qf], cls_pred_all=[cls],
+                     mask_pred_all=[mask])
+        for i in range(self.n_dec):
+            lvl = i % 3
+            attn_mask = attn_mask & (attn_mask.sum(-1) != attn_mask.shape[-1]).unsqueeze(-1)   # :432-434
+            trace['attn_masks'].append(attn_mask)
+            qf = self.transformer_decoder.layers[i](qf, dec_in[lvl], dec_in[lvl], qe, dec_pos[lvl], attn_mask)
+            cls, mask, attn_mask = self._forward_head(qf, mask_features, mem[(i + 1) % 3].shape[-2:])
+            trace['query_feats'].append(qf)
+            trace['cls_pred_all'].append(cls)
+            trace['mask_pred_all'].append(mask)
+        trace.update(cls_pred=cls, mask_pred=mask)
+        return cls, mask, trace
+
+
+class SAMSegMask2FormerOracle(nn.Module):
+    """SAMSegMask2Former.predict = MaskFormer.predict (maskformer.py:83-151): extract_feat (models.py:1262-1274, the
+    neck only) -> MaskFormerHead.predict (maskformer_head.py:569-604: last stage, bilinear up to batch_input_shape) ->
+    MaskFormerFusionHead.predict (maskformer_fusion_head.py:184-270, same body as the RS fusion head)."""
+
+    def __init__(self, arch='base', num_classes=10, num_queries=70, select_layers=None, max_per_image=None):
+        super().__init__()
+        depth = hf_sam.ARCH[arch]['num_hidden_layers']
+        select_layers = list(select_layers) if select_layers is not None else list(range(1, depth + 1, 2))
+        self.num_classes = num_classes
+        self.max_per_image = max_per_image if max_per_image is not None else num_queries
+        self.backbone = _Wrap('vision_encoder', hf_sam.build_vision_encoder(arch))
+        self.neck = nn.Module()
+        self.neck.feature_aggregator = FeatureAggregator(arch, 32, 256, select_layers)
+        self.neck.feature_spliter = SimpleFPN()
+        self.panoptic_head = Mask2FormerHead(num_classes, num_queries)
+        self.eval()
+
+    @torch.no_grad()
+    def extract_feat(self, batch_inputs):
+        _, hidden = hf_sam.run_vision_encoder(self.backbone.vision_encoder, batch_inputs)
+        return self.neck.feature_spliter(self.neck.feature_aggregator(hidden))
+
+    @torch.no_grad()
+    def predict(self, batch_inputs, metas, rescale=True):
+        from .query import fusion_predict
+        x = self.extract_feat(batch_inputs)
+        cls, mask, trace = self.panoptic_head(x)
+        img_shape = metas[0]['batch_input_shape']
+        mask_up = F.interpolate(mask, size=(img_shape[0], img_shape[1]), mode='bilinear', align_corners=False)
+        results = fusion_predict(cls, mask_up, metas, self.num_classes, self.max_per_image, rescale)
+        trace.update(fpn=x)
+        return results, trace

@@ -134,6 +134,8 @@ PROTOTYPES = {
     "rsp_resize_bilinear_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "rsp_msdeform_attn": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
                                   ctypes.POINTER(c_int), c_void_p]),
+    "rsp_msdeform_attn_ex": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                     ctypes.POINTER(c_int), c_int, c_void_p]),
     "rsp_query_attn_mask": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "rsp_sam_mask_embed": (c_int, [ctypes.POINTER(RspMaskEmbedDesc), c_void_p]),
     "rsp_query_topk": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

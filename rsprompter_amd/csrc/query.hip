@@ -122,15 +122,18 @@ struct MsdaP {
   int B, Ntok, ldow;
   int lvl_h[4], lvl_w[4], lvl_start[4];
 };
-constexpr int MS_H = 8, MS_D = 16, MS_L = 3, MS_P = 4;
+constexpr int MS_H = 8, MS_L = 3, MS_P = 4;
 
-// one wave per (b, token): lane = head * 8 + dim pair
+// one wave per (b, token): lane = head * 8 + slot, every lane owns MS_D / 8 consecutive channels of its head
+// (MS_D = 16: embed 128, the RSPrompter query prompter; MS_D = 32: embed 256, the standard Mask2Former pixel decoder)
+template <int MS_D>
 __global__ __launch_bounds__(256) void msda_kernel(const MsdaP p) {
+  constexpr int DPL = MS_D / 8;
   const int lane = threadIdx.x & 63;
   const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (tok >= (int64_t)p.B * p.Ntok) return;
   const int b = (int)(tok / p.Ntok), q = (int)(tok - (int64_t)b * p.Ntok);
-  const int h = lane >> 3, dp = (lane & 7) * 2;
+  const int h = lane >> 3, dp = (lane & 7) * DPL;
   const float* owr = p.ow + tok * p.ldow;
   const float* logit = owr + MS_H * MS_L * MS_P * 2 + h * (MS_L * MS_P);
   float w[MS_L * MS_P];
@@ -142,7 +145,9 @@ __global__ __launch_bounds__(256) void msda_kernel(const MsdaP p) {
   for (int i = 0; i < MS_L * MS_P; ++i) { w[i] = expf(w[i] - m); sum += w[i]; }
   const float rx = p.ref[q * 2], ry = p.ref[q * 2 + 1];
   const float* vb = p.value + (int64_t)b * p.Ntok * (MS_H * MS_D) + h * MS_D + dp;
-  float a0 = 0.f, a1 = 0.f;
+  float acc[DPL];
+#pragma unroll
+  for (int e = 0; e < DPL; ++e) acc[e] = 0.f;
 #pragma unroll
   for (int l = 0; l < MS_L; ++l) {
     const int Hl = p.lvl_h[l], Wl = p.lvl_w[l];
@@ -158,23 +163,26 @@ __global__ __launch_bounds__(256) void msda_kernel(const MsdaP p) {
       const int x0 = (int)xf, y0 = (int)yf;
       const float lx = x - xf, ly = y - yf;
       const float wt = w[l * MS_P + pt] / sum;
-      float s0 = 0.f, s1 = 0.f;
+      float sv[DPL];
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) sv[e] = 0.f;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int xx = x0 + (t & 1), yy = y0 + (t >> 1);
         if (xx >= 0 && xx < Wl && yy >= 0 && yy < Hl) {
           const float bw = ((t & 1) ? lx : 1.f - lx) * ((t >> 1) ? ly : 1.f - ly);
           const float* vp = vl + (int64_t)(yy * Wl + xx) * (MS_H * MS_D);
-          s0 += bw * vp[0];
-          s1 += bw * vp[1];
+#pragma unroll
+          for (int e = 0; e < DPL; ++e) sv[e] += bw * vp[e];
         }
       }
-      a0 += wt * s0;
-      a1 += wt * s1;
+#pragma unroll
+      for (int e = 0; e < DPL; ++e) acc[e] += wt * sv[e];
     }
   }
   float* o = p.out + tok * (MS_H * MS_D) + h * MS_D + dp;
-  o[0] = a0; o[1] = a1;
+#pragma unroll
+  for (int e = 0; e < DPL; ++e) o[e] = acc[e];
 }
 
 // ------------------------------------------------------------------------------------ cross-attention mask
@@ -512,11 +520,11 @@ extern "C" int rsp_resize_bilinear_nhwc(const float* x, float* y, int32_t B, int
   return RSP_OK;
 }
 
-extern "C" int rsp_msdeform_attn(const float* value, const float* offs_weights, int32_t ld_ow, const float* ref_points,
-                                 float* out, int32_t B, int32_t Ntok, int32_t num_levels, const int32_t* level_hw /*host [L,2]*/,
-                                 rsp_stream_t stream) {
+extern "C" int rsp_msdeform_attn_ex(const float* value, const float* offs_weights, int32_t ld_ow, const float* ref_points,
+                                    float* out, int32_t B, int32_t Ntok, int32_t num_levels, const int32_t* level_hw /*host [L,2]*/,
+                                    int32_t head_dim, rsp_stream_t stream) {
   if (!value || !offs_weights || !ref_points || !out || !level_hw || B <= 0 || Ntok <= 0 || num_levels != MS_L ||
-      ld_ow < MS_H * MS_L * MS_P * 3)
+      ld_ow < MS_H * MS_L * MS_P * 3 || !(head_dim == 16 || head_dim == 32))
     return RSP_EINVAL;
   MsdaP p;
   p.value = value; p.ow = offs_weights; p.ref = ref_points; p.out = out; p.B = B; p.Ntok = Ntok; p.ldow = ld_ow;
@@ -529,9 +537,16 @@ extern "C" int rsp_msdeform_attn(const float* value, const float* offs_weights, 
   }
   if (start != Ntok) return RSP_EINVAL;
   const int64_t waves = (int64_t)B * Ntok;
-  hipLaunchKernelGGL(msda_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  if (head_dim == 16) hipLaunchKernelGGL(msda_kernel<16>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(msda_kernel<32>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
+}
+
+extern "C" int rsp_msdeform_attn(const float* value, const float* offs_weights, int32_t ld_ow, const float* ref_points,
+                                 float* out, int32_t B, int32_t Ntok, int32_t num_levels, const int32_t* level_hw,
+                                 rsp_stream_t stream) {
+  return rsp_msdeform_attn_ex(value, offs_weights, ld_ow, ref_points, out, B, Ntok, num_levels, level_hw, 16, stream);
 }
 
 extern "C" int rsp_query_attn_mask(const float* mask_pred_plus, uint8_t* mask, int64_t rows, int32_t Hs, int32_t Ws, int32_t h,

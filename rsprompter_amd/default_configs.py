@@ -189,3 +189,33 @@ def samseg_maskrcnn(arch='huge', num_classes=10, pretrain_name=None, ckpt=None):
                                      num_classes=num_classes,
                                      loss_mask=dict(type='CrossEntropyLoss', use_mask=True, loss_weight=1.0))),
         train_cfg=train_cfg, test_cfg=a['test_cfg'])
+
+
+def samseg_mask2former(arch='base', num_classes=10, num_queries=70, pretrain_name=None, ckpt=None):
+    """configs/rsprompter/_base_/samseg-mask2former.py:58-178 merged with samseg-mask2former-<dataset>.py:
+    the query tree with the STANDARD Mask2FormerHead (feat 256, 9 decoder layers) and no SAM prompt / mask decoder."""
+    q = rsprompter_query(arch, num_classes, (num_queries, 5), pretrain_name, ckpt)
+    ph = q['panoptic_head']
+
+    def widen(layer_cfg, ffn):
+        lc = copy.deepcopy(layer_cfg)
+        for k in ('self_attn_cfg', 'cross_attn_cfg'):
+            if k in lc:
+                lc[k]['embed_dims'] = 256
+        lc['ffn_cfg'].update(embed_dims=256, feedforward_channels=ffn)
+        return lc
+    pd = copy.deepcopy(ph['pixel_decoder'])
+    pd['encoder']['layer_cfg'] = widen(pd['encoder']['layer_cfg'], 1024)
+    pd['positional_encoding'] = dict(num_feats=128, normalize=True)
+    td = copy.deepcopy(ph['transformer_decoder'])
+    td.update(num_layers=9, layer_cfg=widen(td['layer_cfg'], 2048))
+    head = dict(type='Mask2FormerHead', in_channels=[256, 256, 256, 256, 256], feat_channels=256, out_channels=256,
+                num_things_classes=num_classes, num_stuff_classes=0, num_queries=num_queries,
+                num_transformer_feat_level=3, pixel_decoder=pd, enforce_decoder_input_project=False,
+                positional_encoding=dict(num_feats=128, normalize=True), transformer_decoder=td,
+                loss_cls=ph['loss_cls'], loss_mask=ph['loss_mask'], loss_dice=ph['loss_dice'])
+    return dict(type='SAMSegMask2Former', data_preprocessor=q['data_preprocessor'], backbone=q['backbone'], neck=q['neck'],
+                panoptic_head=head,
+                panoptic_fusion_head=dict(type='MaskFormerFusionHead', num_things_classes=num_classes, num_stuff_classes=0,
+                                          loss_panoptic=None, init_cfg=None),
+                train_cfg=q['train_cfg'], test_cfg=q['test_cfg'])

@@ -888,15 +888,18 @@ def resize_bilinear(x_nhwc, size):
     return y
 
 
-def msdeform_attn(value, offs_weights, ref_points, B, Ntok, level_hw):
+def msdeform_attn(value, offs_weights, ref_points, B, Ntok, level_hw, head_dim=16):
+    """value [B*Ntok, 8*head_dim] -> sampled [B*Ntok, 8*head_dim] (before output_proj); head_dim 16 | 32"""
     import ctypes
     lib = _lib.load()
-    out = torch.empty((B * Ntok, 128), dtype=torch.float32, device=value.device)
+    if value.shape[-1] != 8 * head_dim:
+        raise ValueError(f'msdeform_attn: value rows of {value.shape[-1]} channels, expected 8 x {head_dim}')
+    out = torch.empty((B * Ntok, 8 * head_dim), dtype=torch.float32, device=value.device)
     arr = (ctypes.c_int * (2 * len(level_hw)))(*[int(v) for hw in level_hw for v in hw])
     _timed('msda_kernel', 0, 4.0 * out.numel() * 50,
-           lambda: _lib.check(lib.rsp_msdeform_attn(value.data_ptr(), offs_weights.data_ptr(), offs_weights.shape[-1],
-                                                    ref_points.data_ptr(), out.data_ptr(), B, Ntok, len(level_hw), arr,
-                                                    _stream()), "rsp_msdeform_attn"))
+           lambda: _lib.check(lib.rsp_msdeform_attn_ex(value.data_ptr(), offs_weights.data_ptr(), offs_weights.shape[-1],
+                                                       ref_points.data_ptr(), out.data_ptr(), B, Ntok, len(level_hw), arr,
+                                                       head_dim, _stream()), "rsp_msdeform_attn_ex"))
     return out
 
 

@@ -56,9 +56,11 @@ class MSDeformAttnPixelDecoder(HIPModule):
         super().__init__()
         lc = encoder['layer_cfg']
         sa = lc['self_attn_cfg']
-        assert (sa['embed_dims'], sa['num_heads'], sa['num_levels'], sa['num_points']) == (128, 8, 3, 4), \
-            'the MSDeformAttn kernel is specialised for the RSPrompter configuration (128 dims, 8 heads, 3 levels, 4 points)'
-        assert feat_channels == 128 and (norm_cfg or {}).get('num_groups', 32) == 32
+        if (sa['num_heads'], sa['num_levels'], sa['num_points']) != (8, 3, 4) or sa['embed_dims'] not in (128, 256):
+            raise NotImplementedError('the MSDeformAttn kernel covers 8 heads x (16 | 32), 3 levels, 4 points: the '
+                                      'RSPrompter (128) and samseg-mask2former (256) configurations')
+        if feat_channels != sa['embed_dims'] or (norm_cfg or {}).get('num_groups', 32) != 32:
+            raise NotImplementedError('feat_channels must equal the encoder width; GroupNorm(32) only')
         self.in_channels, self.strides = list(in_channels), list(strides)
         self.n_in, self.n_enc, self.num_layers = len(in_channels), sa['num_levels'], encoder['num_layers']
         self.feat, self.out_channels, self.num_outs = feat_channels, out_channels, num_outs
@@ -128,7 +130,7 @@ class MSDeformAttnPixelDecoder(HIPModule):
         return self._const[key]
 
     def forward(self, feats):
-        """feats: 5 logical-NCHW channels-last levels -> (mask_feature [B,256,H0,W0], [3 memories low->high res])."""
+        """feats: 5 logical-NCHW channels-last levels -> (mask_feature [B,out,H0,W0], [3 memories low->high res])."""
         if self._packed is None:
             self._pack()
         P = self._packed
@@ -152,7 +154,7 @@ class MSDeformAttnPixelDecoder(HIPModule):
             qp = ops.add_rows(q, pos, vmod=Ntok)
             value = ops.gemm(q, W['value'])
             ow = ops.gemm(qp, W['ow'])
-            samp = ops.msdeform_attn(value, ow, ref, B, Ntok, shapes)
+            samp = ops.msdeform_attn(value, ow, ref, B, Ntok, shapes, head_dim=f // 8)
             q1 = ops.gemm(samp, W['out'], res=q)                   # output_proj + identity
             q1 = ops.layernorm(q1, _g(L, 'norms.0').weight, _g(L, 'norms.0').bias, 1e-5)
             hmid = ops.gemm(q1, W['f0'], act=ops.ACT_RELU)
@@ -200,28 +202,26 @@ class LazyUpsampledMasks:
         return iter(self.low_res)
 
 
-@MODELS.register_module()
-class RSMask2FormerHead(HIPModule):
-    def __init__(self, mask_decoder, decoder_plus, with_sincos=True, per_pointset_point=1, multimask_output=False,
-                 attention_similarity=None, target_embedding=None, output_attentions=None, in_channels=None,
-                 feat_channels=128, out_channels=256, num_things_classes=80, num_stuff_classes=0, num_queries=100,
-                 num_transformer_feat_level=3, pixel_decoder=None, enforce_decoder_input_project=False,
-                 transformer_decoder=None, positional_encoding=None, loss_cls=None, loss_mask=None, loss_dice=None,
-                 train_cfg=None, test_cfg=None, init_cfg=None, **kwargs):
-        super().__init__()
-        if not decoder_plus:
-            raise NotImplementedError('decoder_plus=False is not used by any shipped RSPrompter config')
-        if multimask_output or not with_sincos:
-            raise NotImplementedError
+class _Mask2FormerCore(HIPModule):
+    """What Mask2FormerHead (mask2former_head.py:62-156) and RSMask2FormerHead (models.py:274-338) share: the pixel
+    decoder, the masked-attention transformer decoder (mask2former_layers.py:73-135), the query / level embeddings and
+    the mask-embedding MLP.  `_decode` runs `forward` up to the last `_forward_head` (mask2former_head.py:403-456)."""
+
+    def _init_core(self, in_channels, feat_channels, out_channels, num_things_classes, num_stuff_classes, num_queries,
+                   num_transformer_feat_level, pixel_decoder, enforce_decoder_input_project, transformer_decoder,
+                   positional_encoding, train_cfg, test_cfg):
         self.num_things_classes, self.num_stuff_classes = num_things_classes, num_stuff_classes
         self.num_classes = num_things_classes + num_stuff_classes
         self.num_queries, self.num_transformer_feat_level = num_queries, num_transformer_feat_level
         td = transformer_decoder
         self.num_heads = td['layer_cfg']['cross_attn_cfg']['num_heads']
         self.num_transformer_decoder_layers = td['num_layers']
-        self.feat_channels, self.out_channels, self.per_pointset_point = feat_channels, out_channels, per_pointset_point
+        self.feat_channels, self.out_channels = feat_channels, out_channels
         self.ffn_dim = td['layer_cfg']['ffn_cfg']['feedforward_channels']
-        assert td['layer_cfg']['cross_attn_cfg']['embed_dims'] == feat_channels and not enforce_decoder_input_project
+        if td['layer_cfg']['cross_attn_cfg']['embed_dims'] != feat_channels or enforce_decoder_input_project:
+            raise NotImplementedError('decoder_input_projs other than Identity are not used by any shipped config')
+        if num_transformer_feat_level != 3:
+            raise NotImplementedError('three transformer feature levels (every shipped config)')
         pd = copy.deepcopy(dict(pixel_decoder))
         pd.update(in_channels=in_channels, feat_channels=feat_channels, out_channels=out_channels)
         self.pixel_decoder = MODELS.build(pd)
@@ -241,32 +241,20 @@ class RSMask2FormerHead(HIPModule):
         add_param(self, 'query_embed.weight', (num_queries, f))
         add_param(self, 'query_feat.weight', (num_queries, f))
         add_param(self, 'level_embed.weight', (num_transformer_feat_level, f))
-        _add_linear(self, 'cls_embed.0', f, f)
-        _add_linear(self, 'cls_embed.2', self.num_classes + 1, f)
-        _add_linear(self, 'mask_embed.0', f, f)
-        _add_linear(self, 'mask_embed.2', f, f)
-        _add_linear(self, 'mask_embed.4', out_channels, f)
-        _add_linear(self, 'point_emb.0', f // 2, f)
-        _add_linear(self, 'point_emb.2', f // 2, f // 2)
-        _add_linear(self, 'point_emb.4', out_channels * 2 * per_pointset_point, f // 2)
-        self.mask_decoder = MODELS.build(mask_decoder)
-        # the reference keeps prompt_encoder.mask_embed as `sam_mask_embed` (models.py:297-305)
-        add_param(self, 'sam_mask_embed.conv1.weight', (4, 1, 2, 2))
-        add_param(self, 'sam_mask_embed.conv1.bias', (4,))
-        add_param(self, 'sam_mask_embed.conv2.weight', (16, 4, 2, 2))
-        add_param(self, 'sam_mask_embed.conv2.bias', (16,))
-        add_param(self, 'sam_mask_embed.conv3.weight', (out_channels, 16, 1, 1))
-        add_param(self, 'sam_mask_embed.conv3.bias', (out_channels,))
-        _add_ln(self, 'sam_mask_embed.layer_norm1', 4)
-        _add_ln(self, 'sam_mask_embed.layer_norm2', 16)
         self.test_cfg, self.train_cfg = test_cfg, train_cfg
         self._const = {}
+
+    def _add_mask_embed(self):
+        f = self.feat_channels
+        _add_linear(self, 'mask_embed.0', f, f)
+        _add_linear(self, 'mask_embed.2', f, f)
+        _add_linear(self, 'mask_embed.4', self.out_channels, f)
 
     def _apply(self, fn, *a, **kw):
         self._const = {}
         return super()._apply(fn, *a, **kw)
 
-    def _pack(self):
+    def _pack_core(self, linears):
         f = self.feat_channels
         P = dict(layers=[])
         for n in range(self.num_transformer_decoder_layers):
@@ -280,17 +268,9 @@ class RSMask2FormerHead(HIPModule):
                 d[f'{a}.o'] = _pw(at.out_proj)
             d['f0'], d['f1'] = _pw(_g(L, 'ffn.layers.0.0')), _pw(_g(L, 'ffn.layers.1'))
             P['layers'].append(d)
-        for nm in ('cls_embed.0', 'cls_embed.2', 'mask_embed.0', 'mask_embed.2', 'mask_embed.4', 'point_emb.0',
-                   'point_emb.2', 'point_emb.4'):
+        for nm in ('mask_embed.0', 'mask_embed.2', 'mask_embed.4') + tuple(linears):
             P[nm] = _pw(_g(self, nm))
-        sm = self.sam_mask_embed
-        P['sam_embed'] = dict(conv1_w=sm.conv1.weight.detach().contiguous(), conv1_b=sm.conv1.bias.detach(),
-                              ln1_w=sm.layer_norm1.weight.detach(), ln1_b=sm.layer_norm1.bias.detach(),
-                              conv2_w=sm.conv2.weight.detach().contiguous(), conv2_b=sm.conv2.bias.detach(),
-                              ln2_w=sm.layer_norm2.weight.detach(), ln2_b=sm.layer_norm2.bias.detach(),
-                              conv3_w=sm.conv3.weight.detach().reshape(self.out_channels, 16).contiguous(),
-                              conv3_b=sm.conv3.bias.detach())
-        self._packed = P
+        return P
 
     def _pos_tables(self, shapes, dev):
         key = (tuple(shapes), str(dev))
@@ -320,20 +300,19 @@ class RSMask2FormerHead(HIPModule):
         return ops.gemm(o, W[pfx + '.o'], res=identity)
 
     def _head_light(self, qf, mf_planes, B, HW0):
-        """the per-layer part of `_forward_head` (models.py:340-357): post_norm, class logits, mask_pred_plus."""
+        """the per-layer part of `_forward_head` (mask2former_head.py:361-367 / models.py:340-357): post_norm and the
+        mask logits einsum('bqc,bchw->bqhw') that the next layer's attention mask is thresholded from."""
         pn = _g(self, 'transformer_decoder.post_norm')
         dn = ops.layernorm(qf, pn.weight, pn.bias, 1e-5)
         me = self._mlp(dn, ('mask_embed.0', 'mask_embed.2', 'mask_embed.4'))
         Nq = self.num_queries
         mpp = torch.empty((B, Nq, HW0), dtype=torch.float32, device=qf.device)
-        for b in range(B):   # einsum('bqc,bchw->bqhw'): mask_feature (as fp16 planes) is the GEMM "weight"
+        for b in range(B):   # mask_feature (as fp16 planes) is the GEMM "weight"
             ops.gemm(me[b * Nq:(b + 1) * Nq], ops.PlaneWeight(mf_planes, b * HW0, HW0), out=mpp[b], bias=None)
         return dn, mpp
 
-    def forward(self, x, batch_data_samples=None, image_embeddings=None, image_positional_embeddings=None):
-        """models.py:395-463 (inference schedule).  Returns (cls [B,Nq,nc+1], SAM low-res masks [B,Nq,4h,4w], trace)."""
-        if self._packed is None:
-            self._pack()
+    def _decode(self, x):
+        """-> (dn [B*Nq, f] post-normed last query features, mask logits [B, Nq, H0, W0], trace)"""
         P = self._packed
         B = x[0].shape[0]
         f, Nq = self.feat_channels, self.num_queries
@@ -351,7 +330,7 @@ class RSMask2FormerHead(HIPModule):
             dec_kin.append(ops.add_rows(d, pos_tabs[i], vmod=pos_tabs[i].shape[0]))          # key + key_pos
         qf = self.query_feat.weight.detach().unsqueeze(0).expand(B, -1, -1).reshape(B * Nq, f).contiguous()
         qe = self.query_embed.weight.detach()
-        trace = dict(attn_masks=[], query_feats=[])
+        trace = dict(attn_masks=[], query_feats=[], mask_features=mask_features, memory=mem)
         dn, mpp = self._head_light(qf, mf_planes, B, H0 * W0)
         for i in range(self.num_transformer_decoder_layers):
             lvl = i % self.num_transformer_feat_level
@@ -370,6 +349,101 @@ class RSMask2FormerHead(HIPModule):
             qf = ops.layernorm(qf, _g(L, 'norms.2').weight, _g(L, 'norms.2').bias, 1e-5)
             trace['query_feats'].append(qf)
             dn, mpp = self._head_light(qf, mf_planes, B, H0 * W0)
+        return dn, mpp.view(B, Nq, H0, W0), trace
+
+
+@MODELS.register_module()
+class Mask2FormerHead(_Mask2FormerCore):
+    """The standard mmdet head of the `samseg-mask2former` configs (mask2former_head.py:62-156, 340-460; predict:
+    maskformer_head.py:569-604): single-Linear class head, mask logits = mask_embed . mask_feature, no SAM decoder."""
+
+    def __init__(self, in_channels=None, feat_channels=256, out_channels=256, num_things_classes=80,
+                 num_stuff_classes=53, num_queries=100, num_transformer_feat_level=3, pixel_decoder=None,
+                 enforce_decoder_input_project=False, transformer_decoder=None, positional_encoding=None, loss_cls=None,
+                 loss_mask=None, loss_dice=None, train_cfg=None, test_cfg=None, init_cfg=None, **kwargs):
+        super().__init__()
+        self._init_core(in_channels, feat_channels, out_channels, num_things_classes, num_stuff_classes, num_queries,
+                        num_transformer_feat_level, pixel_decoder, enforce_decoder_input_project, transformer_decoder,
+                        positional_encoding, train_cfg, test_cfg)
+        _add_linear(self, 'cls_embed', self.num_classes + 1, feat_channels)
+        self._add_mask_embed()
+
+    def _pack(self):
+        self._packed = self._pack_core(('cls_embed',))
+
+    def forward(self, x, batch_data_samples=None):
+        """-> (cls [B,Nq,nc+1], mask logits [B,Nq,H0,W0], trace): the LAST decoder stage, which is all predict reads"""
+        if self._packed is None:
+            self._pack()
+        dn, mask_pred, trace = self._decode(x)
+        B = x[0].shape[0]
+        cls = ops.gemm(dn, self._packed['cls_embed']).view(B, self.num_queries, self.num_classes + 1)
+        return cls, mask_pred, trace
+
+    def predict(self, x, batch_data_samples):
+        """maskformer_head.py:569-604; the bilinear up-sampling to batch_input_shape stays symbolic (LazyUpsampledMasks)."""
+        metas = _metas_of(batch_data_samples)
+        cls, mask_pred, trace = self(x, batch_data_samples)
+        self._last_trace = trace
+        size = metas[0].get('batch_input_shape', metas[0].get('pad_shape'))
+        return cls, LazyUpsampledMasks(mask_pred, size[:2])
+
+
+@MODELS.register_module()
+class RSMask2FormerHead(_Mask2FormerCore):
+    def __init__(self, mask_decoder, decoder_plus, with_sincos=True, per_pointset_point=1, multimask_output=False,
+                 attention_similarity=None, target_embedding=None, output_attentions=None, in_channels=None,
+                 feat_channels=128, out_channels=256, num_things_classes=80, num_stuff_classes=0, num_queries=100,
+                 num_transformer_feat_level=3, pixel_decoder=None, enforce_decoder_input_project=False,
+                 transformer_decoder=None, positional_encoding=None, loss_cls=None, loss_mask=None, loss_dice=None,
+                 train_cfg=None, test_cfg=None, init_cfg=None, **kwargs):
+        super().__init__()
+        if not decoder_plus:
+            raise NotImplementedError('decoder_plus=False is not used by any shipped RSPrompter config')
+        if multimask_output or not with_sincos:
+            raise NotImplementedError
+        self.per_pointset_point = per_pointset_point
+        self._init_core(in_channels, feat_channels, out_channels, num_things_classes, num_stuff_classes, num_queries,
+                        num_transformer_feat_level, pixel_decoder, enforce_decoder_input_project, transformer_decoder,
+                        positional_encoding, train_cfg, test_cfg)
+        f = feat_channels
+        _add_linear(self, 'cls_embed.0', f, f)
+        _add_linear(self, 'cls_embed.2', self.num_classes + 1, f)
+        self._add_mask_embed()
+        _add_linear(self, 'point_emb.0', f // 2, f)
+        _add_linear(self, 'point_emb.2', f // 2, f // 2)
+        _add_linear(self, 'point_emb.4', out_channels * 2 * per_pointset_point, f // 2)
+        self.mask_decoder = MODELS.build(mask_decoder)
+        # the reference keeps prompt_encoder.mask_embed as `sam_mask_embed` (models.py:297-305)
+        add_param(self, 'sam_mask_embed.conv1.weight', (4, 1, 2, 2))
+        add_param(self, 'sam_mask_embed.conv1.bias', (4,))
+        add_param(self, 'sam_mask_embed.conv2.weight', (16, 4, 2, 2))
+        add_param(self, 'sam_mask_embed.conv2.bias', (16,))
+        add_param(self, 'sam_mask_embed.conv3.weight', (out_channels, 16, 1, 1))
+        add_param(self, 'sam_mask_embed.conv3.bias', (out_channels,))
+        _add_ln(self, 'sam_mask_embed.layer_norm1', 4)
+        _add_ln(self, 'sam_mask_embed.layer_norm2', 16)
+
+    def _pack(self):
+        P = self._pack_core(('cls_embed.0', 'cls_embed.2', 'point_emb.0', 'point_emb.2', 'point_emb.4'))
+        sm = self.sam_mask_embed
+        P['sam_embed'] = dict(conv1_w=sm.conv1.weight.detach().contiguous(), conv1_b=sm.conv1.bias.detach(),
+                              ln1_w=sm.layer_norm1.weight.detach(), ln1_b=sm.layer_norm1.bias.detach(),
+                              conv2_w=sm.conv2.weight.detach().contiguous(), conv2_b=sm.conv2.bias.detach(),
+                              ln2_w=sm.layer_norm2.weight.detach(), ln2_b=sm.layer_norm2.bias.detach(),
+                              conv3_w=sm.conv3.weight.detach().reshape(self.out_channels, 16).contiguous(),
+                              conv3_b=sm.conv3.bias.detach())
+        self._packed = P
+
+    def forward(self, x, batch_data_samples=None, image_embeddings=None, image_positional_embeddings=None):
+        """models.py:395-463 (inference schedule).  Returns (cls [B,Nq,nc+1], SAM low-res masks [B,Nq,4h,4w], trace)."""
+        if self._packed is None:
+            self._pack()
+        P = self._packed
+        B = x[0].shape[0]
+        Nq = self.num_queries
+        dn, mpp, trace = self._decode(x)
+        H0, W0 = mpp.shape[-2:]
         # ---- the last `_forward_head` in full: class logits, prompts, dense prompt, ONE SAM decoder call ----
         cls = self._mlp(dn, ('cls_embed.0', 'cls_embed.2')).view(B, Nq, self.num_classes + 1)
         pe = self._mlp(dn, ('point_emb.0', 'point_emb.2', 'point_emb.4'))
@@ -377,13 +451,12 @@ class RSMask2FormerHead(HIPModule):
         emb = nhwc_view(image_embeddings)
         he, we = emb.shape[1], emb.shape[2]
         roi_img = torch.arange(B, dtype=torch.int32, device=emb.device).repeat_interleave(Nq).contiguous()
-        src = ops.sam_mask_embed(mpp.view(B * Nq, H0, W0), emb.reshape(B * he * we, -1), roi_img, P['sam_embed'], he, we)
+        src = ops.sam_mask_embed(mpp.reshape(B * Nq, H0, W0), emb.reshape(B * he * we, -1), roi_img, P['sam_embed'], he, we)
         ident = torch.arange(B * Nq, dtype=torch.int32, device=emb.device)
         masks, _ = self.mask_decoder.mask_decoder.decode(None, image_positional_embeddings, sparse, None, ident,
                                                          want_iou=False, src_rows=src, hw=(he, we))
         mask_pred = masks.view(B, Nq, masks.shape[-2], masks.shape[-1])
-        trace.update(mask_pred_plus=mpp.view(B, Nq, H0, W0), sparse_embeddings=sparse, mask_features=mask_features,
-                     memory=mem)
+        trace.update(mask_pred_plus=mpp, sparse_embeddings=sparse)
         return cls, mask_pred, trace
 
     def predict(self, x, batch_data_samples, image_embeddings=None, image_positional_embeddings=None):
@@ -431,6 +504,12 @@ class RSMaskFormerFusionHead(HIPModule):
             r.query_indices = qidx
             results.append(dict(ins_results=r))
         return results
+
+
+@MODELS.register_module()
+class MaskFormerFusionHead(RSMaskFormerFusionHead):
+    """The reference's (edited) mmdet MaskFormerFusionHead.predict (maskformer_fusion_head.py:184-270) has the same body
+    as RSMaskFormerFusionHead.predict (models.py:662-715): crop by int(ori * scale_factor), resize, instance_postprocess."""
 
 
 @MODELS.register_module()
@@ -494,3 +573,56 @@ class RSPrompterQuery(BaseDetectorHIP):
         x, emb, pe = self.extract_feat(batch_inputs)
         cls, mask_pred, trace = self.panoptic_head(x, batch_data_samples, emb, pe)
         return [cls], [mask_pred], [trace['mask_pred_plus']]
+
+
+@MODELS.register_module()
+class SAMSegMask2Former(BaseDetectorHIP):
+    """models.py:1247-1274 over Mask2Former / MaskFormer (maskformer.py:18-170): SAM encoder -> RSFPN -> the standard
+    Mask2FormerHead -> MaskFormerFusionHead.  No prompt encoder, no SAM mask decoder."""
+
+    def __init__(self, backbone=None, neck=None, panoptic_head=None, panoptic_fusion_head=None, train_cfg=None,
+                 test_cfg=None, data_preprocessor=None, init_cfg=None):
+        super().__init__()
+        self.data_preprocessor = MODELS.build(data_preprocessor or dict(type='DetDataPreprocessor'))
+        self.backbone = MODELS.build(backbone)
+        self.neck = MODELS.build(neck) if neck is not None else None
+        ph = copy.deepcopy(dict(panoptic_head))             # maskformer.py:33-37
+        ph.update(train_cfg=train_cfg, test_cfg=test_cfg)
+        self.panoptic_head = MODELS.build(ph)
+        pf = copy.deepcopy(dict(panoptic_fusion_head))
+        pf.update(test_cfg=test_cfg)
+        self.panoptic_fusion_head = MODELS.build(pf)
+        self.num_things_classes = self.panoptic_head.num_things_classes
+        self.num_stuff_classes = self.panoptic_head.num_stuff_classes
+        self.num_classes = self.panoptic_head.num_classes
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.eval()
+
+    def extract_feat(self, batch_inputs):
+        """models.py:1262-1274: the neck output only."""
+        vo = self.backbone(batch_inputs)
+        if hasattr(vo, 'hidden_states') and vo.hidden_states is not None:
+            hs = vo[1]
+        elif isinstance(vo, tuple):
+            hs = vo
+        else:
+            raise NotImplementedError
+        return self.neck(hs)
+
+    @torch.no_grad()
+    def predict(self, batch_inputs, batch_data_samples, rescale=True):
+        """maskformer.py:83-151."""
+        x = self.extract_feat(batch_inputs)
+        cls, masks = self.panoptic_head.predict(x, batch_data_samples)
+        self._last_head_out = (cls, masks)
+        results = self.panoptic_fusion_head.predict(cls, masks, batch_data_samples, rescale=rescale)
+        for s, r in zip(batch_data_samples, results):
+            if 'ins_results' in r:
+                s.pred_instances = r['ins_results']
+        return batch_data_samples
+
+    @torch.no_grad()
+    def _forward(self, batch_inputs, batch_data_samples=None):
+        """`mode='tensor'` (maskformer.py:153-170): raw `(cls_pred_list, mask_pred_list)`, last decoder stage only."""
+        cls, mask_pred, _ = self.panoptic_head(self.extract_feat(batch_inputs), batch_data_samples)
+        return [cls], [mask_pred]

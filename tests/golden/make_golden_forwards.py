@@ -170,13 +170,10 @@ def seeded(m, seed):
     return m.eval()
 
 
-@torch.no_grad()
-def main():
-    reg, st = install()
+def load_sources():
+    """execute the real reference sources the module forwards are made of; returns (m2h, vs, models) modules"""
     L = mg._load
     mods = sys.modules
-    out = {}
-
     # ------------------------------------------------------------------ real leaf sources that ARE in the reference
     pe_mod = L('mmdet/models/layers/positional_encoding.py', '')
     pg = L('mmdet/models/task_modules/prior_generators/point_generator.py', '')
@@ -208,6 +205,14 @@ def main():
     vs = L('mmpretrain/models/backbones/vit_sam.py', '')
     models = L('mmdet/rsprompter/models.py', '')
     sam_adapters(models)
+    return m2h, vs, models
+
+
+@torch.no_grad()
+def main():
+    reg, st = install()
+    m2h, vs, models = load_sources()
+    out = {}
 
     # ------------------------------------------------------------------ RSSimpleFPN (+ RSFPN wiring) -- config values
     # of configs/rsprompter/_base_/rsprompter_anchor.py:82-89

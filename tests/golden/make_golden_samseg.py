@@ -3,6 +3,8 @@ mmdet/models/roi_heads/mask_heads/fcn_mask_head.py (stubs / stand-ins of make_go
   FCNMaskHead.{__init__, forward}            :27-150   (on the ConvModule stand-in; upsample / predictor = torch layers)
   FCNMaskHead._predict_by_feat_single        :276-420
   _do_paste_mask                             :423-480
+and for SAMSegMask2Former's head the REAL mmdet/models/dense_heads/mask2former_head.py (Mask2FormerHead.__init__ :62-156,
+_forward_head :340-380, forward :382-460) over msdeformattn_pixel_decoder.py / mask2former_layers.py.
 python tests/golden/make_golden_samseg.py -> tests/golden/reference_vectors_samseg.pt"""
 import os
 import sys
@@ -69,6 +71,26 @@ def main():
     bx = torch.tensor([[3.2, 4.1, 40.7, 33.3], [-6.0, 2.0, 20.0, 70.0], [10.0, 10.0, 12.0, 11.0], [0.0, 0.0, 64.0, 48.0]])
     pasted, _ = fcn._do_paste_mask(probs, bx, 48, 64, skip_empty=False)
     out['paste'] = dict(probs=probs, boxes=bx, img_hw=(48, 64), out=pasted.clone())
+
+    # ------------------------------------------------------------------ the STANDARD Mask2FormerHead of SAMSegMask2Former
+    # on the reference's own panoptic_head config (configs/rsprompter/samseg-mask2former-nwpu.py over its _base_)
+    import rsprompter_amd as ra
+    m2h, _, _ = mf.load_sources()
+    qcfg = ra.Config.fromfile('/root/reference/configs/rsprompter/samseg-mask2former-nwpu.py').model
+    ph = mf.CD({k: v for k, v in qcfg.panoptic_head.items() if k != 'type'})
+    NQ, NC, Bq = 10, 3, 2
+    ph.update(num_queries=NQ, num_things_classes=NC, train_cfg=None, test_cfg=None)
+    ph['loss_cls'] = mf.CD(dict(ph['loss_cls'], class_weight=[1.0] * NC + [0.1]))
+    head = mf.seeded(m2h.Mask2FormerHead(**ph), 32)
+    sizes = (32, 16, 8, 4, 2)
+    xs = [mf.rnd(310 + i, Bq, 256, s, s) for i, s in enumerate(sizes)]
+    mask_features, memories = head.pixel_decoder(xs)
+    cls_l, mask_l = head(xs, None)
+    out['m2f_head'] = dict(keys=mf.keyshapes(head), seed=32, num_queries=NQ, num_classes=NC, batch=Bq,
+                           xs=[(310 + i, (Bq, 256, s, s)) for i, s in enumerate(sizes)],
+                           mask_features=mask_features[:, ::4, ::2, ::2].clone(), memories=[m[:, ::4].clone() for m in memories],
+                           cls_pred_all=[c.clone() for c in cls_l], mask_pred_all=[m[:, :, ::2, ::2].clone() for m in mask_l],
+                           mask_pred=mask_l[-1].clone())
     torch.save(out, OUT)
     print('wrote', OUT, os.path.getsize(OUT) // 1024, 'KiB')
 

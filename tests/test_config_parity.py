@@ -119,3 +119,20 @@ def test_reference_samseg_maskrcnn_configs_build(fname, nc):
               'roi_head.mask_head.conv_logits.bias', 'roi_head.bbox_head.fc_reg.weight', 'rpn_head.rpn_cls.weight']:
         assert k in keys, k
     assert not any('mask_decoder' in k or 'shared_image_embedding' in k for k in keys)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
+@pytest.mark.parametrize('fname,nc,nq', [('samseg-mask2former-nwpu.py', 10, 70), ('samseg-mask2former-ssdd.py', 1, None),
+                                         ('samseg-mask2former-whu.py', 1, None)])
+def test_reference_samseg_mask2former_configs_build(fname, nc, nq):
+    """the SAMSegMask2Former sibling model builds from the reference's config files unchanged."""
+    import rsprompter_amd as ra
+    from rsprompter_amd.default_configs import samseg_mask2former
+    cfg = ra.Config.fromfile(os.path.join(REF, fname))
+    nq = cfg.model.panoptic_head.num_queries
+    assert _norm(cfg.model) == _norm(samseg_mask2former('base', nc, nq))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = ra.build_model(cfg)
+    assert type(m).__name__ == 'SAMSegMask2Former' and type(m.panoptic_head).__name__ == 'Mask2FormerHead'
+    assert m.panoptic_head.num_transformer_decoder_layers == 9 and m.panoptic_head.pixel_decoder.feat == 256

@@ -272,3 +272,43 @@ def test_samseg_maskrcnn_end_to_end_host_logic(mocked):
     ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
     assert len(pairs) >= r['labels'].shape[0] - 2
     assert float((pi.masks[ii] != r['masks'][jj]).float().mean()) < 1e-3
+
+
+def test_samseg_mask2former_end_to_end_host_logic(mocked):
+    """SAMSegMask2Former.test_step (encoder + RSFPN + the standard Mask2FormerHead at feat 256 / 9 layers +
+    MaskFormerFusionHead) through the op stand-ins against oracle/samseg.py (pinned on the real Mask2FormerHead); the
+    model is built from the reference's own config file when it is present."""
+    import os
+    import warnings
+    import rsprompter_amd as ra
+    from oracle import glue
+    from oracle.samseg import SAMSegMask2FormerOracle
+    from rsprompter_amd.default_configs import samseg_mask2former
+    from rsprompter_amd.structures import DetDataSample
+    from rsprompter_amd.synth import synth_images, synth_metas, synth_state_dict
+    ref_cfg = '/root/reference/configs/rsprompter/samseg-mask2former-nwpu.py'
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        if os.path.exists(ref_cfg):
+            cfg = ra.Config.fromfile(ref_cfg)
+            assert cfg.model.type == 'SAMSegMask2Former' and cfg.model.panoptic_head.type == 'Mask2FormerHead'
+            model = ra.build_model(cfg)
+        else:
+            model = ra.build_model(samseg_mask2former('base', 10, 70))
+    oracle = SAMSegMask2FormerOracle('base', 10, num_queries=70)
+    sd = synth_state_dict(oracle, 0)
+    oracle.load_state_dict(sd)
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    imgs, metas = synth_images(1), synth_metas(1)
+    x = glue.data_preprocess(imgs, [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], True, 32)
+    ref, tr = oracle.predict(x, metas)
+    out = model.test_step(dict(inputs=imgs, data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
+    cls, masks = model._last_head_out
+    assert _err(cls, tr['cls_pred']) < 1e-4 and _err(masks.low_res, tr['mask_pred']) < 1e-3
+    pi, r = out[0].pred_instances, ref[0]
+    assert tuple(pi.masks.shape) == tuple(r['masks'].shape)
+    same = pi.query_indices.long() == r['query_indices']
+    assert int((~same).sum()) <= 2                      # only exact-tie swaps (see tests/_match.py)
+    assert _err(pi.scores[same], r['scores'][same]) < 1e-4
+    assert float((pi.masks[same] != r['masks'][same]).float().mean()) < 1e-3

@@ -135,3 +135,24 @@ def test_fcn_mask_head_and_paste_match_real_file():
         masks, bb, _ = samseg.fcn_predict_single(c['logits'], c['boxes'].clone(), c['labels'], c['meta'], 0.5, c['rescale'])
         assert masks.shape == c['masks'].shape and torch.equal(masks, c['masks'])
         assert torch.allclose(bb, c['boxes_out'])
+
+
+@torch.no_grad()
+def test_mask2former_head_matches_real_class():
+    """SAMSegMask2Former's panoptic head: the oracle against the REAL mmdet Mask2FormerHead (mask2former_head.py) run on
+    the reference's samseg-mask2former config (feat 256, 9 decoder layers, FFN 2048 / 1024, PE num_feats 128)."""
+    from oracle import samseg
+    g = torch.load(os.path.join(os.path.dirname(GOLD), 'reference_vectors_samseg.pt'), weights_only=False)['m2f_head']
+    m = load(samseg.Mask2FormerHead(g['num_classes'], g['num_queries']), g)
+    xs = [rnd(s) for s in g['xs']]
+    mf, mem = m.pixel_decoder(xs)
+    assert err(mf[:, ::4, ::2, ::2], g['mask_features']) < 1e-4
+    for a, b in zip(mem, g['memories']):
+        assert err(a[:, ::4], b) < 1e-4
+    cls, mask, tr = m(xs)
+    assert len(tr['cls_pred_all']) == len(g['cls_pred_all']) == 10
+    for a, b in zip(tr['cls_pred_all'], g['cls_pred_all']):
+        assert err(a, b) < 1e-4
+    for a, b in zip(tr['mask_pred_all'], g['mask_pred_all']):
+        assert err(a[:, :, ::2, ::2], b) < 2e-4
+    assert err(mask, g['mask_pred']) < 2e-4

@@ -329,7 +329,7 @@ def resize_bilinear(x_nhwc, size):
     return y.permute(0, 2, 3, 1).contiguous()
 
 
-def msdeform_attn(value, offs_weights, ref_points, B, Ntok, level_hw):
+def msdeform_attn(value, offs_weights, ref_points, B, Ntok, level_hw, head_dim=16):
     """mmcv MultiScaleDeformableAttention core (8 heads, 4 points) through the oracle's sampling restatement"""
     from oracle.query import MSDeformAttn
     H, L, P = 8, len(level_hw), 4
