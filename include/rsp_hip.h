@@ -40,6 +40,25 @@ int rsp_abi_version(void);
 const char* rsp_build_info(void);
 
 /* ------------------------------------------------------------------------ */
+/* Plane format word                                                          */
+/* ------------------------------------------------------------------------ */
+/* Every `*_scale_log2` argument / descriptor field that describes a pair of fp16 planes is a FORMAT WORD:          */
+/*   bits 0..7  (signed)  e: the planes hold x * 2^e                                                                  */
+/*   bit  8     RSP_PLANE_F8: the second plane is not lo = f16(x*2^e - hi) but the "cat8" plane of the                */
+/*              fp8-corrected product (same bytes: 64 per row and 32-wide K block):                                   */
+/*                bytes  0..31  e4m3(lo[k] * 2^RSP_F8_LO_EXP)      bytes 32..63  e4m3(hi[k] * 2^-RSP_F8_HI_EXP)       */
+/*              A GEMM whose A and B words both carry the bit computes                                                */
+/*                a_hi b_hi  (fp16 MFMA)  +  a_lo8 b_hi8 + a_hi8 b_lo8  (ONE K=64 fp8 MFMA per 32 k, MX block scales  */
+/*                2^-LO_EXP / 2^+HI_EXP undo the storage scales)                                                      */
+/*              -- 2 units of matrix time instead of 3, error class 2^-15 instead of 2^-22.     */
+#define RSP_PLANE_F8 0x100
+#define RSP_PLANE_EXP(w) ((int)(int8_t)((w) & 0xff))
+#define RSP_PLANE_IS_F8(w) (((w) & RSP_PLANE_F8) != 0)
+#define RSP_PLANE_WORD(e, f8) ((((int)(e)) & 0xff) | ((f8) ? RSP_PLANE_F8 : 0))
+#define RSP_F8_LO_EXP 5
+#define RSP_F8_HI_EXP 7
+
+/* ------------------------------------------------------------------------ */
 /* Weight preparation                                                        */
 /* ------------------------------------------------------------------------ */
 /* hi = f16(w * 2^e), lo = f16(w * 2^e - hi).  n elements.                   */

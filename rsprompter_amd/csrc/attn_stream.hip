@@ -92,6 +92,7 @@ struct AttnSP {
   int kv_e;
   const float* rel;                             // [Bp*nh, T, 2 S]
   float* out; half_t* out_hi; half_t* out_lo; float out_pscale; int64_t out_rows;
+  bool out_f8;                                  // output planes in the cat8 format (plane format word)
   int T, S, nh, D;
   float scale;
 };
@@ -412,13 +413,9 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
           for (int c = 0; c < 4; ++c) o[c] = acc_o[db][4 * g + c] * inv;
           if (dst) *reinterpret_cast<f32x4*>(dst + d0) = o;
           if (p.out_hi) {
-            half4_t h4, l4;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { half_t a, b; rsp_split1(o[c] * p.out_pscale, a, b); h4[c] = a; l4[c] = b; }
             const int col = h * DH + d0;
             const int64_t eo = ((int64_t)(col >> 5) * p.out_rows + (row0 + q)) * 32 + (col & 31);
-            *reinterpret_cast<half4_t*>(p.out_hi + eo) = h4;
-            *reinterpret_cast<half4_t*>(p.out_lo + eo) = l4;
+            rsp_store_planes4(p.out_hi, p.out_lo, eo, o * p.out_pscale, p.out_f8);
           }
         }
       }
@@ -451,11 +448,13 @@ extern "C" int rsp_vit_attention_planes(const float* q, int64_t q_ld, const uint
   if (!(S == 14 || S == 32 || S == 64)) return RSP_EINVAL;
   const int D = nh * dh;
   if ((D & 31) || (q_ld & 3) || kv_rows < (int64_t)Bp * S * S) return RSP_EINVAL;
+  if (RSP_PLANE_IS_F8(kv_scale_log2)) return RSP_EINVAL;   // K | V are consumed as fp16 hi / lo planes
   AttnSP p;
   p.q = q; p.q_ld = q_ld; p.kv_hi = reinterpret_cast<const half_t*>(kv_hi); p.kv_lo = reinterpret_cast<const half_t*>(kv_lo);
-  p.kv_rows = kv_rows; p.kv_e = kv_scale_log2; p.rel = rel; p.out = out;
+  p.kv_rows = kv_rows; p.kv_e = RSP_PLANE_EXP(kv_scale_log2); p.rel = rel; p.out = out;
   p.out_hi = reinterpret_cast<half_t*>(out_hi); p.out_lo = reinterpret_cast<half_t*>(out_lo);
-  p.out_pscale = ldexpf(1.0f, out_scale_log2); p.out_rows = (int64_t)Bp * S * S;
+  p.out_pscale = ldexpf(1.0f, RSP_PLANE_EXP(out_scale_log2)); p.out_f8 = out_hi && RSP_PLANE_IS_F8(out_scale_log2);
+  p.out_rows = (int64_t)Bp * S * S;
   p.T = S * S; p.S = S; p.nh = nh; p.D = D; p.scale = scale;
   hipStream_t s = (hipStream_t)stream;
   if (dh == 64) return launch_stream<64>(p, Bp, s);

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const GemmP p) {
   const int M = d.M, N = d.N, K = d.K;
   const int nbn = (N + BN - 1) / BN;          // 1-D grid, N-blocks fastest: neighbours share the A panel
   const int m0 = (int)(blockIdx.x / nbn) * BM, n0 = (int)(blockIdx.x % nbn) * BN;
-  const float a_scale = ldexpf(1.0f, d.a_scale_log2);
+  const float a_scale = ldexpf(1.0f, RSP_PLANE_EXP(d.a_scale_log2));
 
   // ---- per-thread A row bookkeeping (fixed across K tiles) ----
   const int a_kc = (tid & 7) << 2;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const GemmP p) {
         if (d.C) d.C[(int64_t)crow * d.ldc + col] = v;
         if (d.Chi) {
           half_t h, l;
-          rsp_split1(v * ldexpf(1.0f, d.c_scale_log2), h, l);
+          rsp_split1(v * ldexpf(1.0f, RSP_PLANE_EXP(d.c_scale_log2)), h, l);
           const int64_t po = ((int64_t)(col >> 5) * d.c_rows + crow) * 32 + (col & 31);   // KB32 layout
           reinterpret_cast<half_t*>(d.Chi)[po] = h;
           reinterpret_cast<half_t*>(d.Clo)[po] = l;
@@ -253,7 +253,7 @@ __global__ void split_f16_kernel(const float* __restrict__ w, half_t* __restrict
 
 // row-major [rows, K] fp32 -> KB32 planes [K/32][rows][32]; a thread handles 4 consecutive k
 __global__ void split_f16_kb32_kernel(const float* __restrict__ w, half_t* __restrict__ hi,
-                                      half_t* __restrict__ lo, int64_t rows, int K, float scale) {
+                                      half_t* __restrict__ lo, int64_t rows, int K, float scale, bool f8) {
   const int k4n = K / 4;
   const int64_t total = rows * k4n;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -261,12 +261,8 @@ __global__ void split_f16_kb32_kernel(const float* __restrict__ w, half_t* __res
     const int64_t r = i / k4n;
     const int k = (int)(i - r * k4n) * 4;
     const f32x4 v = *reinterpret_cast<const f32x4*>(w + r * K + k);
-    half4_t h4, l4;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { half_t a, b; rsp_split1(v[j] * scale, a, b); h4[j] = a; l4[j] = b; }
     const int64_t o = ((int64_t)(k >> 5) * rows + r) * 32 + (k & 31);
-    *reinterpret_cast<half4_t*>(hi + o) = h4;
-    *reinterpret_cast<half4_t*>(lo + o) = l4;
+    rsp_store_planes4(hi, lo, o, f32x4{v[0] * scale, v[1] * scale, v[2] * scale, v[3] * scale}, f8);
   }
 }
 
@@ -304,7 +300,7 @@ extern "C" int rsp_split_f16_kb32(const float* w, uint16_t* hi, uint16_t* lo, in
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(split_f16_kb32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, w,
                      reinterpret_cast<half_t*>(hi), reinterpret_cast<half_t*>(lo), rows, K,
-                     ldexpf(1.0f, scale_log2));
+                     ldexpf(1.0f, RSP_PLANE_EXP(scale_log2)), RSP_PLANE_IS_F8(scale_log2));
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }

@@ -89,8 +89,18 @@ __device__ __forceinline__ void static_for(F&& f) {
 // CONV: implicit-GEMM 3x3 convolution loader (A addresses from (pixel, tap)).
 // ORD: 0 = the three products of an accumulator back to back; 1 = pass-major (all a_lo b_hi, then all a_hi b_lo, then all
 // a_hi b_hi: dependent MFMAs TM*TN issue slots apart) -- tuning variant.
-template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false, int ORD = 0>
+// F8: fp8-corrected product (plane format word bit RSP_PLANE_F8): the "lo" planes of A and B are cat8 planes
+// [lo8 x 32 | hi8 x 32] per row and K block.  Half tile 0 = a_hi b_hi for BOTH 16-wide K halves (2 fp16 MFMAs per
+// accumulator), half tile 1 = ONE v_mfma_scale_f32_32x32x64_f8f6f4 per accumulator: lanes 0-31 feed a_lo8 against b_hi8,
+// lanes 32-63 a_hi8 against b_lo8 (its K = 64 is the two correction products side by side), the per-lane E8M0 block
+// scales undo the storage scales.  Same LDS image, same 12 ds_read_b128 per half tile, 128 instead of 192 matrix cycles
+// per accumulator and K tile.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false, int ORD = 0,
+          bool F8 = false>
 __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const GemmP p) {
+  static_assert(!F8 || (ORD == 0 && !CONV), "fp8-corrected product: plain GEMMs, accumulator-major order");
   constexpr int NT = WGM * WGN * 64;
   constexpr int WTM = BM / WGM, WTN = BN / WGN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -131,13 +141,20 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
 
   // ---- per-thread DMA slots.  A unit u = i*256 + tid: plane = u / (BM*4), row = (u % (BM*4)) / 4,
   //      physical 16-B position pos = u & 3 holds logical chunk pos ^ ((row >> 2) & 3).
-  const unsigned char* a_src[NA];  // plain mode: row base (bytes) incl. chunk offset; conv: plane base
-  bool a_ok[NA];
-  int a_chunkb[NA];                // byte offset of the logical chunk inside the K tile
-  int64_t a_pix[NA];               // conv: batch pixel base
-  int a_y[NA], a_x[NA];
+  // When a plane is a whole number of slots (A_PAIR / B_PAIR: every product tile) slot i + N/2 addresses the SAME rows
+  // of the second plane: only the first half of the slots keeps per-thread state (pointers are 2 VGPRs each), the
+  // plane distance rides on the wave-uniform K offset.
+  constexpr bool A_PAIR = (BM * 4) % NT == 0, B_PAIR = (BN * 4) % NT == 0;
+  constexpr int NAH = A_PAIR ? NA / 2 : NA, NBH = B_PAIR ? NB / 2 : NB;
+  const unsigned char* a_src[NAH];  // plain mode: row base (bytes) incl. chunk offset; conv: plane base
+  bool a_ok[NAH];
+  int a_chunkb[NAH];                // byte offset of the logical chunk inside the K tile
+  int64_t a_pix[NAH];               // conv: batch pixel base
+  int a_y[NAH], a_x[NAH];
+  const int64_t a_plane_d = reinterpret_cast<const unsigned char*>(d.Alo) - reinterpret_cast<const unsigned char*>(d.Ahi);
+  const int64_t b_plane_d = reinterpret_cast<const unsigned char*>(d.Blo) - reinterpret_cast<const unsigned char*>(d.Bhi);
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
+  for (int i = 0; i < NAH; ++i) {
     const int u = i * NT + tid;
     const int plane = u / (BM * 4);
     const int row = (u % (BM * 4)) >> 2;
@@ -165,10 +182,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
       }
     }
   }
-  const unsigned char* b_src[NB];
-  bool b_ok[NB], b_in[NB];
+  const unsigned char* b_src[NBH];
+  bool b_ok[NBH], b_in[NBH];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
+  for (int i = 0; i < NBH; ++i) {
     const int u = i * NT + tid;
     b_in[i] = u < B_UNITS;
     const int plane = u / (BN * 4);
@@ -204,19 +221,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   auto issue_slot = [&](auto ic, const TileK& t, unsigned char* lbase) {
     constexpr int I = decltype(ic)::value;
     if constexpr (I < NA) {
+      constexpr int H = I % NAH;                                   // per-thread state of this slot
+      const int64_t koff = (I >= NAH) ? t.koff + a_plane_d : t.koff;   // wave-uniform (scalar) part
       const unsigned char* src;
       if constexpr (!CONV) {
-        src = a_ok[I] ? a_src[I] + t.koff : zero;
+        src = a_ok[H] ? a_src[H] + koff : zero;
       } else {
-        const int y = a_y[I] + t.ky, x = a_x[I] + t.kx;
-        const bool inb = a_ok[I] && (unsigned)y < (unsigned)d.conv_H && (unsigned)x < (unsigned)d.conv_W;
-        src = a_src[I] + t.koff + (a_pix[I] + (int64_t)y * d.conv_W + x) * ROWB + a_chunkb[I];
+        const int y = a_y[H] + t.ky, x = a_x[H] + t.kx;
+        const bool inb = a_ok[H] && (unsigned)y < (unsigned)d.conv_H && (unsigned)x < (unsigned)d.conv_W;
+        src = a_src[H] + koff + (a_pix[H] + (int64_t)y * d.conv_W + x) * ROWB + a_chunkb[H];
         src = inb ? src : zero;
       }
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (I * NT + wave * 64) * 16), 16, 0, 0);
     } else {
-      constexpr int J = I - NA;
-      const unsigned char* src = b_ok[J] ? b_src[J] + t.koffb : zero;
+      constexpr int J = I - NA, H = J % NBH;
+      const int64_t koffb = (J >= NBH) ? t.koffb + b_plane_d : t.koffb;
+      const unsigned char* src = b_ok[H] ? b_src[H] + koffb : zero;
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (A_UNITS + J * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
@@ -249,10 +269,59 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
     for (int s = 0; s < 2; ++s) b_off[j][s] = r * ROWB + (((s * 2 + hh) ^ ((r >> 2) & 3)) << 4);
   }
 
+  // F8: cat8 fragment = 32 bytes per lane = chunks (2h, 2h+1) of the row; A: h = lane half (0 -> lo8, 1 -> hi8),
+  // B: h = the OTHER half (lanes 0-31 read hi8, lanes 32-63 lo8)
+  int a8_off[F8 ? TM : 1][2], b8_off[F8 ? TN : 1][2];
+  if constexpr (F8) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int r = wm * WTM + i * 32 + l31;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) a8_off[i][t] = OFF_ALO + r * ROWB + (((hh * 2 + t) ^ ((r >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int r = wn * WTN + j * 32 + l31;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) b8_off[j][t] = OFF_BLO + r * ROWB + ((((1 - hh) * 2 + t) ^ ((r >> 2) & 3)) << 4);
+    }
+  }
+  // E8M0 block scales (one per lane = per 32 k of the K = 64 instruction)
+  // (byte 0 = A's scale, byte 1 = B's: one register, selected with op_sel)
+  const int sc_ab = hh ? (127 + RSP_F8_HI_EXP) | ((127 - RSP_F8_LO_EXP) << 8) : (127 - RSP_F8_LO_EXP) | ((127 + RSP_F8_HI_EXP) << 8);
+
   const int nk = K / BK;
 
+  // F8: half tile 0 holds {ah = a_hi(k 0..15), al = a_hi(k 16..31), bh / bl likewise}, half tile 1 the two 16-byte
+  // pieces of the cat8 fragments
   struct Frags { half8_t ah[TM], al[TM], bh[TN], bl[TN]; };
   auto read_frags = [&](const unsigned char* sb, int s, Frags& f) {
+    if constexpr (F8) {
+      if (s == 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          f.ah[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i][0]);
+          f.al[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i][1]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f.bh[j] = *reinterpret_cast<const half8_t*>(sb + OFF_BHI + b_off[j][0]);
+          f.bl[j] = *reinterpret_cast<const half8_t*>(sb + OFF_BHI + b_off[j][1]);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          f.ah[i] = *reinterpret_cast<const half8_t*>(sb + a8_off[i][0]);
+          f.al[i] = *reinterpret_cast<const half8_t*>(sb + a8_off[i][1]);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          f.bh[j] = *reinterpret_cast<const half8_t*>(sb + b8_off[j][0]);
+          f.bl[j] = *reinterpret_cast<const half8_t*>(sb + b8_off[j][1]);
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       f.ah[i] = *reinterpret_cast<const half8_t*>(sb + a_off[i][s]);
@@ -264,7 +333,26 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
       f.bl[j] = *reinterpret_cast<const half8_t*>(sb + OFF_BLO + b_off[j][s]);
     }
   };
-  auto mfma_frags = [&](const Frags& f) {
+  // the matrix work of ONE accumulator for half tile s
+  auto mfma_one = [&](const Frags& f, int s, int i, int j) {
+    if constexpr (F8) {
+      if (s == 0) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bl[j], acc[i][j], 0, 0, 0);
+      } else {
+        const i32x8 a8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, f.ah[i]), __builtin_bit_cast(i32x4, f.al[i]),
+                                                 0, 1, 2, 3, 4, 5, 6, 7);
+        const i32x8 b8 = __builtin_shufflevector(__builtin_bit_cast(i32x4, f.bh[j]), __builtin_bit_cast(i32x4, f.bl[j]),
+                                                 0, 1, 2, 3, 4, 5, 6, 7);
+        acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[i][j], 0, 0, 0, sc_ab, 1, sc_ab);
+      }
+    } else {
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+    }
+  };
+  auto mfma_frags = [&](const Frags& f, int s) {
     if constexpr (ORD == 1 && ABL != 2) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -287,9 +375,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
         if (ABL == 2) {   // keep the fragments live without the matrix work
           asm volatile("" ::"v"(f.al[i]), "v"(f.ah[i]), "v"(f.bl[j]), "v"(f.bh[j]));
         } else {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+          mfma_one(f, s, i, j);
         }
       }
   };
@@ -297,7 +383,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   // the same matrix work with the LPT DMA instructions of one K tile spread between the (i, j) groups: a DMA costs
   // its wave 60-185 issue cycles (MI355X_MICROARCH.md, per-instruction constants); issued as one burst after the
   // barrier both waves of a SIMD stall together and the MFMA pipe idles, spread out they cover each other
-  auto mfma_frags_dma = [&](const Frags& f, int k0, int buf, bool do_issue) {
+  auto mfma_frags_dma = [&](const Frags& f, int s, int k0, int buf, bool do_issue) {
     const TileK t = tile_k(k0);
     unsigned char* lbase = &smem[buf][0];
     constexpr int G = TM * TN;
@@ -318,11 +404,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
     }
     static_for<0, G>([&](auto gc) {
       constexpr int g = decltype(gc)::value, i = g / TN, j = g % TN;
-      {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
-      }
+      mfma_one(f, s, i, j);
       __builtin_amdgcn_sched_barrier(0);
       if (do_issue) static_for<g * LPT / G, (g + 1) * LPT / G>([&](auto sc) { issue_slot(sc, t, lbase); });
       __builtin_amdgcn_sched_barrier(0);
@@ -352,7 +434,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
       for (int s = 0; s < 2; ++s) {
         Frags f;
         read_frags(sb, s, f);
-        mfma_frags(f);
+        mfma_frags(f, s);
       }
       if (++buf == NBUF) buf = 0;
     }
@@ -385,7 +467,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
       __builtin_amdgcn_s_waitcnt(WC_LGKM0);       // f0 has landed (issued half a step ago: free)
       read_frags(&smem[buf][0], 1, f1);
       __builtin_amdgcn_sched_barrier(0);          // keep the LDS reads AHEAD of the matrix work they overlap with
-      mfma_frags(f0);
+      mfma_frags(f0, 0);
       __builtin_amdgcn_sched_barrier(0);          // ... and the matrix work ahead of the wait + barrier it hides
       int nb = buf + 1;
       if (nb == NBUF) nb = 0;
@@ -397,11 +479,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
       read_frags(&smem[nb][0], 0, f0);
       __builtin_amdgcn_sched_barrier(0);
       if constexpr (PIPE == 2) {
-        mfma_frags_dma(f1, (kt + NBUF) * BK, buf, ABL == 0 && kt + NBUF < nk);   // DMA spread between the MFMAs
+        mfma_frags_dma(f1, 1, (kt + NBUF) * BK, buf, ABL == 0 && kt + NBUF < nk);   // DMA spread between the MFMAs
       } else {
         if (ABL == 0 && kt + NBUF < nk) issue_tile((kt + NBUF) * BK, buf);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_frags(f1);
+        mfma_frags(f1, 1);
       }
       __builtin_amdgcn_sched_barrier(0);
       buf = nb;
@@ -409,15 +491,16 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
     __builtin_amdgcn_s_waitcnt(WC_LGKM0);
     read_frags(&smem[buf][0], 1, f1);
     __builtin_amdgcn_sched_barrier(0);
-    mfma_frags(f0);
-    mfma_frags(f1);
+    mfma_frags(f0, 0);
+    mfma_frags(f1, 1);
   }
 
   // ---- epilogue (same contract as gemm.hip) + optional fp16-plane output for the next GEMM ----
   // The (i, j) loops are expanded by template recursion: a #pragma unroll the optimizer declines here turns the
   // accumulator indices dynamic and sends all of acc[][] to scratch.
   const float alpha = d.alpha;
-  const float cs = d.Chi ? ldexpf(1.0f, d.c_scale_log2) : 1.0f;
+  const float cs = d.Chi ? ldexpf(1.0f, RSP_PLANE_EXP(d.c_scale_log2)) : 1.0f;
+  const bool c_f8 = RSP_PLANE_IS_F8(d.c_scale_log2);   // output planes in the cat8 format (N % 4 == 0 checked by the host)
   half_t* const chi = reinterpret_cast<half_t*>(d.Chi);
   half_t* const clo = reinterpret_cast<half_t*>(d.Clo);
 
@@ -534,7 +617,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
           const int64_t ro = ((int64_t)(col >> 5) * d.res_rows + rrow) * 32 + (col & 31);
           const half4_t rh = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(d.res_hi) + ro);
           const half4_t rl = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(d.res_lo) + ro);
-          const float rsc = ldexpf(1.0f, -d.res_scale_log2);
+          const float rsc = ldexpf(1.0f, -RSP_PLANE_EXP(d.res_scale_log2));
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += ((float)rh[e] + (float)rl[e]) * rsc;
         }
@@ -564,14 +647,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
           int64_t prow = crow;
           int pch = col - d.pl_col0;
           if (ct) { const int dx = ccol >= ct_c; pch = ccol - dx * ct_c; prow = (int64_t)crow * 2 + dx; }
-          half4_t h4, l4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) { half_t a, b; rsp_split1(v[e] * cs, a, b); h4[e] = a; l4[e] = b; }
           const int64_t po = ((int64_t)(pch >> 5) * d.c_rows + prow) * 32 + (pch & 31);
-          if (vec) {
-            *reinterpret_cast<half4_t*>(chi + po) = h4;
-            *reinterpret_cast<half4_t*>(clo + po) = l4;
+          if (vec || c_f8) {
+            rsp_store_planes4(chi, clo, po, f32x4{v[0] * cs, v[1] * cs, v[2] * cs, v[3] * cs}, c_f8);
           } else {
+            half4_t h4, l4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { half_t a, b; rsp_split1(v[e] * cs, a, b); h4[e] = a; l4[e] = b; }
             for (int e = 0; e < nv; ++e) {      // ragged N: element-wise (a 4-group may straddle a 32-column block)
               const int pc = pch + e;
               const int64_t pe = ((int64_t)(pc >> 5) * d.c_rows + prow) * 32 + (pc & 31);
@@ -586,7 +668,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   }
 }
 
-template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false, int ORD = 0>
+template <int BM, int BN, int WGM, int WGN, int NBUF, int ABL = 0, int EPI = 0, int PIPE = 0, bool CONV = false, int ORD = 0,
+          bool F8 = false>
 int launch_dma(const RspGemmDesc& d, hipStream_t s) {
   GemmP p; p.d = d;
   p.group_m = (d.tile_hint >> 8) & 0xff;      // tuning field: tile_hint = tile | group_m << 8
@@ -595,7 +678,7 @@ int launch_dma(const RspGemmDesc& d, hipStream_t s) {
   p.fd_resb = make_fastdiv(d.res_brows); p.fd_hd = make_fastdiv(d.hd_rows);
   const long long nblk = (long long)((d.N + BN - 1) / BN) * ((d.M + BM - 1) / BM);
   if (nblk > 0x7fffffffLL) return RSP_EINVAL;
-  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF, ABL, EPI, PIPE, CONV, ORD>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
+  hipLaunchKernelGGL((gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF, ABL, EPI, PIPE, CONV, ORD, F8>), dim3((unsigned)nblk), dim3(WGM * WGN * 64), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
@@ -617,6 +700,9 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (d.hd_out && (d.C || d.Chi || d.res || d.c_rowmap)) return RSP_EINVAL;
   if ((d.pl_col0 || d.c_ncols) && (d.ct_W > 0 || (d.pl_col0 & 31) || (d.c_ncols & 3) || d.pl_col0 < 0 || (d.N & 3)))
     return RSP_EINVAL;   // column-range outputs: plain GEMMs only, plane range on a 32-column boundary
+  const bool f8 = RSP_PLANE_IS_F8(d.a_scale_log2);   // A and W "lo" planes are cat8 planes (the caller pairs them)
+  if (f8 && (d.conv_k != 0 || d.N <= 64)) return RSP_EINVAL;
+  if (RSP_PLANE_IS_F8(d.c_scale_log2) && d.Chi && ((d.N & 3) || d.ct_W > 0)) return RSP_EINVAL;
   auto nblk = [&](int bm, int bn) { return (long long)((d.N + bn - 1) / bn) * ((d.M + bm - 1) / bm); };
   // Tile rule (tools/gemm_sweep.py on MI355X; run-to-run spread is a few %): the register-pipelined loops win
   // everywhere; 256x256 needs >= 4 rounds of blocks over the 256 CUs, 256x128 >= 2, else 128x128 (2 blocks/CU).
@@ -650,6 +736,11 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
       // (K = 1280 with only 3 rounds -- the proj shape -- stays with the small tile: 279 vs 252)
       if (d.N > 128 && (nblk(256, 256) >= 1024 || (nblk(256, 256) >= 512 && d.K >= 2048))) tile = 17;
     }
+  }
+  if (f8) {   // fp8-corrected product: the three tiles the rule above picks
+    if (tile == 17 && d.N > 128) return launch_dma<256, 256, 2, 4, 2, 0, 0, 2, false, 0, true>(d, s);
+    if ((tile == 18 || tile == 17) && d.N > 64) return launch_dma<256, 128, 4, 2, 2, 0, 0, 2, false, 0, true>(d, s);
+    return launch_dma<128, 128, 2, 2, 2, 0, 0, 1, false, 0, true>(d, s);
   }
   switch (tile) {   // hints >= 4 are benchmarking variants of the same arithmetic
     case 3: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2>(d, s); break;

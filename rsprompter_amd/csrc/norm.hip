@@ -12,7 +12,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         const float* __restrict__ beta,
                                                         float* __restrict__ y, int64_t rows, int C,
                                                         float eps, int act, half_t* __restrict__ yhi,
-                                                        half_t* __restrict__ ylo, float pscale) {
+                                                        half_t* __restrict__ ylo, float pscale, bool f8) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -61,16 +61,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       }
       if (y) *reinterpret_cast<f32x4*>(yr + c) = o;
       if (yhi) {
-        half4_t h4, l4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          half_t a, b;
-          rsp_split1(o[j] * pscale, a, b);
-          h4[j] = a; l4[j] = b;
-        }
         const int64_t po = ((int64_t)(c >> 5) * rows + row) * 32 + (c & 31);   // KB32 layout
-        *reinterpret_cast<half4_t*>(yhi + po) = h4;
-        *reinterpret_cast<half4_t*>(ylo + po) = l4;
+        rsp_store_planes4(yhi, ylo, po, f32x4{o[0] * pscale, o[1] * pscale, o[2] * pscale, o[3] * pscale}, f8);
       }
     }
   }
@@ -137,7 +129,9 @@ extern "C" int rsp_layernorm_ex(const float* x, const float* gamma, const float*
   hipStream_t s = (hipStream_t)stream;
   half_t* hi = reinterpret_cast<half_t*>(yhi);
   half_t* lo = reinterpret_cast<half_t*>(ylo);
-  const float ps = ldexpf(1.0f, scale_log2);
+  const float ps = ldexpf(1.0f, RSP_PLANE_EXP(scale_log2));
+  const bool f8 = yhi && RSP_PLANE_IS_F8(scale_log2);
+  if (f8 && C <= 64) return RSP_EINVAL;   // cat8 planes feed the wide encoder GEMMs only
   if (C <= 64) {
     const int64_t blocks = (rows + 15) / 16;
     if (blocks > 0x7fffffffLL) return RSP_EINVAL;
@@ -148,7 +142,7 @@ extern "C" int rsp_layernorm_ex(const float* x, const float* gamma, const float*
   const int64_t blocks = (rows + 3) / 4;
   if (blocks > 0x7fffffffLL) return RSP_EINVAL;
   // one instantiation per 256-channel step actually used (ViT widths 768 / 1024 / 1280): no idle chunk iterations
-#define RSP_LN_LAUNCH(NC) hipLaunchKernelGGL((layernorm_kernel<NC>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act, hi, lo, ps)
+#define RSP_LN_LAUNCH(NC) hipLaunchKernelGGL((layernorm_kernel<NC>), dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, beta, y, rows, C, eps, act, hi, lo, ps, f8)
   if (C <= 256) RSP_LN_LAUNCH(1);
   else if (C <= 512) RSP_LN_LAUNCH(2);
   else if (C <= 768) RSP_LN_LAUNCH(3);

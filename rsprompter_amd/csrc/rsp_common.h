@@ -32,6 +32,38 @@ __device__ __forceinline__ void rsp_split1(float x, half_t& hi, half_t& lo) {
   lo = (half_t)__builtin_fminf(__builtin_fmaxf(r, -RSP_F16_MAX), RSP_F16_MAX);
 }
 
+// ---- plane stores (format word: include/rsp_hip.h "Plane format word") -------------------------------------------
+// four fp32 -> four OCP e4m3 bytes (round to nearest even; clamped to +-448 first: e4m3 has no inf)
+__device__ __forceinline__ uint32_t rsp_pack4_e4m3(float a, float b, float c, float d) {
+  auto cl = [](float x) { return __builtin_fminf(__builtin_fmaxf(x, -448.0f), 448.0f); };
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(a), cl(b), 0, false);
+  w = __builtin_amdgcn_cvt_pk_fp8_f32(cl(c), cl(d), w, true);
+  return (uint32_t)w;
+}
+// store 4 consecutive k (k % 4 == 0) of one row: `o` = element offset inside the KB32 plane ([K/32][rows][32]);
+// v already carries the plane scale 2^e.  f8 = the second plane is the cat8 plane.
+__device__ __forceinline__ void rsp_store_planes4(half_t* hi, half_t* lo, int64_t o, const f32x4 v, bool f8) {
+  half4_t h4, l4;
+  float r[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const float xh = __builtin_fminf(__builtin_fmaxf(v[e], -RSP_F16_MAX), RSP_F16_MAX);
+    h4[e] = (half_t)xh;
+    r[e] = v[e] - (float)h4[e];
+    l4[e] = (half_t)__builtin_fminf(__builtin_fmaxf(r[e], -RSP_F16_MAX), RSP_F16_MAX);
+  }
+  *reinterpret_cast<half4_t*>(hi + o) = h4;
+  if (!f8) {
+    *reinterpret_cast<half4_t*>(lo + o) = l4;
+  } else {
+    constexpr float LS = (float)(1 << RSP_F8_LO_EXP), HS = 1.0f / (float)(1 << RSP_F8_HI_EXP);
+    unsigned char* cb = reinterpret_cast<unsigned char*>(lo) + (o & ~(int64_t)31) * 2 + (o & 31);
+    *reinterpret_cast<uint32_t*>(cb) = rsp_pack4_e4m3(r[0] * LS, r[1] * LS, r[2] * LS, r[3] * LS);
+    *reinterpret_cast<uint32_t*>(cb + 32) = rsp_pack4_e4m3((float)h4[0] * HS, (float)h4[1] * HS, (float)h4[2] * HS,
+                                                          (float)h4[3] * HS);
+  }
+}
+
 // exact-erf GELU (nn.GELU default, HF "gelu").  erf through Abramowitz-Stegun 7.1.26 (|err| <= 1.5e-7 absolute,
 // i.e. <= 1e-7 * |x| on the GELU value): branch-free, 2 transcendentals + ~12 VALU ops per element instead of the
 // two-branch libm erff (~40 with divergence).  GELU sits in GEMM epilogues (encoder lin1, SAM upscaler), where

@@ -2,6 +2,7 @@
 -> C-ABI calls into librsp_hip.so.  No arithmetic happens in torch here.
 """
 import math
+import os
 
 import torch
 
@@ -123,10 +124,12 @@ class PackedWeight:
     largest |w| lands near 2^14 (well inside fp16 range, lo plane normal).
     """
 
-    def __init__(self, w, bias=None, device=None):
+    def __init__(self, w, bias=None, device=None, f8=False):
+        """f8=True: the second plane is the cat8 plane of the fp8-corrected product (plane format word, rsp_hip.h)."""
         w = w.detach().to(torch.float32)
         if w.dim() != 2:
             raise ValueError("PackedWeight expects a 2-D [N, K] matrix")
+        self.f8 = bool(f8)
         device = device or w.device
         n, k = w.shape
         kpad = (k + 31) // 32 * 32
@@ -146,18 +149,34 @@ class PackedWeight:
         self.lo = torch.empty((kpad // 32, n, 32), dtype=torch.float16, device=device)
         lib = _lib.load()
         _lib.check(lib.rsp_split_f16_kb32(wd.data_ptr(), self.hi.data_ptr(), self.lo.data_ptr(),
-                                          n, kpad, e, _stream()), "rsp_split_f16_kb32")
+                                          n, kpad, plane_word(e, self.f8), _stream()), "rsp_split_f16_kb32")
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
+
+
+PLANE_F8 = 0x100        # include/rsp_hip.h "Plane format word"
+# encoder GEMMs as fp16 hi.hi + ONE fp8 correction MFMA (2 units of matrix time instead of 3; error class 2^-15):
+# RSP_F8CORR=0 restores the three-pass fp16x3 product everywhere
+F8_CORR = os.environ.get('RSP_F8CORR', '1') != '0'
+
+
+def plane_word(scale_log2, f8=False):
+    return (int(scale_log2) & 0xff) | (PLANE_F8 if f8 else 0)
 
 
 class Planes:
     """An fp32 matrix x [rows, K] held as two fp16 tensors hi = f16(x * 2^e), lo = f16(x * 2^e - hi) in the
     K-blocked "KB32" layout [K/32][rows][32].  Same bytes as fp32; lets the GEMM stream its A operand
     HBM -> LDS with the DMA engine in contiguous 1-KiB bursts.  `shape` is the LOGICAL shape
-    (leading dims are free to re-factor: rows = prod(shape[:-1]))."""
+    (leading dims are free to re-factor: rows = prod(shape[:-1])).
+    f8=True: `lo` holds the cat8 plane [e4m3(lo) x 32 | e4m3(hi) x 32] of the fp8-corrected product instead (same
+    bytes); such planes feed GEMMs whose weight was packed with f8=True and nothing else."""
 
-    def __init__(self, hi, lo, shape, scale_log2=DEFAULT_A_SCALE_LOG2):
-        self.hi, self.lo, self.shape, self.scale_log2 = hi, lo, tuple(shape), scale_log2
+    def __init__(self, hi, lo, shape, scale_log2=DEFAULT_A_SCALE_LOG2, f8=False):
+        self.hi, self.lo, self.shape, self.scale_log2, self.f8 = hi, lo, tuple(shape), scale_log2, bool(f8)
+
+    @property
+    def word(self):
+        return plane_word(self.scale_log2, self.f8)
 
     @property
     def device(self):
@@ -174,12 +193,12 @@ class Planes:
             n *= v
         if shape[-1] != self.shape[-1] or n != self.rows:
             raise ValueError(f'cannot view planes {self.shape} as {shape}')
-        return Planes(self.hi, self.lo, shape, self.scale_log2)
+        return Planes(self.hi, self.lo, shape, self.scale_log2, self.f8)
 
     reshape = view
 
 
-def empty_planes(shape, device, scale_log2=DEFAULT_A_SCALE_LOG2):
+def empty_planes(shape, device, scale_log2=DEFAULT_A_SCALE_LOG2, f8=False):
     shape = tuple(shape)
     K = shape[-1]
     if K % 32:
@@ -188,18 +207,18 @@ def empty_planes(shape, device, scale_log2=DEFAULT_A_SCALE_LOG2):
     for v in shape[:-1]:
         rows *= v
     return Planes(torch.empty((K // 32, rows, 32), dtype=torch.float16, device=device),
-                  torch.empty((K // 32, rows, 32), dtype=torch.float16, device=device), shape, scale_log2)
+                  torch.empty((K // 32, rows, 32), dtype=torch.float16, device=device), shape, scale_log2, f8)
 
 
-def to_planes(x, scale_log2=DEFAULT_A_SCALE_LOG2):
+def to_planes(x, scale_log2=DEFAULT_A_SCALE_LOG2, f8=False):
     """fp32 tensor -> Planes (one extra HBM pass; producers that can emit planes directly avoid it)."""
     lib = _lib.load()
     _chk_f32(x, "x")
     x = x if x.is_contiguous() else x.contiguous()
-    p = empty_planes(x.shape, x.device, scale_log2)
+    p = empty_planes(x.shape, x.device, scale_log2, f8)
     _timed('split_f16_kernel', 0, 8.0 * x.numel(),
            lambda: _lib.check(lib.rsp_split_f16_kb32(x.data_ptr(), p.hi.data_ptr(), p.lo.data_ptr(), p.rows,
-                                                     x.shape[-1], scale_log2, _stream()), "rsp_split_f16_kb32"))
+                                                     x.shape[-1], p.word, _stream()), "rsp_split_f16_kb32"))
     return p
 
 
@@ -211,6 +230,7 @@ class PlaneWeight:
         self.N = planes.rows - r0 if n is None else n
         self.K = planes.shape[-1]
         self.scale_log2 = planes.scale_log2
+        self.f8 = planes.f8
         self.b_rows = planes.rows
         self.hi = planes.hi[:, r0:, :]
         self.lo = planes.lo[:, r0:, :]
@@ -246,22 +266,28 @@ def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30):
 
 def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, c_rowmap=None,
          M=None, out_rows=None, res_mod=0, a_scale_log2=DEFAULT_A_SCALE_LOG2, conv=None,
-         res_bmap=None, res_brows=0, out_planes=False, out_f32=True, dma="auto", tile_hint=0, c_ncols=0, pl_col0=0):
+         res_bmap=None, res_brows=0, out_planes=False, out_f32=True, dma="auto", tile_hint=0, c_ncols=0, pl_col0=0,
+         out_f8=False):
     """C = act(A @ W^T + bias) + res   (see RspGemmDesc in include/rsp_hip.h).
 
     a: [rows, K] fp32 (row stride = a.stride(0)) or, with conv=(k, stride, pad),
        an NHWC tensor [B, H, W, C].
+    A weight packed with f8=True selects the fp8-corrected product: `a` must then be f8 Planes (or an fp32 tensor, which
+    is converted); out_f8=True writes the output planes in that format for the next such GEMM.
     """
     lib = _lib.load()
+    w_f8 = bool(getattr(w, 'f8', False))
     if not isinstance(a, Planes):
         _chk_f32(a, "a")
         # the DMA fast path wants fp16 planes: convert once when the GEMM is big enough to amortise it
         if (dma is True or (dma == "auto" and w.N > 64 and w.K >= 128)) and a.is_contiguous() \
                 and a.shape[-1] % 32 == 0:
-            a = to_planes(a, a_scale_log2)
+            a = to_planes(a, a_scale_log2, w_f8)
     is_planes = isinstance(a, Planes)
     if is_planes:
         a_scale_log2 = a.scale_log2
+    if (a.f8 if is_planes else False) != w_f8:
+        raise ValueError('fp8-corrected product: A planes and the weight must both be packed with f8=True')
     d = _lib.RspGemmDesc()
     if conv is not None:
         k, stride, pad = conv
@@ -289,8 +315,8 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     if (c_ncols or pl_col0) and not (is_planes and out_planes):
         raise ValueError('column-range outputs (c_ncols / pl_col0) belong to the plane path with out_planes=True')
     if out_planes:
-        pl = empty_planes((rows, n - pl_col0), a.device)
-        d.Chi, d.Clo, d.c_scale_log2, d.c_rows = pl.hi.data_ptr(), pl.lo.data_ptr(), pl.scale_log2, rows
+        pl = empty_planes((rows, n - pl_col0), a.device, f8=out_f8)
+        d.Chi, d.Clo, d.c_scale_log2, d.c_rows = pl.hi.data_ptr(), pl.lo.data_ptr(), pl.word, rows
     d.c_ncols, d.pl_col0 = c_ncols, pl_col0
     if out is None and out_f32:
         out = torch.empty((rows, c_ncols or n), dtype=torch.float32, device=a.device)
@@ -320,10 +346,10 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.b_rows = getattr(w, 'b_rows', 0)
     d.tile_hint = tile_hint
     d.act = act
-    d.a_scale_log2 = a_scale_log2
+    d.a_scale_log2 = plane_word(a_scale_log2, w_f8)
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
     tile = _dma_tile_name(m, n, tile_hint, conv is not None, w.K) if is_planes else ('128x128' if n > 64 else ('128x64' if n > 32 else '128x32'))
-    kname = 'gemm_f16x3_dma_kernel' if is_planes else 'gemm_f16x3_kernel'
+    kname = ('gemm_f16f8_dma_kernel' if w_f8 else 'gemm_f16x3_dma_kernel') if is_planes else 'gemm_f16x3_kernel'
     _timed(f'{kname}<{tile}>', 2.0 * m * n * w.K, 4.0 * (m * w.K + m * n) + 4.0 * n * w.K,
            lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm"),
            detail=f'M={m} N={n} K={w.K}' + (' conv' if conv is not None else ''))
@@ -334,8 +360,8 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     return out
 
 
-def layernorm(x, gamma, beta, eps=1e-6, act=ACT_NONE, out=None, planes=False, f32=True):
-    """planes=True additionally returns the result as fp16 Planes (f32=False: planes only)."""
+def layernorm(x, gamma, beta, eps=1e-6, act=ACT_NONE, out=None, planes=False, f32=True, f8=False):
+    """planes=True additionally returns the result as fp16 Planes (f32=False: planes only; f8: cat8 second plane)."""
     lib = _lib.load()
     _chk_f32(x, "x")
     if not x.is_contiguous():
@@ -343,11 +369,11 @@ def layernorm(x, gamma, beta, eps=1e-6, act=ACT_NONE, out=None, planes=False, f3
     C = x.shape[-1]
     rows = x.numel() // C
     if planes:
-        pl = empty_planes(x.shape, x.device)
+        pl = empty_planes(x.shape, x.device, f8=f8)
         y = torch.empty_like(x) if f32 else None
         _timed('layernorm_kernel', 0, 8.0 * x.numel() + (4.0 * x.numel() if f32 else 0),
                lambda: _lib.check(lib.rsp_layernorm_ex(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), _ptr(y),
-                                                       pl.hi.data_ptr(), pl.lo.data_ptr(), pl.scale_log2, rows, C,
+                                                       pl.hi.data_ptr(), pl.lo.data_ptr(), pl.word, rows, C,
                                                        eps, act, _stream()), "rsp_layernorm_ex"))
         return (y, pl) if f32 else pl
     if out is None:
@@ -369,7 +395,7 @@ def vit_relpos(qkv, rel_pos_h, rel_pos_w, Bp, S, nh, dh, q_ld=None):
     return rel
 
 
-def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False):
+def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False, f8=False):
     """SAM ViT attention with q as fp32 rows [Bp*T, nh*dh] and K | V as the fp16 Planes [Bp*T, 2*nh*dh] the qkv GEMM
     wrote (gemm(..., out_planes=True, c_ncols=D, pl_col0=D)).  planes=True: the output only as Planes."""
     lib = _lib.load()
@@ -378,8 +404,10 @@ def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False):
         raise ValueError('kv must be the K | V planes of the qkv GEMM')
     _chk_f32(q, 'q')
     out = None if planes else torch.empty((Bp * T, D), dtype=torch.float32, device=q.device)
-    pl = empty_planes((Bp * T, D), q.device) if planes else None
-    hi, lo, e = (pl.hi.data_ptr(), pl.lo.data_ptr(), pl.scale_log2) if planes else (0, 0, 0)
+    pl = empty_planes((Bp * T, D), q.device, f8=f8) if planes else None
+    hi, lo, e = (pl.hi.data_ptr(), pl.lo.data_ptr(), pl.word) if planes else (0, 0, 0)
+    if kv.f8:
+        raise ValueError('K | V planes are consumed as fp16 hi / lo planes (qkv GEMM: out_f8=False)')
     kind = 'global' if T >= 1024 else 'window'
     _timed('attn_global_kernel<vit>' if kind == 'global' else 'attn_kernel<vit,window>', 4.0 * Bp * nh * T * T * dh, 0,
            lambda: _lib.check(lib.rsp_vit_attention_planes(q.data_ptr(), q.stride(0), kv.hi.data_ptr(), kv.lo.data_ptr(),

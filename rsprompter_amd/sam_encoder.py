@@ -111,7 +111,10 @@ class SamVisionEncoderHIP(HIPModule):
     def _pack(self):
         dev = self.pos_embed.device
         ops.require_device(dev)
-        P = {}
+        # the four big GEMMs of every block run the fp8-corrected product (ops.F8_CORR): weights and
+        # the activation planes feeding them (LN / attention / GELU epilogues) carry the cat8 second plane
+        f8 = bool(ops.F8_CORR)
+        P = {'f8': f8}
         w = self.patch_embed.projection.weight
         P['patch'] = ops.PackedWeight(w.reshape(w.shape[0], -1), self.patch_embed.projection.bias)
         P['pos'] = self.pos_embed.detach().reshape(-1, self.D).contiguous()
@@ -130,10 +133,10 @@ class SamVisionEncoderHIP(HIPModule):
                 S=s,
                 ln1=(ln1.weight.detach(), ln1.bias.detach()),
                 ln2=(ln2.weight.detach(), ln2.bias.detach()),
-                qkv=ops.PackedWeight(wq, L.attn.qkv.bias),
-                proj=ops.PackedWeight(L.attn.proj.weight, L.attn.proj.bias),
-                lin1=ops.PackedWeight(lin1.weight, lin1.bias),
-                lin2=ops.PackedWeight(lin2.weight, lin2.bias),
+                qkv=ops.PackedWeight(wq, L.attn.qkv.bias, f8=f8),
+                proj=ops.PackedWeight(L.attn.proj.weight, L.attn.proj.bias, f8=f8),
+                lin1=ops.PackedWeight(lin1.weight, lin1.bias, f8=f8),
+                lin2=ops.PackedWeight(lin2.weight, lin2.bias, f8=f8),
                 rph=resize_rel_pos(L.attn.rel_pos_h.detach(), s).contiguous(),
                 rpw=resize_rel_pos(L.attn.rel_pos_w.detach(), s).contiguous(),
             ))
@@ -187,11 +190,12 @@ class SamVisionEncoderHIP(HIPModule):
         del patches
         hidden = [x] if want_hidden else None
         scale = dh ** -0.5
+        f8 = P['f8']
         for i in range(self.depth):
             L = P['layers'][i]
             S = L['S']
             # GEMM A operands travel as fp16 (hi, lo) planes: LN / attention / GELU epilogues emit them
-            xn = ops.layernorm(x, L['ln1'][0], L['ln1'][1], self.eps, planes=True, f32=False)
+            xn = ops.layernorm(x, L['ln1'][0], L['ln1'][1], self.eps, planes=True, f32=False, f8=f8)
             # qkv projection: q leaves as fp32 (rel-pos + the attention's Q operand), K | V as the fp16 planes the
             # attention kernel DMAs -- no fp32 K / V tensor, no split pass, no transposed V (csrc/attn_stream.hip)
             if S == g:  # global attention layer
@@ -202,13 +206,13 @@ class SamVisionEncoderHIP(HIPModule):
                 Bp = B * nw * nw
                 q, kv = ops.gemm(xn, L['qkv'], a_rowmap=rowmap, M=Bp * S * S, out_planes=True, c_ncols=D, pl_col0=D)
             rel = ops.vit_relpos(q, L['rph'], L['rpw'], Bp, S, nh, dh, q_ld=D)
-            att = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=True)
+            att = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=True, f8=f8)
             qkv = (q, kv)
             # proj + window_unpartition + crop + residual (HF:830, 924-952, 969)
             x1 = ops.gemm(att, L['proj'], res=x, c_rowmap=rowmap, out_rows=B * T)
             del qkv, rel, att, xn
-            xn2 = ops.layernorm(x1, L['ln2'][0], L['ln2'][1], self.eps, planes=True, f32=False)
-            hmid = ops.gemm(xn2, L['lin1'], act=ops.ACT_GELU, out_planes=True, out_f32=False)
+            xn2 = ops.layernorm(x1, L['ln2'][0], L['ln2'][1], self.eps, planes=True, f32=False, f8=f8)
+            hmid = ops.gemm(xn2, L['lin1'], act=ops.ACT_GELU, out_planes=True, out_f32=False, out_f8=f8)
             x = ops.gemm(hmid, L['lin2'], res=x1)
             del hmid, xn2, x1
             if want_hidden:

@@ -610,3 +610,71 @@ def test_gemm_plane_residual(dev):
     pw = ops.PackedWeight(w, b, device=dev)
     out = ops.gemm(ops.to_planes(a.to(dev)), pw, res=ops.to_planes(res.to(dev)), res_bmap=mp.to(dev), res_brows=200)
     assert _rel_err(out, ref) < 2e-6
+
+
+def _emu_f8corr(a, w, ea, ew):
+    """CPU emulation of the fp8-corrected product (include/rsp_hip.h "Plane format word"): fp16 hi . hi plus the two
+    cross terms with e4m3 operands under the static storage scales 2^5 (lo) / 2^-7 (hi); fp64 accumulation."""
+    def parts(x, e):
+        xs = x.double() * 2.0 ** e
+        hi = xs.float().clamp(-65504, 65504).half().double()
+        lo = xs - hi
+        lo8 = (lo * 32).float().clamp(-448, 448).to(torch.float8_e4m3fn).double() / 32
+        hi8 = (hi / 128).float().clamp(-448, 448).to(torch.float8_e4m3fn).double() * 128
+        return hi, lo8, hi8
+    ah, al8, ah8 = parts(a, ea)
+    wh, wl8, wh8 = parts(w, ew)
+    return (ah @ wh.t() + al8 @ wh8.t() + ah8 @ wl8.t()) * 2.0 ** -(ea + ew)
+
+
+@pytest.mark.parametrize('hint', [14, 18, 17])
+def test_gemm_fp8_corrected_product(dev, hint):
+    """RSP_PLANE_F8 GEMM (fp16 hi.hi + one K = 64 fp8 MFMA for both cross terms) on the three tiles it is built for:
+    the kernel against a CPU emulation of the same arithmetic (data path: cat8 layout, lane halves, block scales) and
+    against the exact product (error class 2^-15 of sum |a||w|)."""
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(21 + hint)
+    M, N, K = 600, 512, 1280
+    a = torch.randn(M, K, generator=g) * torch.exp(torch.randn(M, 1, generator=g))       # rows of different magnitude
+    a[5, 7] = 900.0                                                                       # an outlier activation
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    pw = ops.PackedWeight(w, b, device=dev, f8=True)
+    pa = ops.to_planes(a.to(dev), f8=True)
+    assert pa.f8 and pw.f8
+    out = ops.gemm(pa, pw, tile_hint=hint).cpu().double()
+    exact = a.double() @ w.double().t() + b.double()
+    emu = _emu_f8corr(a, w, pa.scale_log2, pw.scale_log2) + b.double()
+    mag = (a.double().abs() @ w.double().abs().t())
+    e_emu = float(((out - emu).abs() / mag).max())
+    e_exact = float(((out - exact).abs() / mag).max())
+    print(f'tile hint {hint}: vs emulation {e_emu:.2e}, vs exact {e_exact:.2e} (relative to sum |a||w|)')
+    assert e_emu < 2e-6            # fp32 accumulation noise only
+    assert e_exact < 2.0 ** -13    # 2^-15 class; worst element of 300 k
+    with pytest.raises(ValueError):
+        ops.gemm(ops.to_planes(a.to(dev)), pw)            # plain planes against an f8 weight
+
+
+def test_gemm_fp8_chain_with_rowmap_and_f8_output(dev):
+    """two chained f8 GEMMs like lin1 -> GELU -> lin2: the first reads a row-gathered A and writes cat8 planes from
+    its epilogue, the second consumes them; LayerNorm's cat8 output feeds the first."""
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(5)
+    rows, M, K, H = 300, 400, 256, 512
+    x = torch.randn(rows, K, generator=g) * 3 + 0.5
+    gamma, beta = torch.randn(K, generator=g), torch.randn(K, generator=g)
+    w1, b1 = torch.randn(H, K, generator=g) / K ** 0.5, torch.randn(H, generator=g)
+    w2, b2 = torch.randn(K, H, generator=g) / H ** 0.5, torch.randn(K, generator=g)
+    rowmap = torch.randint(-1, rows, (M,), generator=g, dtype=torch.int32)
+    xn = F.layer_norm(x.double(), (K,), gamma.double(), beta.double(), 1e-6)
+    src = torch.where((rowmap >= 0)[:, None], xn[rowmap.clamp(min=0).long()], torch.zeros(1, dtype=torch.float64))
+    h = F.gelu(src @ w1.double().t() + b1.double())
+    ref = h @ w2.double().t() + b2.double()
+    pl = ops.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), 1e-6, planes=True, f32=False, f8=True)
+    hm = ops.gemm(pl, ops.PackedWeight(w1, b1, device=dev, f8=True), a_rowmap=rowmap.to(dev), M=M, act=ops.ACT_GELU,
+                  out_planes=True, out_f32=False, out_f8=True)
+    assert hm.f8
+    out = ops.gemm(hm, ops.PackedWeight(w2, b2, device=dev, f8=True)).cpu().double()
+    e = float((out - ref).abs().max())
+    print(f'f8 chain LN -> lin1 -> GELU -> lin2: max err {e:.2e} (range {float(ref.abs().max()):.1f})')
+    assert e < 5e-4

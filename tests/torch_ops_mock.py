@@ -11,6 +11,7 @@ import torch.nn.functional as F
 
 ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
 DEFAULT_A_SCALE_LOG2 = 6
+F8_CORR = True          # the flag only travels through the host wiring here (planes are fp32 tensors in the mock)
 
 
 def require_device(dev):
@@ -22,7 +23,7 @@ def _act(x, act):
 
 
 class PackedWeight:
-    def __init__(self, w, bias=None, device=None):
+    def __init__(self, w, bias=None, device=None, f8=False):
         self.w = w.detach().float()
         self.N, self.K = self.w.shape
         self.bias = None if bias is None else bias.detach().float()
@@ -31,7 +32,7 @@ class PackedWeight:
 
 def gemm(a, w, *, out=None, bias='auto', res=None, act=0, a_rowmap=None, c_rowmap=None, M=None, out_rows=None,
          res_mod=0, a_scale_log2=6, conv=None, res_bmap=None, res_brows=0, out_planes=False, out_f32=True,
-         dma='auto', tile_hint=0, c_ncols=0, pl_col0=0):
+         dma='auto', tile_hint=0, c_ncols=0, pl_col0=0, out_f8=False):
     if conv is not None:
         k, s, p = conv
         B, H, W, C = a.shape
@@ -68,7 +69,7 @@ def gemm(a, w, *, out=None, bias='auto', res=None, act=0, a_rowmap=None, c_rowma
     return (out, out) if (out_planes and out_f32) else out
 
 
-def layernorm(x, gamma, beta, eps=1e-6, act=0, out=None, planes=False, f32=True):
+def layernorm(x, gamma, beta, eps=1e-6, act=0, out=None, planes=False, f32=True, f8=False):
     # the mock keeps "planes" as plain fp32 tensors: only the host wiring is under test
     y = _act(F.layer_norm(x, (x.shape[-1],), gamma, beta, eps), act)
     return (y, y) if (planes and f32) else y
@@ -95,7 +96,7 @@ def vit_attention(qkv, rel, Bp, S, nh, dh, scale, planes=False):
     return (attn @ v).view(Bp, nh, T, dh).permute(0, 2, 1, 3).reshape(Bp * T, nh * dh)
 
 
-def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False):
+def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False, f8=False):
     T = S * S
     qkv = torch.cat([q.view(Bp * T, 1, nh * dh), kv.view(Bp * T, 2, nh * dh)], 1)
     return vit_attention(qkv.reshape(Bp * T, 3 * nh * dh), rel, Bp, S, nh, dh, scale)
@@ -132,11 +133,11 @@ def conv_transpose2x2(x, w_dy, bias, act=0, a_scale_log2=6, out_planes=False, hy
     return out
 
 
-def empty_planes(shape, device, scale_log2=6):
+def empty_planes(shape, device, scale_log2=6, f8=False):
     return torch.zeros(shape)
 
 
-def to_planes(x, scale_log2=6):
+def to_planes(x, scale_log2=6, f8=False):
     return x
 
 
