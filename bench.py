@@ -140,6 +140,9 @@ def main():
                     help="prompter variant; the headline line is 'anchor' (BASELINE.json configs[3])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shapes', action='store_true', help='break the kernel table down by GEMM/attention shape')
+    ap.add_argument('--f8corr', action='store_true',
+                    help='opt-in fast mode: encoder GEMMs as fp16 hi.hi + one fp8 correction MFMA (DESIGN.md section 3); '
+                         'NOT the headline configuration -- parity margins are 8x smaller')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -161,6 +164,8 @@ def main():
 
     from rsprompter_amd import dist as rdist
     from rsprompter_amd import ops
+    if args.f8corr:
+        ops.F8_CORR = True
     from rsprompter_amd.structures import DetDataSample
     from rsprompter_amd.synth import synth_images, synth_metas
     import torch.distributed as tdist
@@ -252,7 +257,8 @@ def main():
             'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32 (fp32 in/out; GEMMs and attention as fp16x3 split-precision MFMA with fp32 accumulate)',
+            'dtype': 'f32 (fp32 in/out; GEMMs and attention as fp16x3 split-precision MFMA with fp32 accumulate'
+                     + ('; --f8corr: encoder GEMMs as fp16 hi.hi + one fp8 (e4m3, MX block scales) correction MFMA)' if args.f8corr else ')'),
             'data': 'synthetic',
             'config': {'workload': f'rsprompter_{args.model} SAM-ViT-{args.arch}, batch {B}x1024x1024 per GPU, '
                                    f'{num_classes} classes, seeded synthetic weights' + _config_tag(args, B, world),
@@ -264,7 +270,8 @@ def main():
                          'traffic': (_pmc_traffic(args.arch) or {}).get('bytes_per_launch'), 'traffic_detail': _pmc_traffic(args.arch),
                          'note': 'achieved = algorithmic fp32 FLOPs (2MNK) of all launches of the kernel in one step / '
                                  'their summed HIP-event durations; the kernel issues 3 fp16 MFMA passes per algorithmic '
-                                 'FLOP (fp16x3), so its ceiling is peak/3 = 833 TFLOP/s',
+                                 'FLOP (fp16x3), so its ceiling is peak/3 = 833 TFLOP/s'
+                                 + (' (gemm_f16f8: 2 fp16 + 1 fp8 K=64 MFMA per 32 k = 2 units of matrix time, ceiling peak/2)' if args.f8corr else ''),
                          'frac_of_fp16x3_ceiling': round(achieved / (PEAK_F16_MFMA_TFLOPS / 3), 4)},
             'roofline_attention': {'bound': 'mfma', 'kernel': 'attn_kernel<vit>', 'achieved': None if attn_tf is None else round(attn_tf, 2),
                                    'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',

@@ -154,9 +154,12 @@ class PackedWeight:
 
 
 PLANE_F8 = 0x100        # include/rsp_hip.h "Plane format word"
-# encoder GEMMs as fp16 hi.hi + ONE fp8 correction MFMA (2 units of matrix time instead of 3; error class 2^-15):
-# RSP_F8CORR=0 restores the three-pass fp16x3 product everywhere
-F8_CORR = os.environ.get('RSP_F8CORR', '1') != '0'
+# Opt-in fast mode (RSP_F8CORR=1, or set ops.F8_CORR before the model is built / first run): the four big GEMMs of every
+# encoder block run fp16 hi.hi + ONE fp8 MFMA carrying both correction terms (2 units of matrix time instead of 3).
+# Measured: GEMMs 1.15-1.25x faster, image embeddings 1.0-1.4e-4 instead of 1.2-1.6e-5 off the fp32
+# reference -- inside the 1e-3 budget, but the masked query decoder then flips 10 instead of 4 attention-mask decisions
+# on the ViT-H + LoRA fixture, so the default stays the three-pass fp16x3 product.
+F8_CORR = os.environ.get('RSP_F8CORR', '0') == '1'
 
 
 def plane_word(scale_log2, f8=False):

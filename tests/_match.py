@@ -8,7 +8,8 @@ entries that tie with a neighbour / the cut-off score to within `tie`."""
 import torch
 
 
-def match_detections(p_boxes, p_scores, p_labels, r_boxes, r_scores, r_labels, box_tol=1e-2, tie=5e-5, max_odd=4):
+def match_detections(p_boxes, p_scores, p_labels, r_boxes, r_scores, r_labels, box_tol=1e-2, tie=5e-5, max_odd=4,
+                     score_tol=1e-4):
     p_boxes, p_scores, p_labels = p_boxes.detach().float().cpu(), p_scores.detach().float().cpu(), p_labels.detach().cpu()
     r_boxes, r_scores, r_labels = r_boxes.detach().float().cpu(), r_scores.detach().float().cpu(), r_labels.detach().cpu()
     k = r_scores.shape[0]
@@ -24,7 +25,7 @@ def match_detections(p_boxes, p_scores, p_labels, r_boxes, r_scores, r_labels, b
         d = (p_boxes - r_boxes[j]).abs().amax(1)
         d[(p_labels != r_labels[j]) | used] = float('inf')
         i = int(d.argmin())
-        if float(d[i]) < box_tol and abs(float(p_scores[i]) - float(r_scores[j])) < 1e-4:
+        if float(d[i]) < box_tol and abs(float(p_scores[i]) - float(r_scores[j])) < score_tol:
             used[i] = True
             pairs.append((i, j))
             if i != j:
