@@ -73,11 +73,14 @@ def _check_query(model, oracle, imgs, metas, dev, tag):
     print(f'{tag}: attention-mask bits that differ from the oracle per decoder layer: {flips} '
           f'({int(flipped_q.sum())} queries touched); 5 largest per-query logit errors: {["%.2e" % v for v in top]}; '
           f'median {float(per_q.median()):.2e}')
-    # The masked decoder thresholds its auxiliary masks (sigmoid < 0.5 <=> logit < 0, models.py:390): a logit within fp32
-    # noise of 0 may land on the other side -- a DISCRETE difference like a score tie in the anchor path.  A query whose
-    # attention mask differs in some layer attends one more / one fewer key, which moves its logits by more than
-    # round-off; it is held to 1e-2 and there may be at most 4 of them.  Every other query is held to the 1e-3 budget.
-    assert int(flipped_q.sum()) <= 4 and sum(flips) <= 8
+    # The masked decoder thresholds its auxiliary masks (sigmoid < 0.5 <=> logit < 0, models.py:390): a logit within the
+    # round-off of 0 lands on the other side -- a DISCRETE difference like a score tie in the anchor path.  How many:
+    # Nq x keys x layers = 100 x ~4300 x 6 = 2.6 M decisions per image, logits spread over +-5 (density ~0.1 per unit near
+    # 0), auxiliary-mask error ~2e-5 -> an expectation of ~5 differing bits (measured 4 and 5 on two runs of the ViT-H +
+    # LoRA fixture; 0-1 on the others).  The bound is the 99.9 % quantile of that Poisson count, not the observed value.
+    # A query whose attention mask differs in some layer attends one more / one fewer key, which moves its logits by more
+    # than round-off: such queries are held to 1e-2, every other query to the 1e-3 budget.
+    assert int(flipped_q.sum()) <= 12 and sum(flips) <= 14
     assert float(per_q[~flipped_q].max()) < LOGIT_TOL and e_cls < LOGIT_TOL
     assert float(per_q.max()) < 1e-2
     for b in range(len(imgs)):
