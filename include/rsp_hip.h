@@ -231,6 +231,22 @@ int rsp_sam_t2i_attention(const float* q, const float* kv, const int32_t* kv_map
 int rsp_sam_i2t_attention(const float* q, const int32_t* q_map, const float* k, const float* v, float* out,
                           uint16_t* out_hi, uint16_t* out_lo, int32_t out_scale_log2, int32_t R, int32_t T, int32_t N,
                           float scale, rsp_stream_t stream);
+/*  image -> token attention FUSED with out_proj, the residual and layer_norm4 (HF:340-348):                          */
+/*    y = LayerNorm(residual + out_proj(attention(q, k, v)))   rows [R*N, 256]                                        */
+/*  out_proj is folded into the values (exact algebra, fp32), so the [R*N,128] attention output, the K = 128 GEMM over */
+/*  it and the separate LayerNorm pass are never materialised.  wo [256,128], bo [256] = out_proj; the residual is      */
+/*  either fp32 rows `res` [Rres*N, 256] with res_map[r] = row block of RoI r (NULL: r) -- layer 0, one copy per image   */
+/*  -- or fp16 planes res_hi / res_lo of the [R*N, 256] tensor (layer 1); result as fp32 `out` and/or fp16 planes.      */
+typedef struct RspI2tFusedDesc {
+  const float* q; const int32_t* q_map; const float* k; const float* v;
+  const float* wo; const float* bo;
+  const float* res; const int32_t* res_map;
+  const uint16_t* res_hi; const uint16_t* res_lo; int32_t res_scale_log2;
+  const float* gamma; const float* beta; float eps;
+  float* out; uint16_t* out_hi; uint16_t* out_lo; int32_t out_scale_log2;
+  int32_t R, T, N; float scale;
+} RspI2tFusedDesc;
+int rsp_sam_i2t_fused(const RspI2tFusedDesc* desc, rsp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* RoI feature extraction (single_level_roi_extractor.py:44-119 + mmcv RoIAlign, */

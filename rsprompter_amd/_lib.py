@@ -60,6 +60,14 @@ class RspMaskEmbedDesc(ctypes.Structure):
         ("R", c_int), ("he", c_int), ("we", c_int), ("C", c_int), ("eps", c_float)]
 
 
+class RspI2tFusedDesc(ctypes.Structure):
+    _fields_ = [("q", c_void_p), ("q_map", c_void_p), ("k", c_void_p), ("v", c_void_p), ("wo", c_void_p), ("bo", c_void_p),
+                ("res", c_void_p), ("res_map", c_void_p), ("res_hi", c_void_p), ("res_lo", c_void_p),
+                ("res_scale_log2", c_int), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float),
+                ("out", c_void_p), ("out_hi", c_void_p), ("out_lo", c_void_p), ("out_scale_log2", c_int),
+                ("R", c_int), ("T", c_int), ("N", c_int), ("scale", c_float)]
+
+
 class RspRoiAlignDesc(ctypes.Structure):
     _fields_ = [
         ("feat", c_void_p * 4), ("pe", c_void_p * 4), ("H", c_int * 4), ("W", c_int * 4),
@@ -109,6 +117,7 @@ PROTOTYPES = {
     "rsp_sam_upscale2": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
                                  c_void_p, c_int, c_int, c_void_p]),
     "rsp_sam_t2i_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "rsp_sam_i2t_fused": (c_int, [ctypes.POINTER(RspI2tFusedDesc), c_void_p]),
     "rsp_sam_i2t_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                       c_int, c_int, c_int, c_float, c_void_p]),
     "rsp_roi_align": (c_int, [ctypes.POINTER(RspRoiAlignDesc), c_void_p]),

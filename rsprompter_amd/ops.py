@@ -420,6 +420,49 @@ def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False, f8=Fals
     return pl if planes else out
 
 
+SAM_I2T_FUSED_MAX_TOKENS = 10   # rsp_sam_i2t_fused (LDS budget); more tokens: sam_i2t_attention + GEMM + layernorm
+
+
+def sam_i2t_fused(q, k, v, wo, bo, gamma, beta, *, R, T, N, scale, eps=1e-6, q_map=None, res=None, res_map=None,
+                  res_planes=None, planes=True, f32=False):
+    """LayerNorm(residual + out_proj(image -> token attention)) in one kernel (HF:340-348), out_proj folded into the
+    values.  q [Rq*N,128] (q_map: RoI -> row block), k / v [R*T,128], wo [256,128] fp32, bo [256]; residual either fp32
+    rows `res` [Rres*N,256] (+ res_map) or Planes of the [R*N,256] tensor.  Returns Planes (and / or fp32)."""
+    lib = _lib.load()
+    for t, n in ((q, 'q'), (k, 'k'), (v, 'v'), (wo, 'wo'), (bo, 'bo'), (gamma, 'gamma'), (beta, 'beta')):
+        _chk_f32(t, n)
+        if not t.is_contiguous():
+            raise ValueError(f'sam_i2t_fused: {n} must be contiguous')
+    if tuple(wo.shape) != (256, 128) or q.shape[-1] != 128:
+        raise ValueError('sam_i2t_fused expects internal width 128 and a [256, 128] out_proj weight')
+    if (res is None) == (res_planes is None):
+        raise ValueError('sam_i2t_fused: exactly one of res / res_planes')
+    d = _lib.RspI2tFusedDesc()
+    d.q, d.q_map, d.k, d.v, d.wo, d.bo = q.data_ptr(), _ptr(q_map), k.data_ptr(), v.data_ptr(), wo.data_ptr(), bo.data_ptr()
+    if res is not None:
+        _chk_f32(res, 'res')
+        if not res.is_contiguous() or res.shape[-1] != 256:
+            raise ValueError('sam_i2t_fused: res must be contiguous rows of 256')
+        d.res, d.res_map = res.data_ptr(), _ptr(res_map)
+    else:
+        if res_planes.f8 or res_planes.rows != R * N or res_planes.shape[-1] != 256:
+            raise ValueError('sam_i2t_fused: res_planes must be the fp16 hi / lo planes of the [R*N, 256] tensor')
+        d.res_hi, d.res_lo, d.res_scale_log2 = res_planes.hi.data_ptr(), res_planes.lo.data_ptr(), res_planes.scale_log2
+    d.gamma, d.beta, d.eps = gamma.data_ptr(), beta.data_ptr(), eps
+    out = torch.empty((R * N, 256), dtype=torch.float32, device=q.device) if f32 else None
+    pl = empty_planes((R * N, 256), q.device) if planes else None
+    d.out = _ptr(out)
+    if pl is not None:
+        d.out_hi, d.out_lo, d.out_scale_log2 = pl.hi.data_ptr(), pl.lo.data_ptr(), pl.scale_log2
+    d.R, d.T, d.N, d.scale = R, T, N, scale
+    # algorithmic work: scores + the folded out_proj product; bytes: q + residual + result rows
+    _timed('sam_i2t_fused_kernel', 2.0 * R * N * T * (128 + 8 * 256), 4.0 * R * N * (128 + 256 + 256),
+           lambda: _lib.check(lib.rsp_sam_i2t_fused(d, _stream()), "rsp_sam_i2t_fused"), detail=f'R={R} T={T} N={N}')
+    if planes and f32:
+        return out, pl
+    return pl if planes else out
+
+
 _attn_ws = {}
 
 

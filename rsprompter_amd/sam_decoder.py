@@ -235,14 +235,23 @@ class SamMaskDecoderHIP(HIPModule):
                       res=pe_t['0.cross_attn_image_to_token.q_proj'], res_mod=N)
         kt = ops.gemm(qpe, P['0.cross_attn_image_to_token.k_proj'])
         vt = ops.gemm(q, P['0.cross_attn_image_to_token.v_proj'])
-        ai = ops.empty_planes((R * N, d2), dev)      # attention output goes straight to the out_proj GEMM as planes
-        self._i2t(qi, kt, vt, ai, R, T, N, q_map=roi_img)
-        keys = ops.gemm(ai, P['0.cross_attn_image_to_token.out_proj'], res=src, res_bmap=roi_img, res_brows=N)
-        # layer_norm4 emits planes only: they are both the A operand of layer 1's projections and (hi + lo) the
-        # residual of its out_proj GEMM, so the fp32 copy of the per-RoI keys is never written
         m4 = _g(self, 'transformer.layers.0.layer_norm4')
-        keys_pl = ops.layernorm(keys, m4.weight, m4.bias, 1e-6, planes=True, f32=False)   # [R*N, 256] planes
-        del keys
+        fused = T <= ops.SAM_I2T_FUSED_MAX_TOKENS
+        ai = None
+        if fused:
+            # attention + out_proj (folded into the values) + residual (the per-IMAGE src rows) + layer_norm4 in one
+            # kernel: neither the [R*N, 128] attention output nor the fp32 [R*N, 256] keys are ever written
+            op = _g(self, 'transformer.layers.0.cross_attn_image_to_token.out_proj')
+            keys_pl = ops.sam_i2t_fused(qi, kt, vt, op.weight.detach(), op.bias.detach(), m4.weight, m4.bias, R=R, T=T,
+                                        N=N, scale=dh2 ** -0.5, eps=1e-6, q_map=roi_img, res=src, res_map=roi_img)
+        else:
+            ai = ops.empty_planes((R * N, d2), dev)  # attention output goes straight to the out_proj GEMM as planes
+            self._i2t(qi, kt, vt, ai, R, T, N, q_map=roi_img)
+            keys = ops.gemm(ai, P['0.cross_attn_image_to_token.out_proj'], res=src, res_bmap=roi_img, res_brows=N)
+            # layer_norm4 emits planes only: they are both the A operand of layer 1's projections and (hi + lo) the
+            # residual of its out_proj GEMM, so the fp32 copy of the per-RoI keys is never written
+            keys_pl = ops.layernorm(keys, m4.weight, m4.bias, 1e-6, planes=True, f32=False)   # [R*N, 256] planes
+            del keys
         del qi, kv_img
 
         # ---------------- layer 1 ----------------
@@ -264,11 +273,16 @@ class SamMaskDecoderHIP(HIPModule):
                       res=pe_t['1.cross_attn_image_to_token.q_proj'], res_mod=N)
         kt = ops.gemm(qpe, P['1.cross_attn_image_to_token.k_proj'])
         vt = ops.gemm(q, P['1.cross_attn_image_to_token.v_proj'])
-        self._i2t(qi, kt, vt, ai, R, T, N)
-        keys = ops.gemm(ai, P['1.cross_attn_image_to_token.out_proj'], res=keys_pl)
         m4 = _g(self, 'transformer.layers.1.layer_norm4')
-        keys_pl = ops.layernorm(keys, m4.weight, m4.bias, 1e-6, planes=True, f32=False)   # planes only from here on
-        del keys
+        if fused:
+            op = _g(self, 'transformer.layers.1.cross_attn_image_to_token.out_proj')
+            keys_pl = ops.sam_i2t_fused(qi, kt, vt, op.weight.detach(), op.bias.detach(), m4.weight, m4.bias, R=R, T=T,
+                                        N=N, scale=dh2 ** -0.5, eps=1e-6, res_planes=keys_pl)
+        else:
+            self._i2t(qi, kt, vt, ai, R, T, N)
+            keys = ops.gemm(ai, P['1.cross_attn_image_to_token.out_proj'], res=keys_pl)
+            keys_pl = ops.layernorm(keys, m4.weight, m4.bias, 1e-6, planes=True, f32=False)   # planes only from here on
+            del keys
 
         # ---------------- final token -> image attention (HF:396-404; LayerNorm default eps 1e-5) ----
         qpe = ops.add_rows(q, tokens0)

@@ -678,3 +678,45 @@ def test_gemm_fp8_chain_with_rowmap_and_f8_output(dev):
     e = float((out - ref).abs().max())
     print(f'f8 chain LN -> lin1 -> GELU -> lin2: max err {e:.2e} (range {float(ref.abs().max()):.1f})')
     assert e < 5e-4
+
+
+@pytest.mark.parametrize('T,N,planes_res', [(10, 600, False), (10, 1024, True), (7, 520, True), (3, 64, False)])
+def test_sam_i2t_fused_matches_composition(dev, T, N, planes_res):
+    """rsp_sam_i2t_fused = LayerNorm(residual + out_proj(image -> token attention)) (HF:340-348) against the fp64
+    composition of the plain pieces: per-image queries / residual through RoI maps (layer 0) and per-RoI plane
+    residual (layer 1); N not a multiple of the block's 512 positions; T on both kernel instantiations."""
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(100 + T)
+    R, B = 5, 2
+    roi_img = torch.tensor([0, 0, 1, 1, 1], dtype=torch.int32)
+    scale = 16 ** -0.5
+    k, v = torch.randn(R * T, 128, generator=g), torch.randn(R * T, 128, generator=g)
+    wo, bo = torch.randn(256, 128, generator=g) / 128 ** 0.5, torch.randn(256, generator=g)
+    gamma, beta = torch.randn(256, generator=g), torch.randn(256, generator=g)
+    if planes_res:
+        q = torch.randn(R * N, 128, generator=g) * 2
+        res = torch.randn(R * N, 256, generator=g) * 3
+        qq, rr = q.view(R, N, 128), res.view(R, N, 256)
+    else:
+        q = torch.randn(B * N, 128, generator=g) * 2
+        res = torch.randn(B * N, 256, generator=g) * 3
+        qq, rr = q.view(B, N, 128)[roi_img.long()], res.view(B, N, 256)[roi_img.long()]
+    qh = qq.double().view(R, N, 8, 16).permute(0, 2, 1, 3)
+    kh = k.double().view(R, T, 8, 16).permute(0, 2, 1, 3)
+    vh = v.double().view(R, T, 8, 16).permute(0, 2, 1, 3)
+    att = ((qh * scale) @ kh.transpose(-1, -2)).softmax(-1) @ vh
+    y = att.permute(0, 2, 1, 3).reshape(R, N, 128) @ wo.double().t() + bo.double() + rr.double()
+    ref = F.layer_norm(y, (256,), gamma.double(), beta.double(), 1e-6).reshape(R * N, 256)
+    kw = dict(R=R, T=T, N=N, scale=scale, eps=1e-6, planes=True, f32=True)
+    args = [t.to(dev) for t in (q, k, v, wo, bo, gamma, beta)]
+    if planes_res:
+        out, pl = ops.sam_i2t_fused(*args, res_planes=ops.to_planes(res.to(dev)), **kw)
+    else:
+        out, pl = ops.sam_i2t_fused(*args, q_map=roi_img.to(dev), res=res.to(dev), res_map=roi_img.to(dev), **kw)
+    e32 = float((out.cpu().double() - ref).abs().max())
+    epl = float((_planes_to_f32(pl) - ref).abs().max())
+    print(f'sam_i2t_fused T={T} N={N} planes_res={planes_res}: fp32 err {e32:.2e}, planes err {epl:.2e}')
+    assert e32 < 2e-5 and epl < 2e-5
+    with pytest.raises(RuntimeError):
+        ops.sam_i2t_fused(*[t.to(dev) for t in (q, torch.randn(R * 11, 128), torch.randn(R * 11, 128), wo, bo, gamma, beta)],
+                          R=R, T=11, N=N, scale=scale, res=torch.zeros(R * N, 256, device=dev))

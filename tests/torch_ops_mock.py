@@ -188,6 +188,25 @@ def sam_i2t_attention(q, k, v, *, R, T, N, scale, q_map=None, out=None, out_plan
     return dst
 
 
+SAM_I2T_FUSED_MAX_TOKENS = 10
+
+
+def sam_i2t_fused(q, k, v, wo, bo, gamma, beta, *, R, T, N, scale, eps=1e-6, q_map=None, res=None, res_map=None,
+                  res_planes=None, planes=True, f32=False):
+    """LayerNorm(residual + out_proj(image -> token attention)) composed from the plain pieces (HF:340-348)"""
+    att = torch.empty(R * N, 128)
+    sam_i2t_attention(q, k, v, R=R, T=T, N=N, scale=scale, q_map=q_map, out=att)
+    y = att @ wo.t() + bo
+    if res is not None:
+        rr = res.view(-1, N, 256)
+        rr = rr[res_map.long()] if res_map is not None else rr
+        y = y + rr.reshape(R * N, 256)
+    else:
+        y = y + res_planes.reshape(R * N, 256)
+    y = F.layer_norm(y, (256,), gamma, beta, eps)
+    return (y, y) if (planes and f32) else y
+
+
 def add_rows(x, v, vmod=None, out=None):
     C = x.shape[-1]
     rows = x.numel() // C
