@@ -317,6 +317,8 @@ extern "C" int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream) {
   if (d.Chi && (d.c_rows <= 0 || (d.N & 31))) return RSP_EINVAL;
   if ((d.hd_out || d.ln_gamma || d.res_hi || (d.ct_W > 0 && d.ct_dy < 0)) && !(d.Ahi && d.Alo)) return RSP_EINVAL;   // the fused hyper-network epilogue lives in the plane path
   if (d.M < 0 || d.N <= 0 || d.K <= 0 || (d.K % BK) != 0) return RSP_EINVAL;
+  // the fp8-corrected product lives in the plane path: with an fp32 A the cat8 plane of W would be read as a lo plane
+  if (RSP_PLANE_IS_F8(d.a_scale_log2) && !(d.Ahi && d.Alo)) return RSP_EINVAL;
   if (d.M == 0) return RSP_OK;
   if (d.conv_k != 0) {
     if (d.conv_C % BK != 0) return RSP_EINVAL;
