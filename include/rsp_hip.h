@@ -92,7 +92,9 @@ typedef struct RspGemmDesc {
   int32_t res_mod;         /* >0: residual row = crow % res_mod (broadcast)   */
   int32_t act;             /* RSP_ACT_*                                       */
   float alpha;             /* 2^-(a_scale_log2 + weight scale_log2)           */
-  int32_t a_scale_log2;    /* A is multiplied by 2^e before the fp16 split    */
+  int32_t a_scale_log2;    /* plane format word of A (and of W): exponent e of the   */
+                           /* fp16 split, RSP_PLANE_F8 selects the fp8-corrected     */
+                           /* product (A planes and W planes then both carry cat8)   */
   /* implicit-GEMM convolution over an NHWC input (conv_k == 0: plain GEMM)   */
   int32_t conv_k;          /* kernel size (3) ; K must equal conv_k^2 * conv_C */
   int32_t conv_stride, conv_pad;
@@ -114,7 +116,7 @@ typedef struct RspGemmDesc {
   /* result pre-split, scale 2^c_scale_log2, KB32 layout [N/32][c_rows][32], for the next GEMM.   */
   const uint16_t* Ahi; const uint16_t* Alo;
   uint16_t* Chi; uint16_t* Clo;
-  int32_t c_scale_log2;
+  int32_t c_scale_log2;    /* plane format word of Chi / Clo (RSP_PLANE_F8: Clo is written as the cat8 plane) */
   int32_t a_rows, c_rows;
   int32_t b_rows;   /* rows of the Bhi/Blo plane tensors when the weight is a row slice of them (0 = N) */
   /* hyper-network epilogue (HF:523-531 fused into the last ConvTranspose of the SAM upscaler): instead of  */
