@@ -63,6 +63,25 @@ def matmul_f8corr(a, bt):
     return ah @ bh + r8(al) @ r8(bh) + r8(ah) @ r8(bl)
 
 
+def matmul_s8corr(a, bt):
+    """the product as SHIPPED behind RSP_PLANE_F8 (include/rsp_hip.h): activations pre-scaled by 2^2, weights by the
+    power of two that puts |w|max in [2^13, 2^14); hi = fp16, lo8 = e4m3(lo * 2^5), hi8 = e4m3(hi * 2^-7)."""
+    import math
+
+    def parts(x, e):
+        xs = x.double() * 2.0 ** e
+        hi = xs.float().clamp(-65504, 65504).half().double()
+        lo = xs - hi
+        lo8 = (lo * 32).float().clamp(-448, 448).to(torch.float8_e4m3fn).double() / 32
+        hi8 = (hi / 128).float().clamp(-448, 448).to(torch.float8_e4m3fn).double() * 128
+        return hi, lo8, hi8
+    ea = 2
+    eb = int(math.floor(math.log2(16384.0 / float(bt.abs().max()))))
+    ah, al8, ah8 = parts(a, ea)
+    bh, bl8, bh8 = parts(bt, eb)
+    return ((ah @ bh + al8 @ bh8 + ah8 @ bl8) * 2.0 ** -(ea + eb)).to(a.dtype)
+
+
 def opnd(a, b, prec):
     if prec == 'x3':
         return a, b
@@ -102,6 +121,8 @@ def encoder_precision(policy):
     def lin(x, layer, prec):
         if prec == 'x3f8':
             return matmul_f8corr(x, layer.weight.t()) + layer.bias
+        if prec == 'x3s8':
+            return matmul_s8corr(x, layer.weight.t()) + layer.bias
         a, w = opnd(x, layer.weight, prec)
         return F.linear(a, w, layer.bias)
 
