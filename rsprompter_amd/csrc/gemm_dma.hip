@@ -405,6 +405,9 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
     static_for<0, G>([&](auto gc) {
       constexpr int g = decltype(gc)::value, i = g / TN, j = g % TN;
       mfma_one(f, s, i, j);
+      // F8: without this pin the optimizer sinks the (side-effect free) fp8 MFMAs below all the `if (do_issue)` branches:
+      // eight DMA instructions in one burst, then eight MFMAs -- the order this function exists to avoid
+      if constexpr (F8) asm volatile("" : "+v"(acc[i][j]));
       __builtin_amdgcn_sched_barrier(0);
       if (do_issue) static_for<g * LPT / G, (g + 1) * LPT / G>([&](auto sc) { issue_slot(sc, t, lbase); });
       __builtin_amdgcn_sched_barrier(0);
