@@ -741,6 +741,9 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
     }
   }
   if (f8) {   // fp8-corrected product: the three tiles the rule above picks
+    // with a third less matrix time per tile the big tile already pays from two rounds of blocks on, also at K = 1280
+    // (proj shape, tools/gemm_f8_exp.py: 337 vs 301 TFLOP/s)
+    if ((d.tile_hint & 0xff) == 0 && d.N > 128 && nblk(256, 256) >= 512) tile = 17;
     if (tile == 17 && d.N > 128) return launch_dma<256, 256, 2, 4, 2, 0, 0, 2, false, 0, true>(d, s);
     if ((tile == 18 || tile == 17) && d.N > 64) return launch_dma<256, 128, 4, 2, 2, 0, 0, 2, false, 0, true>(d, s);
     return launch_dma<128, 128, 2, 2, 2, 0, 0, 1, false, 0, true>(d, s);

@@ -240,7 +240,7 @@ class PlaneWeight:
         self.bias = None
 
 
-def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30):
+def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30, f8=False):
     """Mirror of the tile choice in rsp_gemm_dma_dispatch (gemm_dma.hip) - profiler labels only."""
     nblk = lambda bm, bn: -(-n // bn) * -(-m // bm)
     small = '128x128' if n > 64 else ('128x64' if n > 32 else '128x32')
@@ -253,6 +253,8 @@ def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30):
         return small
     if conv:
         return '256x256' if n > 128 and nblk(256, 256) >= 1024 else small
+    if f8 and n > 128 and nblk(256, 256) >= 512:
+        return '256x256'
     if k <= 256:
         return '256x256' if n > 128 and nblk(256, 256) >= 1024 else small
     if n <= 64:
@@ -351,7 +353,7 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.act = act
     d.a_scale_log2 = plane_word(a_scale_log2, w_f8)
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
-    tile = _dma_tile_name(m, n, tile_hint, conv is not None, w.K) if is_planes else ('128x128' if n > 64 else ('128x64' if n > 32 else '128x32'))
+    tile = _dma_tile_name(m, n, tile_hint, conv is not None, w.K, w_f8) if is_planes else ('128x128' if n > 64 else ('128x64' if n > 32 else '128x32'))
     kname = ('gemm_f16f8_dma_kernel' if w_f8 else 'gemm_f16x3_dma_kernel') if is_planes else 'gemm_f16x3_kernel'
     _timed(f'{kname}<{tile}>', 2.0 * m * n * w.K, 4.0 * (m * w.K + m * n) + 4.0 * n * w.K,
            lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm"),
