@@ -5,7 +5,7 @@
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py ...)
 
 A "step" is one pass of the whole hot path (DetDataPreprocessor -> SAM ViT encoder -> RSFPN -> RPN ->
-RoI prompter -> SAM mask decoder -> mask post-process -> result all-gather when N > 1) over one batch of
+RoI prompter -> SAM mask decoder -> mask post-process -> result gather to rank 0 when N > 1) over one batch of
 synthetic 1024x1024 tiles already resident in HBM.  The default workload is the configuration BASELINE.json's
 metric is quoted on ("images/sec (1024x1024, ViT-H)", configs[3]: rsprompter_anchor, SAM ViT-H, 64 tiles over 8
 GPUs): 8 x 1024 x 1024 per GPU per step, weak scaling (every rank runs its own batch of 8), so N=1 is the per-GPU
@@ -182,9 +182,11 @@ def main():
     imgs = [im.to(dev) for im in synth_images(B, seed=1234 + 1000 * rank)]
     metas = synth_metas(B)
 
-    # N > 1: the result exchange (records + COCO RLE of every instance, rsprompter_amd/dist.py::gather_results) of
-    # step i is queued on a side stream and finished on the host after step i + 1 has been launched, so the collective
-    # overlaps the next step's kernels; every exchange is collected inside the timed region (sync() drains the last).
+    # N > 1: the result exchange of step i (records + COCO RLE strings of every instance, produced by device kernels and
+    # gathered to rank 0 like mmengine collect_results: rsprompter_amd/dist.py::gather_results) is queued completely --
+    # kernels, collectives, pinned-host copy -- on a side stream when the step ends; the host only waits for that stream's
+    # event after step i + 1 has been launched and receives a lazy view (no per-instance Python work on any rank).
+    # Every exchange is collected inside the timed region (sync() drains the last).
     side = torch.cuda.Stream(device=dev) if world > 1 else None
     pending = [None]
 
@@ -195,7 +197,7 @@ def main():
         if world > 1:
             if pending[0] is not None:
                 pending[0].collect()
-            pending[0] = rdist.gather_results(res, dataset_size=world * B, stream=side)
+            pending[0] = rdist.gather_results(res, dataset_size=world * B, stream=side, dst=0)
         return res
 
     def sync():
@@ -223,7 +225,7 @@ def main():
 
     result = None
     # ---- roofline leg: one extra instrumented step, per-kernel HIP events on the launch stream.  Every rank runs
-    # the step (it contains the result all-gather); only rank 0 records and reports ----
+    # the step (it contains the result gather); only rank 0 records and reports ----
     prof = ops.Profiler() if rank == 0 else None
     if prof is not None:
         prof.shapes = args.shapes
@@ -263,7 +265,7 @@ def main():
             'config': {'workload': f'rsprompter_{args.model} SAM-ViT-{args.arch}, batch {B}x1024x1024 per GPU, '
                                    f'{num_classes} classes, seeded synthetic weights' + _config_tag(args, B, world),
                        'images_per_gpu_per_step': B, 'detections_per_step_rank0': n_dets,
-                       'parallelism': f'dp{world} (images sharded by batch, result all-gather)' if world > 1 else 'single GPU'},
+                       'parallelism': f'dp{world} (images sharded by batch, result gather to rank 0 over RCCL)' if world > 1 else 'single GPU'},
             'roofline': {'bound': 'mfma', 'kernel': dom_name, 'launches_per_step': dom['calls'],
                          'ms_per_step': round(dom['ms'], 3), 'achieved': round(achieved, 2),
                          'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4),

@@ -51,9 +51,14 @@ const char* rsp_build_info(void);
 /*                a_hi b_hi  (fp16 MFMA)  +  a_lo8 b_hi8 + a_hi8 b_lo8  (ONE K=64 fp8 MFMA per 32 k, MX block scales  */
 /*                2^-LO_EXP / 2^+HI_EXP undo the storage scales)                                                      */
 /*              -- 2 units of matrix time instead of 3, error class 2^-15 instead of 2^-22.     */
+/* Decoding is strict: a word is an F8 word only when its upper bits are exactly RSP_PLANE_F8; a plain (sign-extended)   */
+/* negative exponent -- legal under the pre-format-word contract of these fields -- has all upper bits set and is NOT  */
+/* mistaken for one; any other upper-bit pattern is invalid (entry points return RSP_EINVAL).                          */
 #define RSP_PLANE_F8 0x100
 #define RSP_PLANE_EXP(w) ((int)(int8_t)((w) & 0xff))
-#define RSP_PLANE_IS_F8(w) (((w) & RSP_PLANE_F8) != 0)
+#define RSP_PLANE_IS_F8(w) ((((int32_t)(w)) & ~0xff) == RSP_PLANE_F8)
+#define RSP_PLANE_WORD_VALID(w) \
+  (RSP_PLANE_IS_F8(w) || (((int32_t)(w)) & ~0xff) == 0 || (((int32_t)(w)) & ~0xff) == ~0xff)
 #define RSP_PLANE_WORD(e, f8) ((((int)(e)) & 0xff) | ((f8) ? RSP_PLANE_F8 : 0))
 #define RSP_F8_LO_EXP 5
 #define RSP_F8_HI_EXP 7
@@ -313,6 +318,13 @@ int rsp_batched_nms(const float* boxes, const float* scores, const int32_t* ids,
 /* or -(needed) when cap is too small; workspace: k*cap uint32.  W <= 8192.                                          */
 int rsp_mask_rle(const uint8_t* masks, int32_t k, int32_t H, int32_t W, void* workspace, uint32_t* counts,
                  int32_t* n_counts, int32_t cap, rsp_stream_t stream);
+/* ... and their compression to COCO's ASCII strings (cocoapi maskApi.c rleToString: what encode_mask_results returns   */
+/* as `counts`, structures/mask/utils.py:38-53; consumed by CocoMetric.process, coco_metric.py:346-391): for the k      */
+/* instances of `counts` [k, cap] / n_counts [k] (as written by rsp_mask_rle; n_counts <= 0 gives an empty string)      */
+/* lens[m] = bytes of string m, offs [k + 1] = exclusive scan of lens, flat[offs[m] .. offs[m + 1]) = string m.          */
+/* Strings that would end beyond flat_cap are not written: the caller compares offs[k] with flat_cap.                    */
+int rsp_rle_to_string(const uint32_t* counts, const int32_t* n_counts, int32_t k, int32_t cap, int32_t* lens,
+                      int64_t* offs, uint8_t* flat, int64_t flat_cap, rsp_stream_t stream);
 /* SAM upscaler tail, streaming form (HF:521-531): rows = R*H2*W2 input pixels as fp16 planes (KB32, K = 64),      */
 /* weight planes [2][128][32] with rows (dy, dx, c) of ConvTranspose2d(64 -> 32, k2, s2), bias tiled x4 [128],       */
 /* hyper [R, 32]; out [R, 2*H2, 2*W2] = sum_c GELU(convT)[.., c] * hyper[r, c].  rows_per_roi = H2*W2, ct_W = W2.    */

@@ -46,19 +46,41 @@ def _digest():
     return h.hexdigest()
 
 
-def build(force=False, verbose=True):
-    dig = _digest()
-    if not force and os.path.exists(LIB) and os.path.exists(STAMP):
+def _up_to_date(dig):
+    if os.path.exists(LIB) and os.path.exists(STAMP):
         with open(STAMP) as f:
-            if f.read().strip() == dig:
-                return LIB
+            return f.read().strip() == dig
+    return False
+
+
+def build(force=False, verbose=True):
+    """Compile + link under an exclusive file lock: N ranks of `bench.py --gpus N` / torchrun that all find a stale
+    library at import time must not run hipcc into the same object files or replace the .so while another rank is
+    dlopen()ing it.  The first rank builds (objects in a private directory, library and stamp moved into place with
+    os.replace, stamp last); the others block on the lock and then find the library up to date."""
+    import fcntl
+    dig = _digest()
+    if not force and _up_to_date(dig):
+        return LIB
     if not os.path.exists(HIPCC):
         raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build librsp_hip.so")
+    with open(os.path.join(HERE, ".librsp_hip.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and _up_to_date(dig):          # somebody else built it while we waited
+                return LIB
+            return _build_locked(dig, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(dig, verbose):
     objs = []
     procs = []
-    os.makedirs(os.path.join(HERE, "build"), exist_ok=True)
+    bdir = os.path.join(HERE, "build")
+    os.makedirs(bdir, exist_ok=True)
     for src in sources():
-        obj = os.path.join(HERE, "build", os.path.basename(src) + ".o")
+        obj = os.path.join(bdir, os.path.basename(src) + ".o")
         cmd = [HIPCC] + [f for f in FLAGS if f != "-shared"] + file_flags(src) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
@@ -67,12 +89,18 @@ def build(force=False, verbose=True):
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    tmp_lib = LIB + f".tmp{os.getpid()}"
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp_lib] + objs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    with open(STAMP, "w") as f:
+    if os.path.exists(STAMP):
+        os.remove(STAMP)                 # never a stamp that describes another library than the one on disk
+    os.replace(tmp_lib, LIB)
+    tmp_stamp = STAMP + f".tmp{os.getpid()}"
+    with open(tmp_stamp, "w") as f:
         f.write(dig)
+    os.replace(tmp_stamp, STAMP)
     return LIB
 
 

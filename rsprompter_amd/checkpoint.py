@@ -27,18 +27,37 @@ _WEIGHT_FILES = ('model.safetensors', 'pytorch_model.bin', 'model.safetensors.in
                  'pytorch_model.bin.index.json')
 
 
-def _read_file(path):
+def _trusted_default():
+    return os.environ.get('RSP_TRUSTED_CHECKPOINTS', '0') == '1'
+
+
+def _read_file(path, trusted=None):
+    """One weight file -> the object stored in it.  Pickle files are read with torch's restricted unpickler
+    (`weights_only=True`: tensors, containers, numbers, strings).  Checkpoints whose meta block pickles arbitrary classes
+    (some mmengine `.pth`: ConfigDict, numpy scalars, ...) are exactly what the restricted loader refuses; the full
+    unpickler -- which executes code chosen by whoever wrote the file -- is used only on an explicit opt-in
+    (`trusted=True` or RSP_TRUSTED_CHECKPOINTS=1).  I/O and corruption errors are never retried."""
+    import pickle
     if path.endswith('.safetensors'):
         from safetensors.torch import load_file
         return load_file(path, device='cpu')
     try:
         return torch.load(path, map_location='cpu', weights_only=True)
-    except Exception:                                  # mmengine checkpoints carry non-tensor meta objects
+    except pickle.UnpicklingError as e:
+        if trusted is None:
+            trusted = _trusted_default()
+        if not trusted:
+            raise RuntimeError(
+                f'{path}: the restricted (weights-only) loader refused this checkpoint ({str(e).splitlines()[0]}). '
+                'It pickles objects other than tensors / plain containers; loading it runs code from the file. If you '
+                'trust its origin pass trusted=True (read_state_dict / load_checkpoint) or set RSP_TRUSTED_CHECKPOINTS=1; '
+                'prefer re-saving it as safetensors.') from e
         return torch.load(path, map_location='cpu', weights_only=False)
 
 
-def read_state_dict(path):
-    """file / index json / directory -> flat {key: tensor} (wrappers and DeepSpeed's `module.` prefix removed)."""
+def read_state_dict(path, trusted=None):
+    """file / index json / directory -> flat {key: tensor} (wrappers and DeepSpeed's `module.` prefix removed).
+    `trusted`: see _read_file (None = the RSP_TRUSTED_CHECKPOINTS environment switch, default off)."""
     path = os.path.expanduser(str(path))
     if os.path.isdir(path):
         for name in _WEIGHT_FILES:
@@ -52,9 +71,9 @@ def read_state_dict(path):
             shards = sorted(set(json.load(f)['weight_map'].values()))
         sd = {}
         for s in shards:
-            sd.update(_read_file(os.path.join(os.path.dirname(path), s)))
+            sd.update(_read_file(os.path.join(os.path.dirname(path), s), trusted))
     else:
-        sd = _read_file(path)
+        sd = _read_file(path, trusted)
     for key in ('state_dict', 'model', 'module'):      # mmengine / lightning / DeepSpeed engine wrappers
         if isinstance(sd, dict) and key in sd and isinstance(sd[key], dict) and \
                 any(isinstance(v, torch.Tensor) for v in sd[key].values()):
@@ -92,7 +111,7 @@ def remap_to(own_keys, sd):
     return out, unused
 
 
-def load_checkpoint_into(module, path, revise_keys=(), strict=False, prefix=None):
+def load_checkpoint_into(module, path, revise_keys=(), strict=False, prefix=None, trusted=None):
     """mmengine.load_checkpoint stand-in: read any of the formats above, apply the regex key rewrites, keep what the
     module owns (after alias resolution) and load it.  Returns False (with a warning) when the file is missing, like
     the rest of the loaders: the synthetic-weight tests and benches run without the SAM files on disk."""
@@ -102,7 +121,7 @@ def load_checkpoint_into(module, path, revise_keys=(), strict=False, prefix=None
     if not os.path.exists(path):
         warnings.warn(f'checkpoint {path} not found; keeping current weights')
         return False
-    sd = read_state_dict(path)
+    sd = read_state_dict(path, trusted)
     out = {}
     for k, v in sd.items():
         for pat, rep in revise_keys:

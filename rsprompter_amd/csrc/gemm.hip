@@ -319,6 +319,12 @@ extern "C" int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream) {
   if (d.M < 0 || d.N <= 0 || d.K <= 0 || (d.K % BK) != 0) return RSP_EINVAL;
   // the fp8-corrected product lives in the plane path: with an fp32 A the cat8 plane of W would be read as a lo plane
   if (RSP_PLANE_IS_F8(d.a_scale_log2) && !(d.Ahi && d.Alo)) return RSP_EINVAL;
+  // ... and so do the column-range outputs and the cat8 output planes: the fp32-A kernel writes all N columns of C and
+  // plain (hi, lo) planes from column 0
+  if (!(d.Ahi && d.Alo) && (d.c_ncols != 0 || d.pl_col0 != 0 || (d.Chi && RSP_PLANE_IS_F8(d.c_scale_log2)))) return RSP_EINVAL;
+  if (!RSP_PLANE_WORD_VALID(d.a_scale_log2) || (d.Chi && !RSP_PLANE_WORD_VALID(d.c_scale_log2)) ||
+      (d.res_hi && !RSP_PLANE_WORD_VALID(d.res_scale_log2)))
+    return RSP_EINVAL;
   if (d.M == 0) return RSP_OK;
   if (d.conv_k != 0) {
     if (d.conv_C % BK != 0) return RSP_EINVAL;

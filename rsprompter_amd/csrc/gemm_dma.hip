@@ -28,25 +28,6 @@ constexpr int ROWB = BK * 2;  // bytes per LDS row
 
 __device__ uint4 g_zero_page[16];  // zeros: source of padded rows / out-of-image conv taps
 
-// unsigned division by a run-time constant prepared on the host (Granlund-Montgomery, branch-free form):
-// q = (t + ((x - t) >> sh1)) >> sh2 with t = mulhi(m, x); exact for all 32-bit x.
-struct FastDiv {
-  uint32_t m, sh1, sh2;
-  __device__ __forceinline__ int div(int x) const {
-    const uint32_t t = __umulhi(m, (uint32_t)x);
-    return (int)((t + (((uint32_t)x - t) >> sh1)) >> sh2);
-  }
-};
-static FastDiv make_fastdiv(int dv) {
-  FastDiv f{0u, 0u, 0u};
-  if (dv <= 1) return f;              // q = x
-  uint32_t d = (uint32_t)dv, l = 0;
-  while ((1ull << l) < d) ++l;        // ceil(log2 d)
-  f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
-  f.sh1 = 1; f.sh2 = l - 1;
-  return f;
-}
-
 struct GemmP {
   RspGemmDesc d;
   FastDiv fd_ctw, fd_resmod, fd_resb, fd_hd;   // ct_W, res_mod, res_brows, hd_rows
@@ -688,9 +669,17 @@ int launch_dma(const RspGemmDesc& d, hipStream_t s) {
 
 }  // namespace
 
+bool rsp_gemm_s2_eligible(const RspGemmDesc& d);                       // gemm_s2.hip
+int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s);
+
 // called from rsp_gemm (gemm.hip) when the descriptor carries A planes
 int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (d.a_rows <= 0) return RSP_EINVAL;
+  // tile hints 40 + v: the two-blocks-per-CU persistent kernel (gemm_s2.hip), experiment variant v
+  if ((d.tile_hint & 0xff) >= 40 && (d.tile_hint & 0xff) < 104) {
+    if (!rsp_gemm_s2_eligible(d)) return RSP_EINVAL;
+    return rsp_gemm_s2_dispatch(d, (d.tile_hint & 0xff) - 40, s);
+  }
   if (d.ct_W > 0 && (d.res || d.res_hi)) return RSP_EINVAL;   // no caller needs a residual on a ConvTranspose
   if (d.res_hi && (!d.res_lo || d.res || d.res_rows <= 0 || (d.N & 3))) return RSP_EINVAL;
   if (d.hd_out && (!d.hd_hyper || d.ct_W <= 0 || d.N != (d.ct_dy < 0 ? 128 : 64) || d.hd_rows <= 0)) return RSP_EINVAL;

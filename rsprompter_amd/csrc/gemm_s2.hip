@@ -1,0 +1,372 @@
+// fp16x3 GEMM, "two blocks per CU" persistent form (round 3).  Same arithmetic and the same plane operands as
+// gemm_dma.hip (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi per 16 k, fp32 accumulate in v_mfma_f32_32x32x16_f16; results are
+// bit-identical to that kernel), other structure:
+//
+//   * 256-thread blocks (4 waves, ONE per SIMD), block tile 256 x 128, wave tile 128 x 64 (8 accumulators = 128 VGPRs),
+//     72 KB of LDS -> TWO independent blocks per CU.  The 8-wave 256 x 256 kernel runs its two waves per SIMD in
+//     lockstep through one barrier per K tile, the fragment-read burst behind it, its prologue and its epilogue: whenever
+//     one wave of a SIMD stalls its partner stalls too (PMC r2: matrix pipe busy 58 %, and a K = 1280 tile spends ~18 % of
+//     its time outside the main loop).  Two independent blocks share nothing but the CU: one block's barrier waits, DMA
+//     issue, prologue latency and (VALU / store bound) epilogue run under the other block's matrix work.
+//   * persistent: min(#tiles, 512) blocks walk the tile list; the first three ring stages of the NEXT tile are in flight
+//     while the current tile's epilogue runs.
+//   * ring of 3 stages x 16 k (24 KB each: A_hi | A_lo | B_hi | B_lo, 32-byte rows), fed by the DMA engine through
+//     BUFFER loads (`buffer_load_dwordx4 ... offen lds`): the per-lane part of a source address is a 32-bit offset that is
+//     constant for the whole tile (row * 64 + chunk * 16), the K position is a scalar offset, rows that do not exist
+//     (tile overhang, padded window rows a_rowmap < 0) carry an offset beyond the descriptor's range and read as zeros.
+//     No per-DMA vector ALU work at all (gemm_dma.hip: 5 VALU + 3 SALU per DMA instruction for the 64-bit address
+//     select against a zero page).
+//   * accumulators are kept TRANSPOSED (mfma(W fragment, A fragment): lane = output row, 4 consecutive registers =
+//     4 consecutive output columns), so the epilogue needs no LDS staging and no block barrier: every lane owns rows,
+//     loads / stores 16 bytes (fp32) or 8 bytes per plane at a time, and each wave finishes on its own.
+//   * tile order: every XCD owns a contiguous range of the (grouped, M-fastest) tile list and its 64 resident blocks
+//     work on 64 consecutive entries = an 8 x 8 patch of tiles sharing 8 A panels and 8 W panels in that XCD's L2.
+//
+// Scope: plain GEMMs of the plane path (row gather / scatter, bias, activation, fp32 or plane residual, fp32 and / or
+// plane outputs incl. column ranges).  Convolutions, ConvTranspose / fused-LayerNorm / hyper-network epilogues and the
+// fp8-corrected product stay with gemm_dma.hip.
+#include <type_traits>
+#include "rsp_common.h"
+
+namespace {
+
+constexpr int KS = 16;                      // k per ring stage
+constexpr int BM = 256, BN = 128;           // block tile
+constexpr int NTHR = 256;
+constexpr int NS = 3;                       // ring depth
+constexpr int A_PL = BM * 32, B_PL = BN * 32;            // bytes of one plane of one stage
+constexpr int OFF_ALO = A_PL, OFF_BHI = 2 * A_PL, OFF_BLO = 2 * A_PL + B_PL;
+constexpr int STAGE = 2 * A_PL + 2 * B_PL;               // 24576
+constexpr int NDMA = STAGE / (NTHR * 16);                // 6 DMA instructions per wave and stage
+constexpr int TM = 4, TN = 2;
+constexpr unsigned OOB = 0x80000000u;                    // voffset of a row that does not exist: reads zeros
+
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct S2P {
+  RspGemmDesc d;
+  FastDiv fd_resmod, fd_resb;
+  int nbm, nbn, ntiles, per_xcd, group_m;
+  unsigned long long* trace;     // tools only (VAR bit 5): per block and tile {start, loop end, epilogue end, hw id}
+};
+unsigned long long* g_s2_trace = nullptr;
+
+template <int I, int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    sfor<I + 1, N>(f);
+  }
+}
+
+// VAR (experiment switches; 0 = product): bit 0 = static priority for the block in the odd workgroup slot of its CU
+// (HW_ID.TG_ID), bit 1 = fragment reads as one burst behind the barrier instead of between the MFMAs, bit 2 = no DMA
+// inside the K loop (ablation, garbage results), bit 3 = no epilogue (ablation), bit 4 = every DMA reads the first K block
+// (cache-hot sources: separates memory latency from issue / LDS-write cost; garbage results), bit 5 = time stamps
+template <int VAR>
+__global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+  const RspGemmDesc& d = p.d;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int M = d.M, N = d.N;
+  const int nk = d.K / KS;
+
+  const unsigned hw_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
+  if constexpr (VAR & 1) {
+    if ((hw_id >> 16) & 1) __builtin_amdgcn_s_setprio(1);
+  }
+  int trace_n = 0;
+
+  // ---- buffer descriptors of the four operand planes (host checked: every plane < 2^31 bytes) ----
+  const int a_kstr = d.a_rows * 64, b_kstr = (d.b_rows > 0 ? d.b_rows : N) * 64;   // bytes between K blocks of 32
+  const int a_bytes = (d.K / 32) * a_kstr, b_bytes = (d.K / 32) * b_kstr;
+  const __amdgpu_buffer_rsrc_t rAh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.Ahi), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rAl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.Alo), 0, a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rBh = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.Bhi), 0, b_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rBl = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(d.Blo), 0, b_bytes, 0x00020000);
+
+  // ---- DMA lane constants: unit u = slot * 256 + tid of a stage image; inside a plane v = row * 2 + physical chunk.
+  // A 32-byte-row image read with ds_read_b128 (16-lane groups {0-3, 12-15, 20-27}, ...) is conflict free when the
+  // 16-byte chunk is XOR-swizzled with bit 3 of the row; the swizzle goes on the SOURCE offset (DMA writes lane-linear).
+  const int d_row = tid >> 1;                                        // 0..127 (+128 for the second A slot)
+  const int d_chunk = ((tid & 1) ^ ((d_row >> 3) & 1)) << 4;         // logical chunk * 16 held at this physical place
+
+  // ---- fragment read offsets ----
+  const int f_chunk = (hh ^ ((l31 >> 3) & 1)) << 4;
+  const int a_lane = (wm * 128 + l31) * 32 + f_chunk;
+  const int b_lane = OFF_BHI + (wn * 64 + l31) * 32 + f_chunk;
+
+  struct Tile { int m0, n0; unsigned vA0, vA1, vB; };
+  auto tile_setup = [&](int id) {
+    Tile t;
+    int mb = id / p.nbn, nb = id - mb * p.nbn;
+    if (p.group_m > 1) {
+      const int per = p.group_m * p.nbn;
+      const int grp = id / per, rem = id - grp * per;
+      const int first = grp * p.group_m;
+      const int gsz = min(p.nbm - first, p.group_m);
+      nb = rem / gsz;
+      mb = first + (rem - nb * gsz);
+    }
+    t.m0 = mb * BM; t.n0 = nb * BN;
+    auto arow = [&](int r) -> unsigned {
+      const int gm = t.m0 + r;
+      if (gm >= M) return OOB;
+      const int srow = d.a_rowmap ? d.a_rowmap[gm] : gm;
+      return srow < 0 ? OOB : (unsigned)srow * 64u + (unsigned)d_chunk;
+    };
+    t.vA0 = arow(d_row);
+    t.vA1 = arow(d_row + 128);
+    const int gn = t.n0 + d_row;
+    t.vB = gn < N ? (unsigned)gn * 64u + (unsigned)d_chunk : OOB;
+    return t;
+  };
+  // ONE DMA instruction (1 KiB) of stage s into the ring buffer at byte offset sb
+  auto issue_slot = [&](auto ic, const Tile& t, int s, int sb) {
+    constexpr int I = decltype(ic)::value;
+    const int so = ((VAR & 16) ? 0 : (s >> 1) * (I < 4 ? a_kstr : b_kstr)) + (s & 1) * 32;
+    unsigned char* l = smem + sb + I * 4096 + wave * 1024;
+    if constexpr (I == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rAh, (lptr_t)l, 16, (int)t.vA0, so, 0, 0);
+    if constexpr (I == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rAh, (lptr_t)l, 16, (int)t.vA1, so, 0, 0);
+    if constexpr (I == 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rAl, (lptr_t)l, 16, (int)t.vA0, so, 0, 0);
+    if constexpr (I == 3) __builtin_amdgcn_raw_ptr_buffer_load_lds(rAl, (lptr_t)l, 16, (int)t.vA1, so, 0, 0);
+    if constexpr (I == 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rBh, (lptr_t)l, 16, (int)t.vB, so, 0, 0);
+    if constexpr (I == 5) __builtin_amdgcn_raw_ptr_buffer_load_lds(rBl, (lptr_t)l, 16, (int)t.vB, so, 0, 0);
+  };
+  auto issue_stage = [&](const Tile& t, int s, int sb) { sfor<0, NDMA>([&](auto ic) { issue_slot(ic, t, s, sb); }); };
+
+  struct Frags { half8_t ah[TM], al[TM], bh[TN], bl[TN]; };
+  // fragment read number q (0..11) of the stage at byte offset sb
+  auto read_frag = [&](auto qc, Frags& f, int sb) {
+    constexpr int q = decltype(qc)::value;
+    const unsigned char* a = smem + sb + a_lane;
+    const unsigned char* b = smem + sb + b_lane;
+    if constexpr (q < 4) f.ah[q] = *reinterpret_cast<const half8_t*>(a + q * 1024);
+    else if constexpr (q < 8) f.al[q - 4] = *reinterpret_cast<const half8_t*>(a + OFF_ALO + (q - 4) * 1024);
+    else if constexpr (q < 10) f.bh[q - 8] = *reinterpret_cast<const half8_t*>(b + (q - 8) * 1024);
+    else f.bl[q - 10] = *reinterpret_cast<const half8_t*>(b + B_PL + (q - 10) * 1024);
+  };
+
+  f32x16 acc[TM][TN];
+  // MFMA number q (0..23) of a stage, pass-major: dependent MFMAs are 8 issue slots apart
+  auto mfma_q = [&](auto qc, const Frags& f) {
+    constexpr int q = decltype(qc)::value, ps = q / 8, g = q % 8, i = g / TN, j = g % TN;
+    if constexpr (ps == 0) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.al[i], acc[i][j], 0, 0, 0);
+    else if constexpr (ps == 1) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bl[j], f.ah[i], acc[i][j], 0, 0, 0);
+    else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.bh[j], f.ah[i], acc[i][j], 0, 0, 0);
+  };
+
+  // s_waitcnt through the builtin (the compiler's own waitcnt insertion understands it):
+  // gfx9 encoding vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]
+  constexpr auto wc_vm_lgkm0 = [](int n) { return (n & 15) | ((n >> 4) << 14) | 0x70; };
+  constexpr int WC_LGKM0 = 0xC07F;
+
+  // one ring step: [my DMA of stage t+1 has landed, fc has landed | barrier] then the 24 MFMAs on fc with the 12
+  // fragment reads of stage t+1 (ring offset on) and the 6 DMA instructions of stage t+3 (-> ring offset oc, whose last
+  // reads every wave completed before the barrier) spread between them
+  auto step = [&](const Frags& fc, Frags& fn, const Tile& tl, int t, int oc, int on, auto rdc, auto dmac, auto vmc) {
+    constexpr bool RD = decltype(rdc)::value, DMA = decltype(dmac)::value && !(VAR & 4);
+    constexpr int VM = decltype(vmc)::value;
+    __builtin_amdgcn_s_waitcnt(wc_vm_lgkm0(VM));
+    __builtin_amdgcn_s_barrier();
+    if constexpr (RD && (VAR & 2)) {
+      sfor<0, 12>([&](auto qc) { read_frag(qc, fn, on); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    sfor<0, 24>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      mfma_q(qc, fc);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (RD && !(VAR & 2) && q < 12) {
+        read_frag(qc, fn, on);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (DMA && q >= 12 && (q & 1) == 0) {
+        issue_slot(std::integral_constant<int, (q - 12) / 2>{}, tl, t + 3, oc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    });
+  };
+  using T_ = std::true_type; using F_ = std::false_type;
+
+  // ---- persistent tile walk ----
+  const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nl = gridDim.x >> 3;
+  const int id_end = min((xcd + 1) * p.per_xcd, p.ntiles);
+  int id = xcd * p.per_xcd + bl;
+  if (id >= id_end) return;
+  Tile cur = tile_setup(id);
+  sfor<0, NS>([&](auto sc) { issue_stage(cur, decltype(sc)::value, decltype(sc)::value * STAGE); });
+
+  while (true) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    unsigned long long ts0 = 0, ts1 = 0;
+    if constexpr (VAR & 32) ts0 = __builtin_amdgcn_s_memtime();
+    Frags f0, f1;
+    // stage 0 of this tile has landed (mine: <= 12 younger DMA instructions outstanding; everybody's: barrier)
+    __builtin_amdgcn_s_waitcnt(wc_vm_lgkm0(2 * NDMA));
+    __builtin_amdgcn_s_barrier();
+    sfor<0, 12>([&](auto qc) { read_frag(qc, f0, 0); });
+
+    int oc = 0, on = STAGE;
+    auto adv = [&]() { oc = on; on += STAGE; if (on == NS * STAGE) on = 0; };
+    int t = 0;
+    for (; t + 4 < nk; t += 2) {
+      step(f0, f1, cur, t, oc, on, T_{}, T_{}, std::integral_constant<int, NDMA>{}); adv();
+      step(f1, f0, cur, t + 1, oc, on, T_{}, T_{}, std::integral_constant<int, NDMA>{}); adv();
+    }
+    // t = nk - 4: the last stage that still has a DMA to issue (nk - 1)
+    step(f0, f1, cur, t, oc, on, T_{}, T_{}, std::integral_constant<int, NDMA>{}); adv();
+    step(f1, f0, cur, t + 1, oc, on, T_{}, F_{}, std::integral_constant<int, NDMA>{}); adv();
+    step(f0, f1, cur, t + 2, oc, on, T_{}, F_{}, std::integral_constant<int, 0>{}); adv();
+    // last stage: its fragments are in f1; once every wave holds its own the ring is free for the next tile
+    __builtin_amdgcn_s_waitcnt(WC_LGKM0);
+    __builtin_amdgcn_s_barrier();
+    sfor<0, 24>([&](auto qc) { mfma_q(qc, f1); });
+    __builtin_amdgcn_sched_barrier(0);
+
+    if constexpr (VAR & 32) ts1 = __builtin_amdgcn_s_memtime();
+    const Tile done = cur;
+    id += nl;
+    const bool more = id < id_end;
+    if (more) {
+      cur = tile_setup(id);
+      sfor<0, NS>([&](auto sc) { issue_stage(cur, decltype(sc)::value, decltype(sc)::value * STAGE); });
+    }
+
+    // ---- epilogue of tile `done`, straight from the (transposed) accumulators: lane = row, register quad = 4 columns ----
+    if constexpr (!(VAR & 8)) {
+      const float alpha = d.alpha;
+      const float cs = d.Chi ? ldexpf(1.0f, RSP_PLANE_EXP(d.c_scale_log2)) : 1.0f;
+      const bool c_f8 = RSP_PLANE_IS_F8(d.c_scale_log2);
+      half_t* const chi = reinterpret_cast<half_t*>(d.Chi);
+      half_t* const clo = reinterpret_cast<half_t*>(d.Clo);
+      const float rsc = d.res_hi ? ldexpf(1.0f, -RSP_PLANE_EXP(d.res_scale_log2)) : 1.0f;
+      const int colw = done.n0 + wn * 64 + 4 * hh;           // + j * 32 + 8 * q
+      f32x4 bias4[TN][4];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int col = colw + j * 32 + 8 * q;
+          bias4[j][q] = (d.bias && col < N) ? *reinterpret_cast<const f32x4*>(d.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      sfor<0, TM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int row = done.m0 + wm * 128 + i * 32 + l31;
+        int cr = -1;
+        if (row < M) cr = d.c_rowmap ? d.c_rowmap[row] : row;
+        if (cr >= 0) {
+          int64_t rrow = cr;
+          if (d.res || d.res_hi) {
+            if (d.res_mod > 0) rrow = cr - p.fd_resmod.div(cr) * d.res_mod;
+            if (d.res_bmap) {
+              const int rb = p.fd_resb.div(cr);
+              rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (cr - rb * d.res_brows);
+            }
+          }
+          sfor<0, TN * 4>([&](auto jqc) {
+            constexpr int jq = decltype(jqc)::value, j = jq / 4, q = jq % 4;
+            const int col = colw + j * 32 + 8 * q;
+            if (col < N) {
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rsp_act(acc[i][j][4 * q + e] * alpha + bias4[j][q][e], d.act);
+              if (d.res_hi) {
+                const int64_t ro = ((int64_t)(col >> 5) * d.res_rows + rrow) * 32 + (col & 31);
+                const half4_t rh = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(d.res_hi) + ro);
+                const half4_t rl = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(d.res_lo) + ro);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += ((float)rh[e] + (float)rl[e]) * rsc;
+              }
+              if (d.res) {
+                const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + rrow * d.ldr + col);
+                v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+              }
+              if (d.C && (d.c_ncols <= 0 || col < d.c_ncols)) *reinterpret_cast<f32x4*>(d.C + (int64_t)cr * d.ldc + col) = v;
+              if (d.Chi && col >= d.pl_col0) {
+                const int pch = col - d.pl_col0;
+                const int64_t po = ((int64_t)(pch >> 5) * d.c_rows + cr) * 32 + (pch & 31);
+                rsp_store_planes4(chi, clo, po, f32x4{v[0] * cs, v[1] * cs, v[2] * cs, v[3] * cs}, c_f8);
+              }
+            }
+          });
+        }
+      });
+    } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    }
+    if constexpr (VAR & 32) {
+      if (p.trace && tid == 0 && trace_n < 16) {
+        unsigned long long* t = p.trace + ((size_t)blockIdx.x * 16 + trace_n) * 4;
+        t[0] = ts0; t[1] = ts1; t[2] = __builtin_amdgcn_s_memtime();
+        t[3] = ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32) | hw_id;
+      }
+      ++trace_n;
+    }
+    if (!more) break;
+  }
+}
+
+template <int VAR>
+int launch_s2(const RspGemmDesc& d, hipStream_t s) {
+  S2P p; p.d = d;
+  p.fd_resmod = make_fastdiv(d.res_mod); p.fd_resb = make_fastdiv(d.res_brows);
+  p.nbm = (d.M + BM - 1) / BM; p.nbn = (d.N + BN - 1) / BN;
+  const long long nt = (long long)p.nbm * p.nbn;
+  if (nt > 0x3fffffffLL) return RSP_EINVAL;
+  p.ntiles = (int)nt;
+  p.per_xcd = (p.ntiles + 7) / 8;
+  p.group_m = (d.tile_hint >> 8) & 0xff;
+  if (p.group_m == 0) p.group_m = 8;
+  p.trace = g_s2_trace;
+  int nblk = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;     // a multiple of 8: every XCD gets nblk / 8 walkers
+  hipLaunchKernelGGL((gemm_f16x3_s2_kernel<VAR>), dim3((unsigned)nblk), dim3(NTHR), 0, s, p);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+}  // namespace
+
+// the shapes / modes this kernel implements (everything else stays with gemm_dma.hip)
+bool rsp_gemm_s2_eligible(const RspGemmDesc& d) {
+  if (!(d.Ahi && d.Alo) || d.conv_k != 0 || d.ct_W > 0 || d.ln_gamma || d.hd_out) return false;
+  if (RSP_PLANE_IS_F8(d.a_scale_log2)) return false;
+  if ((d.N & 3) || (d.K & 31) || d.K < 64 || d.M <= 0 || d.a_rows <= 0) return false;
+  if (d.C && ((d.ldc & 3) || (reinterpret_cast<uintptr_t>(d.C) & 15))) return false;
+  if (d.res && ((d.ldr & 3) || (reinterpret_cast<uintptr_t>(d.res) & 15))) return false;
+  if (d.bias && (reinterpret_cast<uintptr_t>(d.bias) & 15)) return false;
+  if (d.res_hi && (!d.res_lo || d.res || d.res_rows <= 0)) return false;
+  if ((d.pl_col0 & 31) || (d.c_ncols & 3) || d.pl_col0 < 0) return false;
+  const long long brows = d.b_rows > 0 ? d.b_rows : d.N;
+  const long long kb = d.K / 32;
+  if (kb * d.a_rows * 64 >= (1LL << 31) || kb * brows * 64 >= (1LL << 31)) return false;   // 32-bit buffer offsets
+  return true;
+}
+
+int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s) {
+  switch (var) {
+    case 0: return launch_s2<0>(d, s);
+    case 1: return launch_s2<1>(d, s);
+    case 4: return launch_s2<4>(d, s);
+    case 8: return launch_s2<8>(d, s);
+    case 16: return launch_s2<16>(d, s);
+    case 32: return launch_s2<32>(d, s);
+    case 33: return launch_s2<33>(d, s);
+    default: return RSP_EINVAL;
+  }
+}
+
+// tools only (not part of include/rsp_hip.h): device buffer [512][16][4] u64 for the time-stamp variant
+extern "C" void rsp_debug_s2_trace(void* p) { g_s2_trace = reinterpret_cast<unsigned long long*>(p); }

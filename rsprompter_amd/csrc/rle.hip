@@ -3,7 +3,8 @@
 // Reference: encode_mask_results (mmdet/structures/mask/utils.py:38-53) = pycocotools.mask.encode on the
 // Fortran-ordered mask, i.e. cocoapi maskApi.c rleEncode: run lengths of the COLUMN-major pixel stream, first run
 // counts zeros.  The compression of the counts to the ASCII string (rleToString) is a few hundred integers per
-// instance and stays on the host (rsprompter_amd/rle.py).
+// instance; round 3 moved it onto the device as well (rsp_rle_to_string below), so that the multi-GPU result exchange
+// carries finished strings and no rank loops over instances in Python.
 #include "rsp_common.h"
 
 namespace {
@@ -80,7 +81,119 @@ __global__ __launch_bounds__(RLE_THREADS) void mask_rle_kernel(const uint8_t* __
   if (tid == 0) n_counts[m] = ntrans + 1;
 }
 
+// ---- counts -> COCO ASCII string (cocoapi maskApi.c rleToString; structures/mask/utils.py:38-53 hands these strings to
+// CocoMetric): count i is delta-coded against count i-2 from i = 3 on, then written 5 bits per character, least
+// significant group first, bit 5 = "more follows", + 48.  A 32-bit value needs at most 7 characters.
+__device__ __forceinline__ int rle_encode_one(const uint32_t* __restrict__ c, int i, unsigned char* ch) {
+  int x = (int)c[i];
+  if (i > 2) x -= (int)c[i - 2];
+  int n = 0;
+  bool more = true;
+  while (more) {
+    int v = x & 0x1f;
+    x >>= 5;                                          // arithmetic: deltas may be negative
+    more = (v & 0x10) ? (x != -1) : (x != 0);
+    if (more) v |= 0x20;
+    ch[n++] = (unsigned char)(v + 48);
+  }
+  return n;
+}
+
+constexpr int STR_THREADS = 256;
+
+// one block per instance: length of its string (n_counts[m] <= 0 -- capacity overflow of rsp_mask_rle -- gives 0)
+__global__ __launch_bounds__(STR_THREADS) void rle_strlen_kernel(const uint32_t* __restrict__ counts,
+                                                                 const int32_t* __restrict__ n_counts, int cap,
+                                                                 int32_t* __restrict__ lens) {
+  __shared__ int part[STR_THREADS / 64];
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int n = max(n_counts[m], 0);
+  const uint32_t* c = counts + (int64_t)m * cap;
+  int mine = 0;
+  unsigned char ch[8];
+  for (int i = tid; i < n; i += STR_THREADS) mine += rle_encode_one(c, i, ch);
+  mine = (int)rsp_wave_sum((float)mine);              // < 2^24 per wave: exact in fp32
+  if ((tid & 63) == 0) part[tid >> 6] = mine;
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int w = 0; w < STR_THREADS / 64; ++w) t += part[w];
+    lens[m] = t;
+  }
+}
+
+// exclusive scan of the k lengths -> offs[0..k] (one block; k is a few thousand at most)
+__global__ __launch_bounds__(1024) void rle_stroffs_kernel(const int32_t* __restrict__ lens, int k, int64_t* __restrict__ offs) {
+  __shared__ long long part[1024];
+  const int tid = threadIdx.x;
+  const int C = (k + 1023) / 1024;
+  long long mine = 0;
+  for (int i = 0; i < C; ++i) { const int j = tid * C + i; if (j < k) mine += lens[j]; }
+  part[tid] = mine;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const long long v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  long long run = part[tid] - mine;
+  for (int i = 0; i < C; ++i) { const int j = tid * C + i; if (j < k) { offs[j] = run; run += lens[j]; } }
+  if (tid == 1023) offs[k] = part[tid];
+}
+
+// one block per instance: the characters of chunk after chunk of 256 counts, positions from a block scan
+__global__ __launch_bounds__(STR_THREADS) void rle_strwrite_kernel(const uint32_t* __restrict__ counts,
+                                                                   const int32_t* __restrict__ n_counts, int cap,
+                                                                   const int64_t* __restrict__ offs,
+                                                                   uint8_t* __restrict__ flat, int64_t flat_cap) {
+  __shared__ int sc[STR_THREADS];
+  __shared__ int s_base;
+  const int m = blockIdx.x, tid = threadIdx.x;
+  const int n = max(n_counts[m], 0);
+  if (offs[m + 1] > flat_cap) return;                 // does not fit: the caller sees offs[k] > flat_cap and retries
+  const uint32_t* c = counts + (int64_t)m * cap;
+  uint8_t* out = flat + offs[m];
+  if (tid == 0) s_base = 0;
+  __syncthreads();
+  for (int i0 = 0; i0 < n; i0 += STR_THREADS) {
+    const int i = i0 + tid;
+    unsigned char ch[8];
+    const int len = i < n ? rle_encode_one(c, i, ch) : 0;
+    sc[tid] = len;
+    __syncthreads();
+    for (int o = 1; o < STR_THREADS; o <<= 1) {
+      const int v = tid >= o ? sc[tid - o] : 0;
+      __syncthreads();
+      sc[tid] += v;
+      __syncthreads();
+    }
+    const int pos = s_base + sc[tid] - len;
+    for (int j = 0; j < len; ++j) out[pos + j] = ch[j];
+    __syncthreads();
+    if (tid == STR_THREADS - 1) s_base += sc[tid];
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+extern "C" int rsp_rle_to_string(const uint32_t* counts, const int32_t* n_counts, int32_t k, int32_t cap, int32_t* lens,
+                                 int64_t* offs, uint8_t* flat, int64_t flat_cap, rsp_stream_t stream) {
+  if (!counts || !n_counts || !lens || !offs || !flat || k < 0 || cap < 2 || flat_cap < 0) return RSP_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (k > 0) {
+    hipLaunchKernelGGL(rle_strlen_kernel, dim3(k), dim3(STR_THREADS), 0, s, counts, n_counts, cap, lens);
+    RSP_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(rle_stroffs_kernel, dim3(1), dim3(1024), 0, s, lens, k, offs);
+  RSP_CHECK_LAUNCH();
+  if (k > 0) {
+    hipLaunchKernelGGL(rle_strwrite_kernel, dim3(k), dim3(STR_THREADS), 0, s, counts, n_counts, cap, offs, flat, flat_cap);
+    RSP_CHECK_LAUNCH();
+  }
+  return RSP_OK;
+}
 
 extern "C" int rsp_mask_rle(const uint8_t* masks, int32_t k, int32_t H, int32_t W, void* workspace, uint32_t* counts,
                             int32_t* n_counts, int32_t cap, rsp_stream_t stream) {

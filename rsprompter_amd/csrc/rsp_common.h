@@ -100,3 +100,22 @@ __device__ __forceinline__ float rsp_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// unsigned division by a run-time constant prepared on the host (Granlund-Montgomery, branch-free form):
+// q = (t + ((x - t) >> sh1)) >> sh2 with t = mulhi(m, x); exact for all 32-bit x.
+struct FastDiv {
+  uint32_t m, sh1, sh2;
+  __device__ __forceinline__ int div(int x) const {
+    const uint32_t t = __umulhi(m, (uint32_t)x);
+    return (int)((t + (((uint32_t)x - t) >> sh1)) >> sh2);
+  }
+};
+static inline FastDiv make_fastdiv(int dv) {
+  FastDiv f{0u, 0u, 0u};
+  if (dv <= 1) return f;              // q = x
+  uint32_t d = (uint32_t)dv, l = 0;
+  while ((1ull << l) < d) ++l;        // ceil(log2 d)
+  f.m = (uint32_t)((((1ull << l) - d) << 32) / d + 1);
+  f.sh1 = 1; f.sh2 = l - 1;
+  return f;
+}

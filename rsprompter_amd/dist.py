@@ -5,11 +5,12 @@ Reference equivalent: tools/dist_test.sh (1 proc / GPU) + DefaultSampler round-r
 (configs/rsprompter/_base_/rsprompter_anchor.py:269) + CocoMetric.process (per-rank RLE,
 mmdet/evaluation/metrics/coco_metric.py:346-391) + mmengine `collect_results`.
 Two exchanges are provided:
-  * `gather_results` (the default hand-off): what the reference's ranks exchange -- per-image records plus COCO RLE
-    run lengths (`rsp_mask_rle`, KBs per instance instead of 128 KiB of packed bits), images of DIFFERENT sizes in one
-    batch (rescale=True puts masks at each image's own `ori_shape`), issued on a side stream so that the next step's
-    kernels overlap it, and returned in DATASET order with the sampler's wrap-around padding dropped -- exactly what
-    mmengine `collect_results` does with the per-rank lists.
+  * `gather_results` (the default hand-off): what the reference's ranks exchange -- per-image records plus the COCO RLE
+    strings of the masks, both produced on the device (`rsp_mask_rle`, `rsp_rle_to_string`: a few hundred bytes per
+    instance instead of 128 KiB of packed bits), images of DIFFERENT sizes in one batch (rescale=True puts masks at each
+    image's own `ori_shape`), queued completely on a side stream so that the next step's kernels overlap it, gathered to
+    rank 0 like mmengine `collect_results`, and handed back as a lazy list in DATASET order with the sampler's
+    wrap-around padding dropped.
   * `all_gather_results`: dense bit-packed masks for consumers that want pixels on every rank (all images one size).
 """
 import os
@@ -97,17 +98,63 @@ def all_gather_results(results_list, pack_fn=None, group=None):
 
 
 # ----------------------------------------------------------------------------- RLE exchange (default hand-off)
-def _rle_device(masks):
-    from . import ops
-    return ops.mask_rle_counts(masks)
+# Reference: every rank RLE-encodes its own predictions (CocoMetric.process, coco_metric.py:346-391, through
+# encode_mask_results, structures/mask/utils.py:38-53) and mmengine `collect_results` brings the per-rank lists to RANK 0
+# only (tools/dist_test.sh:11-22 launches one process per GPU).  Here:
+#   * run-length counting AND the COCO string compression run on the device (rsp_mask_rle, rsp_rle_to_string): what
+#     travels is finished strings, a few hundred bytes per instance;
+#   * everything a step contributes is queued at `gather_results` time on the caller's side stream -- kernels, a 32-byte
+#     header all-gather, four fixed-capacity gathers to the destination rank, the copy into pinned host memory -- with
+#     no host synchronisation, so it runs behind the next step's kernels;
+#   * `collect()` waits for that stream's event and hands back a LAZY sequence: the per-image dicts (and the Python bytes
+#     of an instance's string) are built when the consumer indexes them, never in a per-step loop;
+#   * capacities (images, instances, string bytes per rank and step, runs per mask) are agreed from the all-gathered
+#     headers: a step that does not fit is re-sent with doubled capacities by every rank (they all see the same headers).
+class ExchangeState:
+    """Capacities of the fixed-shape exchange + the pinned host buffers of the destination rank (one per process group)."""
+
+    def __init__(self):
+        self.img_cap = self.inst_cap = self.byte_cap = 0
+        self.run_cap = 4096
+        self.host = {}
+
+    def fits(self, need):
+        return need[0] <= self.img_cap and need[1] <= self.inst_cap and need[2] <= self.byte_cap and need[3] <= 0
+
+    def grow(self, need):
+        p2 = lambda v, lo: max(lo, 1 << (max(int(v), 1) * 5 // 4).bit_length())
+        self.img_cap = max(self.img_cap, p2(need[0], 1))
+        self.inst_cap = max(self.inst_cap, p2(need[1], 16))
+        self.byte_cap = max(self.byte_cap, p2(need[2], 1 << 16))
+        if need[3] > 0:
+            self.run_cap = max(self.run_cap, 1 << (int(need[3]) - 1).bit_length())
 
 
-def _pad_to(t, n):
-    if t.shape[0] == n:
-        return t
-    out = torch.zeros((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    out[:t.shape[0]] = t
-    return out
+_STATES = {}
+
+
+def _state_of(group):
+    return _STATES.setdefault(id(group) if group is not None else 0, ExchangeState())
+
+
+class DeviceCodec:
+    """results -> (records, COCO RLE strings) with the two HIP kernels; nothing in here touches the host."""
+
+    def encode(self, results_list, run_cap, byte_cap, dev):
+        from . import ops
+        ks = [int(r.bboxes.shape[0]) for r in results_list]
+        K = sum(ks)
+        counts = torch.empty((max(K, 1), run_cap), dtype=torch.int32, device=dev)
+        ws = torch.empty((max(K, 1), run_cap), dtype=torch.int32, device=dev)
+        n = torch.ones((max(K, 1),), dtype=torch.int32, device=dev)
+        i0 = 0
+        for r, k in zip(results_list, ks):
+            if k:
+                ops.mask_rle_into(r.masks, counts[i0:i0 + k], ws[i0:i0 + k], n[i0:i0 + k])
+            i0 += k
+        lens, offs, flat = ops.rle_to_string(counts, n, K, byte_cap)
+        runs_needed = (-n[:K]).clamp_min(0).max() if K else torch.zeros((), dtype=torch.int32, device=dev)
+        return lens[:K], flat, offs[K], runs_needed
 
 
 class PendingGather:
@@ -122,93 +169,149 @@ class PendingGather:
         return self._out
 
 
-def gather_results(results_list, dataset_size=None, rle_fn=None, group=None, stream=None, compress=True):
-    """Gather every rank's per-image results (records + COCO RLE) on every rank.
+class GatheredResults:
+    """What the destination rank holds after an exchange: the gathered flat buffers (host) + index tables.  Behaves like
+    the list `collect_results` returns -- dataset order, the sampler's wrap-around duplicates dropped -- but builds
+    item j (dict(bboxes, scores, labels, masks=[dict(size=[h, w], counts=bytes)])) only when it is asked for."""
+
+    def __init__(self, headers, meta, rec, lens, flat, dataset_size=None):
+        import numpy as np
+        self._meta, self._rec, self._lens, self._flat = meta, rec, lens, flat
+        world = headers.shape[0]
+        n_img = [int(headers[w, 0]) for w in range(world)]
+        self._inst0 = [np.concatenate([[0], np.cumsum(meta[w, :n_img[w], 0].astype(np.int64))]) for w in range(world)]
+        self._byte0 = [np.concatenate([[0], np.cumsum(lens[w, :int(headers[w, 1])].astype(np.int64))]) for w in range(world)]
+        # mmengine collect_results: interleave the per-rank lists (zip), then cut to the dataset size
+        order = [(w, i) for i in range(max(n_img + [0])) for w in range(world) if i < n_img[w]]
+        self._order = order if dataset_size is None else order[:dataset_size]
+        self.n_instances = int(sum(self._inst0[w][i + 1] - self._inst0[w][i] for w, i in self._order))
+        self.n_bytes = int(sum(int(headers[w, 2]) for w in range(world)))
+
+    def __len__(self):
+        return len(self._order)
+
+    def __getitem__(self, j):
+        if isinstance(j, slice):
+            return [self[i] for i in range(*j.indices(len(self)))]
+        w, i = self._order[j]
+        k, h, wd = (int(v) for v in self._meta[w, i])
+        i0 = int(self._inst0[w][i])
+        rr = torch.from_numpy(self._rec[w, i0:i0 + k].copy())
+        b = self._byte0[w]
+        buf = self._flat[w]
+        masks = [dict(size=[h, wd], counts=buf[int(b[i0 + t]):int(b[i0 + t + 1])].tobytes()) for t in range(k)]
+        return dict(bboxes=rr[:, :4].clone(), scores=rr[:, 4].clone(), labels=rr[:, 5].long(), masks=masks)
+
+    def __iter__(self):
+        return (self[j] for j in range(len(self)))
+
+
+def _pad_rows(t, n):
+    if t.shape[0] == n:
+        return t.contiguous()
+    out = torch.zeros((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    m = min(n, t.shape[0])
+    out[:m] = t[:m]
+    return out
+
+
+def gather_results(results_list, dataset_size=None, group=None, stream=None, dst=0, codec=None, state=None):
+    """Bring every rank's per-image results (records + COCO RLE strings) to rank `dst` (None: to every rank).
 
     results_list: this rank's InstanceData list (bboxes, scores, labels, masks bool [k, H_i, W_i]); mask sizes may
-    differ from image to image.  Images are assumed sharded round-robin (`shard_indices`): the i-th image of rank r
-    is dataset item i * world + r.  Returns a list of per-image dicts in dataset order, truncated to `dataset_size`
-    (the sampler's wrap-around duplicates are dropped): dict(bboxes f32 [k,4], scores f32 [k], labels i64 [k],
-    masks=[dict(size=[h, w], counts=bytes)]) -- the `pred` CocoMetric.process builds (coco_metric.py:346-391).
-    stream: a side torch.cuda.Stream; the RLE kernel, the packing and the collectives are queued there (after the
-    work already on the current stream), so the caller can launch the next step before `collect()`-ing:
+    differ from image to image.  Images are assumed sharded round-robin (`shard_indices`): the i-th image of rank r is
+    dataset item i * world + r.  Returns (from `collect()` when a side `stream` is given, directly otherwise) a
+    `GatheredResults` on the destination rank(s) and None elsewhere, as mmengine `collect_results` does.
         h = gather_results(out, stream=side, ...)   ->  PendingGather;  ...next test_step...;  res = h.collect()
-    """
-    rle_fn = rle_fn or _rle_device
+    codec: the (records, strings) encoder; the default runs the HIP kernels (tests on CPU inject a numpy one)."""
+    import numpy as np
+    codec = codec or DeviceCodec()
+    state = state or _state_of(group)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_img = len(results_list)
     dev = results_list[0].bboxes.device if n_img else torch.device('cpu')
-    use_stream = stream is not None and dev.type == 'cuda'
-    if use_stream:
-        stream.wait_stream(torch.cuda.current_stream(dev))
-    ctx = torch.cuda.stream(stream) if use_stream else _null()
-    with ctx:
-        ks = [int(r.bboxes.shape[0]) for r in results_list]
-        meta = torch.tensor([[k, r.masks.shape[-2], r.masks.shape[-1]] for k, r in zip(ks, results_list)],
-                            dtype=torch.int32).reshape(n_img, 3)
-        rec_parts, cnt_parts, len_parts = [], [], []
-        for r, k in zip(results_list, ks):
-            if k == 0:
-                continue
-            rec_parts.append(torch.cat([r.bboxes.float(), r.scores.float()[:, None], r.labels.float()[:, None]], 1))
-            counts, n = rle_fn(r.masks)                       # [k, cap] int32, [k] int32 (device)
-            cnt_parts.append((counts, n))
-            len_parts.append(n)
-        rec = torch.cat(rec_parts, 0) if rec_parts else torch.zeros((0, 6), dtype=torch.float32, device=dev)
-        run_len = torch.cat(len_parts, 0).to(torch.int32) if len_parts else torch.zeros((0,), dtype=torch.int32, device=dev)
+    on_gpu = dev.type == 'cuda'
+    use_stream = stream is not None and on_gpu
+    to_me = dst is None or rank == dst
+    ks = [int(r.bboxes.shape[0]) for r in results_list]
+    K = sum(ks)
+    if state.img_cap == 0:
+        # first exchange of this process group: one synchronous MAX over the ranks so that everybody starts from the
+        # SAME capacities (afterwards they only change through the all-gathered headers)
+        need0 = torch.tensor([n_img, K, 512 * K, 0], dtype=torch.int64, device=dev)
+        if world > 1:
+            dist.all_reduce(need0, op=dist.ReduceOp.MAX, group=group)
+        state.grow(need0.tolist())
+    meta_h = torch.tensor([[k, r.masks.shape[-2], r.masks.shape[-1]] for k, r in zip(ks, results_list)],
+                          dtype=torch.int32).reshape(n_img, 3)
+
+    def queue():
+        """all device work + collectives of one attempt; returns the tensors collect() reads and an event"""
+        if use_stream:
+            stream.wait_stream(torch.cuda.current_stream(dev))
+            for r in results_list:                          # produced on the compute stream, read on `stream`
+                for t in (r.bboxes, r.scores, r.labels, r.masks):
+                    t.record_stream(stream)
+        with (torch.cuda.stream(stream) if use_stream else _null()):
+            lens, flat, total, runs_needed = codec.encode(results_list, state.run_cap, state.byte_cap, dev)
+            rec_parts = [torch.cat([r.bboxes.float(), r.scores.float()[:, None], r.labels.float()[:, None]], 1)
+                         for r, k in zip(results_list, ks) if k]
+            rec = torch.cat(rec_parts, 0) if rec_parts else torch.zeros((0, 6), dtype=torch.float32, device=dev)
+            header = torch.stack([torch.tensor(n_img, dtype=torch.int64, device=dev), torch.tensor(K, dtype=torch.int64, device=dev),
+                                  total.to(torch.int64).reshape(()), runs_needed.to(torch.int64).reshape(())])
+            payload = [_pad_rows(meta_h.to(dev, non_blocking=True), state.img_cap), _pad_rows(rec, state.inst_cap),
+                       _pad_rows(lens.to(torch.int32), state.inst_cap), _pad_rows(flat, state.byte_cap)]
+            if world > 1:
+                headers = torch.empty((world, 4), dtype=torch.int64, device=dev)
+                dist.all_gather_into_tensor(headers.view(-1), header, group=group)
+                got = []
+                for t in payload:
+                    if dst is None:
+                        g = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=dev)
+                        dist.all_gather_into_tensor(g.view(-1), t.view(-1), group=group)
+                        got.append(g)
+                    else:
+                        parts = [torch.empty_like(t) for _ in range(world)] if to_me else None
+                        dist.gather(t, parts, dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group)
+                        got.append(torch.stack(parts, 0) if to_me else None)
+            else:
+                headers, got = header[None], [t[None] for t in payload]
+            ev = None
+            if on_gpu:                                      # device -> pinned host, still on the side stream
+                def pinned(name, t):
+                    h = state.host.get(name)
+                    if h is None or h.shape != t.shape or h.dtype != t.dtype:
+                        h = state.host[name] = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+                    h.copy_(t, non_blocking=True)
+                    return h
+                headers = pinned('headers', headers)
+                if to_me:
+                    got = [pinned(f'p{i}', t) for i, t in enumerate(got)]
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+        return headers, got, ev
+
+    inflight = queue()
 
     def finish():
-        if use_stream:
-            stream.synchronize()                              # only the side stream: the compute stream keeps running
-        ctx2 = torch.cuda.stream(stream) if use_stream else _null()
-        with ctx2:
-            # ragged run-length lists -> one flat int32 buffer (instance-major): one masked select per image
-            flat = [c[torch.arange(c.shape[1], device=c.device)[None, :] < nn_[:, None].to(torch.int64)]
-                    for c, nn_ in cnt_parts]
-            runs = torch.cat(flat, 0).to(torch.int32) if flat else torch.zeros((0,), dtype=torch.int32, device=dev)
-            sizes = torch.tensor([n_img, rec.shape[0], runs.shape[0]], dtype=torch.int64, device=dev)
-            if world > 1:
-                all_sizes = torch.empty((world, 3), dtype=torch.int64, device=dev)
-                dist.all_gather_into_tensor(all_sizes.view(-1), sizes, group=group)
-                all_sizes = all_sizes.cpu()
-                mx = all_sizes.max(0).values.tolist()
-                bufs = []
-                for t, n in ((meta.to(dev), mx[0]), (rec, mx[1]), (run_len, mx[1]), (runs, mx[2])):
-                    t = _pad_to(t.contiguous(), max(int(n), 1))
-                    g = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=dev)
-                    dist.all_gather_into_tensor(g.view(-1), t.view(-1), group=group)
-                    bufs.append(g.cpu())
-                g_meta, g_rec, g_len, g_runs = bufs
-            else:
-                all_sizes = sizes.cpu()[None]
-                g_meta, g_rec, g_len, g_runs = meta[None], rec.cpu()[None], run_len.cpu()[None], runs.cpu()[None]
-        from .rle import _counts_to_string
-        per_rank = []
-        for w in range(world):
-            ni, _, _ = [int(v) for v in all_sizes[w]]
-            imgs, i0, r0 = [], 0, 0
-            for i in range(ni):
-                k, h, wd = [int(v) for v in g_meta[w, i]]
-                ls = g_len[w, i0:i0 + k].tolist()
-                rles = []
-                for ln in ls:
-                    cnts = g_runs[w, r0:r0 + ln].tolist()
-                    rles.append(dict(size=[h, wd], counts=_counts_to_string(cnts) if compress else cnts))
-                    r0 += ln
-                rr = g_rec[w, i0:i0 + k]
-                imgs.append(dict(bboxes=rr[:, :4].clone(), scores=rr[:, 4].clone(), labels=rr[:, 5].long(), masks=rles))
-                i0 += k
-            per_rank.append(imgs)
-        # mmengine collect_results: interleave the per-rank lists (zip), then cut to the dataset size
-        ordered = []
-        for i in range(max(len(p) for p in per_rank)):
-            for w in range(world):
-                if i < len(per_rank[w]):
-                    ordered.append(per_rank[w][i])
-        if dataset_size is not None:
-            ordered = ordered[:dataset_size]
-        return ordered
+        nonlocal inflight
+        while True:
+            headers, got, ev = inflight
+            if ev is not None:
+                ev.synchronize()                            # the side stream's work only: the compute stream keeps running
+            hd = headers.numpy().copy()
+            need = [int(v) for v in hd.max(0)]
+            if state.fits(need):
+                break
+            state.grow(need)                                # every rank sees the same headers -> the same decision
+            inflight = queue()
+        if not to_me:
+            return None
+        meta, rec, lens, flat = (t.numpy() for t in got)
+        if on_gpu:                                          # the pinned buffers are reused by the next exchange
+            meta, rec, lens, flat = meta.copy(), rec.copy(), lens.copy(), flat.copy()
+        return GatheredResults(hd, meta, rec, lens, flat, dataset_size)
 
     return PendingGather(finish) if use_stream else finish()
 

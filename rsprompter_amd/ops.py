@@ -940,6 +940,31 @@ def mask_rle_counts(masks, cap=4096):
         return counts, n
 
 
+def mask_rle_into(masks, counts, ws, n):
+    """rsp_mask_rle into rows of preallocated buffers (counts / ws int32 [k, cap], n int32 [k]); nothing here touches
+    the host: n[i] < 0 reports a mask with more than cap runs (-needed), checked by whoever reads n later."""
+    lib = _lib.load()
+    k, H, W = masks.shape
+    if k:
+        m = masks.contiguous()
+        _lib.check(lib.rsp_mask_rle(m.data_ptr(), k, H, W, ws.data_ptr(), counts.data_ptr(), n.data_ptr(),
+                                    counts.shape[1], _stream()), "rsp_mask_rle")
+
+
+def rle_to_string(counts, n, k, flat_cap):
+    """COCO ASCII strings of k run-length lists (rsp_rle_to_string): returns (lens int32 [k], offs int64 [k + 1],
+    flat uint8 [flat_cap]) on the device, no host synchronisation; strings beyond flat_cap are not written
+    (offs[k] > flat_cap tells)."""
+    lib = _lib.load()
+    dev = counts.device
+    lens = torch.zeros((max(k, 1),), dtype=torch.int32, device=dev)
+    offs = torch.zeros((k + 1,), dtype=torch.int64, device=dev)
+    flat = torch.empty((max(int(flat_cap), 1),), dtype=torch.uint8, device=dev)
+    _lib.check(lib.rsp_rle_to_string(counts.data_ptr(), n.data_ptr(), k, counts.shape[1], lens.data_ptr(),
+                                     offs.data_ptr(), flat.data_ptr(), int(flat_cap), _stream()), "rsp_rle_to_string")
+    return lens, offs, flat
+
+
 # ----------------------------------------------------------------------------- query prompter ops
 def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, add=None):
     """GroupNorm on channels-last [B, ..., C]; `add` (same shape) is added after the norm."""

@@ -107,6 +107,35 @@ def _np_rle(masks):
     return counts, torch.tensor([len(r) for r in rows], dtype=torch.int32)
 
 
+class NumpyCodec:
+    """CPU stand-in of dist.DeviceCodec (rsp_mask_rle + rsp_rle_to_string) for the gloo tests: same contract, incl. the
+    capacity reports (runs_needed > 0 / total > byte_cap mean "did not fit")."""
+
+    def encode(self, results_list, run_cap, byte_cap, dev):
+        from rsprompter_amd.rle import counts_to_string
+        strs, runs_needed = [], 0
+        for r in results_list:
+            if r.bboxes.shape[0] == 0:
+                continue
+            counts, n = _np_rle(r.masks)
+            for i in range(counts.shape[0]):
+                ln = int(n[i])
+                if ln > run_cap:
+                    runs_needed = max(runs_needed, ln)
+                    strs.append(b'')
+                else:
+                    strs.append(counts_to_string(counts[i, :ln].tolist()))
+        lens = torch.tensor([len(x) for x in strs], dtype=torch.int32)
+        total = int(lens.sum())
+        flat = torch.zeros((max(byte_cap, 1),), dtype=torch.uint8)
+        o = 0
+        for x in strs:
+            if o + len(x) <= byte_cap:
+                flat[o:o + len(x)] = torch.frombuffer(bytearray(x), dtype=torch.uint8) if x else flat[o:o]
+            o += len(x)
+        return lens, flat, torch.tensor(total, dtype=torch.int64), torch.tensor(runs_needed, dtype=torch.int64)
+
+
 def _hetero_results(item):
     """dataset item -> results with its OWN mask size (NWPU-style: every image has its own ori_shape)."""
     from rsprompter_amd.structures import InstanceData
@@ -117,37 +146,90 @@ def _hetero_results(item):
                         labels=torch.randint(0, 10, (k,), generator=g), masks=torch.rand(k, *hw, generator=g) > 0.5)
 
 
-def _worker_rle(rank, world, port, n_items, ret):
+def _worker_rle(rank, world, port, n_items, dst, ret):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
     import torch.distributed as dist
     from rsprompter_amd import dist as rdist
     rdist.init_from_env(backend='gloo')
-    mine = [_hetero_results(i) for i in rdist.shard_indices(n_items, rank, world)]
-    ret[rank] = rdist.gather_results(mine, dataset_size=n_items, rle_fn=_np_rle)
+    state = rdist.ExchangeState()
+    state.run_cap = 64                      # small on purpose: item 2 (30x7 noise) and the byte capacity have to grow
+    out = []
+    for rep in range(2):                    # second exchange: capacities already agreed, no growth
+        mine = [_hetero_results(i) for i in rdist.shard_indices(n_items, rank, world)]
+        got = rdist.gather_results(mine, dataset_size=n_items, codec=NumpyCodec(), dst=dst, state=state)
+        out.append(None if got is None else list(got))
+    ret[rank] = (out, (state.img_cap, state.inst_cap, state.byte_cap, state.run_cap))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_results_rle_heterogeneous_sizes_world2():
-    """world 2, 5 items (5 % 2 != 0: rank 1 gets a wrap-around duplicate), every item with its own mask size:
-    results come back in DATASET order, truncated to the dataset size, masks as COCO RLE that decode to the input."""
+def _check_items(got, n_items):
     from oracle import rle as orle
+    assert len(got) == n_items                                     # padded duplicate dropped
+    for i, g in enumerate(got):
+        r = _hetero_results(i)
+        assert torch.equal(g['bboxes'], r.bboxes) and torch.equal(g['scores'], r.scores)
+        assert torch.equal(g['labels'], r.labels) and len(g['masks']) == len(r.bboxes)
+        for j, rle in enumerate(g['masks']):
+            assert rle['size'] == list(r.masks.shape[-2:])
+            dec = orle.rle_decode(orle.rle_from_string(rle['counts']), *rle['size'])
+            assert np.array_equal(dec, r.masks[j].numpy())
+
+
+@pytest.mark.parametrize('dst', [0, None])
+def test_gather_results_rle_heterogeneous_sizes_world2(dst):
+    """world 2, 5 items (5 % 2 != 0: rank 1 gets a wrap-around duplicate), every item with its own mask size: results
+    arrive on rank 0 only (mmengine collect_results) -- or on every rank with dst=None -- in DATASET order, truncated to
+    the dataset size, masks as COCO RLE strings that decode to the input; the capacities start too small and every rank
+    grows them identically from the all-gathered headers."""
     world, n_items = 2, 5
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker_rle, args=(world, _free_port(), n_items, ret), nprocs=world, join=True)
+    mp.spawn(_worker_rle, args=(world, _free_port(), n_items, dst, ret), nprocs=world, join=True)
+    assert ret[0][1] == ret[1][1]                                      # identical capacities on both ranks
     for rank in range(world):
-        got = ret[rank]
-        assert len(got) == n_items                                     # padded duplicate dropped
-        for i, g in enumerate(got):
-            r = _hetero_results(i)
-            assert torch.equal(g['bboxes'], r.bboxes) and torch.equal(g['scores'], r.scores)
-            assert torch.equal(g['labels'], r.labels) and len(g['masks']) == len(r.bboxes)
-            for j, rle in enumerate(g['masks']):
-                assert rle['size'] == list(r.masks.shape[-2:])
-                dec = orle.rle_decode(orle.rle_from_string(rle['counts']), *rle['size'])
-                assert np.array_equal(dec, r.masks[j].numpy())
+        for got in ret[rank][0]:
+            if dst is None or rank == dst:
+                _check_items(got, n_items)
+            else:
+                assert got is None
+
+
+def test_gather_results_single_process_and_lazy_view():
+    from rsprompter_amd import dist as rdist
+    mine = [_hetero_results(i) for i in range(5)]
+    got = rdist.gather_results(mine, codec=NumpyCodec(), state=rdist.ExchangeState())
+    assert isinstance(got, rdist.GatheredResults) and got.n_instances == 11
+    _check_items(list(got), 5)
+    _check_items(got[0:5], 5)
+
+
+def test_collect_host_budget_world8_800_instances():
+    """What rank 0 does per step at world = 8 with 8 x 100 instances per rank (the bench shape): build the lazy view of
+    the gathered buffers.  No per-instance Python work: the budget is 20 ms (it takes well under one)."""
+    import time
+    from rsprompter_amd import dist as rdist
+    world, n_img, k = 8, 8, 100
+    rng = np.random.default_rng(0)
+    headers = np.zeros((world, 4), dtype=np.int64)
+    lens = rng.integers(200, 1200, size=(world, 1024)).astype(np.int32)
+    meta = np.zeros((world, 8, 3), dtype=np.int32)
+    meta[:, :, 0], meta[:, :, 1], meta[:, :, 2] = k, 1024, 1024
+    headers[:, 0], headers[:, 1] = n_img, n_img * k
+    headers[:, 2] = lens[:, :n_img * k].sum(1)
+    rec = rng.random((world, 1024, 6), dtype=np.float32)
+    flat = rng.integers(48, 112, size=(world, 1 << 20), dtype=np.uint8)
+    t = time.perf_counter()
+    for _ in range(10):
+        g = rdist.GatheredResults(headers, meta, rec, lens, flat, dataset_size=world * n_img)
+    dt = (time.perf_counter() - t) / 10
+    assert len(g) == 64 and g.n_instances == 6400
+    assert dt < 0.020, f'collect-side host work {dt * 1e3:.2f} ms'
+    item = g[9]                                                        # dataset item 9 = rank 1, image 1
+    assert item['bboxes'].shape == (100, 4) and len(item['masks']) == 100
+    b0 = int(lens[1, :100].sum())
+    assert item['masks'][0]['counts'] == flat[1, b0:b0 + int(lens[1, 100])].tobytes()
 
 
 def test_dense_exchange_rejects_heterogeneous_sizes():

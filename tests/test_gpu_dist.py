@@ -103,3 +103,77 @@ def test_mask_rle_matches_coco_restatement(dev):
     d = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'coco_rle_strings.json')))
     it = d['items'][0]
     assert got[0]['counts'].decode() == it['counts']                      # the reference's own string for this box
+
+
+def _blob_results(rank, n_imgs, dev):
+    """per-image results with their own mask sizes and blob-like masks (tens of runs each)"""
+    from rsprompter_amd.structures import InstanceData
+    out = []
+    for i in range(n_imgs):
+        g = torch.Generator().manual_seed(900 + 10 * rank + i)
+        k = [3, 0, 5, 2][(2 * rank + i) % 4]
+        hw = [(96, 128), (70, 50), (128, 64), (33, 77)][(rank + i) % 4]
+        noise = torch.rand(k, 1, *hw, generator=g)
+        masks = torch.nn.functional.avg_pool2d(noise, 9, 1, 4)[:, 0] > 0.5 if k else torch.zeros(0, *hw, dtype=torch.bool)
+        out.append(InstanceData(bboxes=(torch.rand(k, 4, generator=g) * 50).to(dev), scores=torch.rand(k, generator=g).to(dev),
+                                labels=torch.randint(0, 10, (k,), generator=g).to(dev), masks=masks.to(dev)))
+    return out
+
+
+def test_gather_results_device_codec_side_stream(dev):
+    """the default hand-off on the device, single process: RLE counts + COCO strings by the HIP kernels on a side
+    stream, pinned-host copy, lazy view; strings decode to the masks (oracle/rle.py)."""
+    from oracle import rle as orle
+    from rsprompter_amd import dist as rdist
+    res = _blob_results(0, 4, dev)
+    side = torch.cuda.Stream(device=dev)
+    state = rdist.ExchangeState()
+    for rep in range(2):
+        h = rdist.gather_results(res, stream=side, state=state)
+        got = h.collect()
+        assert isinstance(got, rdist.GatheredResults) and len(got) == 4
+        for g, r in zip(got, res):
+            assert torch.equal(g['bboxes'], r.bboxes.cpu()) and torch.equal(g['labels'], r.labels.cpu())
+            for j, rle in enumerate(g['masks']):
+                dec = orle.rle_decode(orle.rle_from_string(rle['counts']), *rle['size'])
+                assert np.array_equal(dec, r.masks[j].cpu().numpy())
+
+
+def _worker_rle(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from rsprompter_amd import dist as rdist
+    dev = torch.device('cuda:0')
+    try:
+        rdist.init_from_env(backend='gloo')
+        side = torch.cuda.Stream(device=dev)
+        got = rdist.gather_results(_blob_results(rank, 2, dev), dataset_size=4, stream=side).collect()
+        ret[rank] = None if got is None else list(got)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception as e:
+        ret[rank] = repr(e)
+
+
+def test_gather_results_two_ranks_on_one_device():
+    """two processes sharing cuda:0 over gloo (the calls bench.py issues over RCCL): results reach rank 0 only, in
+    dataset order (item j = image j // 2 of rank j % 2)."""
+    from oracle import rle as orle
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_rle, args=(2, port, ret), nprocs=2, join=True)
+    if isinstance(ret[0], str) or isinstance(ret[1], str):
+        msg = f'{ret[0]} / {ret[1]}'
+        if 'gloo' in msg.lower() or 'not supported' in msg.lower() or 'not implemented' in msg.lower():
+            pytest.skip(f'gloo cannot run this collective on device tensors here: {msg[:200]}')
+        raise AssertionError(msg)
+    assert ret[1] is None and len(ret[0]) == 4
+    cpu = torch.device('cpu')
+    for j, g in enumerate(ret[0]):
+        r = _blob_results(j % 2, 2, cpu)[j // 2]
+        assert torch.equal(g['bboxes'], r.bboxes) and len(g['masks']) == len(r.bboxes)
+        for t, rle in enumerate(g['masks']):
+            dec = orle.rle_decode(orle.rle_from_string(rle['counts']), *rle['size'])
+            assert np.array_equal(dec, r.masks[t].numpy())
