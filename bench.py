@@ -99,6 +99,64 @@ def cpu_baseline(arch, num_classes, passes=3):
                        f'({n_det} prompt sets through the SAM decoder)')
 
 
+def parity_canary(model, imgs, metas, arch, kind):
+    """One extra step OUTSIDE the timed region on the bench's own inputs, tile 0 compared with the CPU oracle's answer
+    for exactly this fixture (tests/golden/bench_canary_anchor_<arch>.pt, written by tests/golden/make_golden_bench.py;
+    nothing under oracle/ is imported here).  Reports whether every output of the step is finite, the max-abs error
+    of the image embedding and of the SAM low-resolution mask logits of the detections matched to the oracle's, and how
+    many matched.  A bench that runs on NaN rows, stale kernels or a wrong weight layout says so on its own line."""
+    import rsprompter_amd.debug as dbg
+    from rsprompter_amd.structures import DetDataSample
+    out = dict(finite=None, golden=None)
+    keep, dbg.KEEP_TRACES = dbg.KEEP_TRACES, True
+    try:
+        res = model.test_step(dict(inputs=imgs, data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
+        torch.cuda.synchronize()
+        fin = True
+        for r in res:
+            pi = r.pred_instances
+            fin &= bool(torch.isfinite(pi.bboxes).all()) and bool(torch.isfinite(pi.scores).all())
+        emb = getattr(model, '_last_embeddings', None)
+        if emb is not None:
+            fin &= bool(torch.isfinite(emb).all())
+        low = None
+        if kind == 'anchor':
+            tr = model.roi_head._last_mask_trace
+            low = None if tr is None else tr['mask_preds']
+            if low is not None:
+                fin &= bool(torch.isfinite(low).all())
+        out['finite'] = bool(fin)
+        path = os.path.join(ROOT, 'tests', 'golden', f'bench_canary_{kind}_{arch}.pt')
+        if kind != 'anchor' or not os.path.exists(path) or low is None:
+            return out
+        g = torch.load(path, map_location='cpu', weights_only=True)
+        out['golden'] = os.path.relpath(path, ROOT)
+        out['image_embedding_max_abs_err'] = float((emb[0, :, ::8, ::8].float().cpu() - g['embedding_sample']).abs().max())
+        pi = res[0].pred_instances
+        k0 = int(pi.labels.shape[0])
+        pb, ps, pl = pi.bboxes.float().cpu(), pi.scores.float().cpu(), pi.labels.cpu()
+        sample = low[:k0, 0, ::16, ::16].float().cpu()
+        used, errs = set(), []
+        for j in range(g['labels'].shape[0]):          # same label, same box (1e-2 px), same score (1e-4): tests/_match.py
+            d = (pb - g['bboxes'][j]).abs().amax(1)
+            d[(pl != g['labels'][j])] = float('inf')
+            for u in used:
+                d[u] = float('inf')
+            i = int(d.argmin()) if d.numel() else -1
+            if i >= 0 and float(d[i]) < 1e-2 and abs(float(ps[i]) - float(g['scores'][j])) < 1e-4:
+                used.add(i)
+                errs.append(float((sample[i] - g['low_res_sample'][j]).abs().max()))
+        out['detections_matched'] = f'{len(errs)}/{int(g["labels"].shape[0])}'
+        out['mask_logit_max_abs_err'] = max(errs) if errs else None
+        out['mask_logit_range'] = g['low_res_absmax']
+        out['tolerance'] = 1e-3
+        out['ok'] = bool(fin and errs and max(errs) < 1e-3 and out['image_embedding_max_abs_err'] < 1e-3
+                         and len(errs) >= int(g['labels'].shape[0]) - 4)
+    finally:
+        dbg.KEEP_TRACES = keep
+    return out
+
+
 def _pmc_traffic(arch):
     """HBM bytes per launch of the dominant GEMM from the committed rocprofv3 PMC passes (profiles/r1_pmc/,
     FETCH_SIZE x2 + WRITE_SIZE as MI355X_MICROARCH.md prescribes); the counters cannot be collected inside this
@@ -222,6 +280,7 @@ def main():
         elapsed = float(t.item())
     n_dets = sum(len(r.bboxes) for r in step())
     sync()
+    canary = parity_canary(model, imgs, metas, args.arch, args.model) if rank == 0 and not args.f8corr else None
 
     result = None
     # ---- roofline leg: one extra instrumented step, per-kernel HIP events on the launch stream.  Every rank runs
@@ -279,6 +338,7 @@ def main():
                                    'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                    'frac': None if attn_tf is None else round(attn_tf / PEAK_F16_MFMA_TFLOPS, 4),
                                    'attention_gemm_gflop_per_image': ATTN_GEMM_GFLOP_PER_IMAGE[args.arch]},
+            'parity_canary': canary,
             'kernels': kernels,
         }
         if world == 1 and not args.no_cpu_baseline and args.model == 'anchor':

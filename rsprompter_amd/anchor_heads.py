@@ -15,7 +15,7 @@ import math
 import numpy as np
 import torch
 
-from . import ops
+from . import debug, ops
 from .necks import conv3x3_weight, fold_bn
 from .nnutil import HIPModule, add_param, nchw_view, nhwc_view
 from .registry import MODELS, TASK_UTILS
@@ -505,7 +505,7 @@ class RSPrompterAnchorRoIPromptHead(HIPModule):
             r.labels = out['ids'][b, :k].to(torch.long)
             r.cand_index = out['src'][b, :k]
             res.append(r)
-        self._last_bbox_trace = dict(rois=rois, roi_feats=feats, head=head)
+        self._last_bbox_trace = debug.keep(lambda: dict(rois=rois, roi_feats=feats, head=head))   # tests only
         return res
 
     @staticmethod
@@ -536,7 +536,7 @@ class RSPrompterAnchorRoIPromptHead(HIPModule):
                 res.masks = torch.zeros((0, h, w), dtype=torch.bool, device=res.bboxes.device)
             return results_list
         mr = self._mask_forward(x, mask_rois, image_embeddings, image_positional_embeddings, pes)
-        self._last_mask_trace = dict(mr, mask_rois=mask_rois)
+        self._last_mask_trace = debug.keep(lambda: dict(mr, mask_rois=mask_rois))                  # tests only
         mask_preds = mr['mask_preds'].split([len(r) for r in results_list], 0)
         return self.mask_head.predict_by_feat(mask_preds, results_list, batch_img_metas, self.test_cfg,
                                               rescale=rescale)

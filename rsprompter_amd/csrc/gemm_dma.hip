@@ -676,7 +676,7 @@ int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s);
 int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (d.a_rows <= 0) return RSP_EINVAL;
   // tile hints 40 + v: the two-blocks-per-CU persistent kernel (gemm_s2.hip), experiment variant v
-  if ((d.tile_hint & 0xff) >= 40 && (d.tile_hint & 0xff) < 104) {
+  if ((d.tile_hint & 0xff) >= 40 && (d.tile_hint & 0xff) < 168) {
     if (!rsp_gemm_s2_eligible(d)) return RSP_EINVAL;
     return rsp_gemm_s2_dispatch(d, (d.tile_hint & 0xff) - 40, s);
   }

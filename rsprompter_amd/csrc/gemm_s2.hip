@@ -47,9 +47,21 @@ struct S2P {
   RspGemmDesc d;
   FastDiv fd_resmod, fd_resb;
   int nbm, nbn, ntiles, per_xcd, group_m;
+  unsigned* ticket;              // 9 words of this launch: next tile of XCD 0..7, blocks done
   unsigned long long* trace;     // tools only (VAR bit 5): per block and tile {start, loop end, epilogue end, hw id}
 };
 unsigned long long* g_s2_trace = nullptr;
+
+// Tile tickets: the blocks of an XCD draw their tiles from that XCD's counter (one returning device-scope atomic per
+// tile, ~1 us against a ~100 us tile) instead of a static stride -- co-resident blocks do not run at the same speed (the
+// older wave of a SIMD wins the matrix pipe, the younger fills its gaps), a static split leaves the fast half idle at
+// the end.  Every launch takes the next of 64 slots; the last block to finish zeroes the slot again.
+constexpr int TICKET_SLOTS = 64, TICKET_WORDS = 16;
+__device__ unsigned g_s2_tickets[TICKET_SLOTS * TICKET_WORDS];
+
+// epilogue specialisations (EPI template argument): bit flags of what the tile's outputs need; E_GENERIC = everything at
+// run time (all modes of the descriptor, slow: branches per 4 outputs)
+constexpr int E_RES = 1, E_GELU = 2, E_C = 4, E_PL = 8, E_GENERIC = 64;
 
 template <int I, int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -59,13 +71,14 @@ __device__ __forceinline__ void sfor(F&& f) {
   }
 }
 
-// VAR (experiment switches; 0 = product): bit 0 = static priority for the block in the odd workgroup slot of its CU
-// (HW_ID.TG_ID), bit 1 = fragment reads as one burst behind the barrier instead of between the MFMAs, bit 2 = no DMA
+// VAR (experiment switches; 0 = product): bit 0 = raised wave priority during the epilogue, bit 1 = epilogue without its stores (ablation), bit 2 = no DMA
 // inside the K loop (ablation, garbage results), bit 3 = no epilogue (ablation), bit 4 = every DMA reads the first K block
 // (cache-hot sources: separates memory latency from issue / LDS-write cost; garbage results), bit 5 = time stamps
-template <int VAR>
+template <int VAR, int EPI>
 __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+  // ONE LDS object (a second __shared__ variable makes hipcc drain the DMA queue before every fragment read): the ring
+  // + one word for the block-wide broadcast of the next tile ticket
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE + 16];
   const RspGemmDesc& d = p.d;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,9 +88,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
   const int nk = d.K / KS;
 
   const unsigned hw_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));     // HW_REG_HW_ID
-  if constexpr (VAR & 1) {
-    if ((hw_id >> 16) & 1) __builtin_amdgcn_s_setprio(1);
-  }
   int trace_n = 0;
 
   // ---- buffer descriptors of the four operand planes (host checked: every plane < 2^31 bytes) ----
@@ -167,20 +177,19 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
   // one ring step: [my DMA of stage t+1 has landed, fc has landed | barrier] then the 24 MFMAs on fc with the 12
   // fragment reads of stage t+1 (ring offset on) and the 6 DMA instructions of stage t+3 (-> ring offset oc, whose last
   // reads every wave completed before the barrier) spread between them
-  auto step = [&](const Frags& fc, Frags& fn, const Tile& tl, int t, int oc, int on, auto rdc, auto dmac, auto vmc) {
+  // (a software L2 prefetch -- one dword per operand row touched 4 K blocks ahead of the ring, by LDS-DMA into a
+  // landing zone -- was built and measured in round 3: 25-40 % SLOWER (64 separate lines per wave instruction cost the
+  // texture path more than the hidden latency is worth); removed)
+  auto step = [&](const Frags& fc, Frags& fn, const Tile& tl, int t, int oc, int on, auto rdc, auto dmac, auto vmc, auto evc) {
     constexpr bool RD = decltype(rdc)::value, DMA = decltype(dmac)::value && !(VAR & 4);
     constexpr int VM = decltype(vmc)::value;
     __builtin_amdgcn_s_waitcnt(wc_vm_lgkm0(VM));
     __builtin_amdgcn_s_barrier();
-    if constexpr (RD && (VAR & 2)) {
-      sfor<0, 12>([&](auto qc) { read_frag(qc, fn, on); });
-      __builtin_amdgcn_sched_barrier(0);
-    }
     sfor<0, 24>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       mfma_q(qc, fc);
       __builtin_amdgcn_sched_barrier(0);
-      if constexpr (RD && !(VAR & 2) && q < 12) {
+      if constexpr (RD && q < 12) {
         read_frag(qc, fn, on);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -192,11 +201,94 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
   };
   using T_ = std::true_type; using F_ = std::false_type;
 
+  // ---- generic epilogue: every mode of the descriptor at run time (plane residual, cat8 planes, relu / sigmoid,
+  // ragged N ...); ~5x the instructions of the specialised forms, kept for the rare shapes ----
+  auto epilogue_generic = [&](const Tile& done) {
+    const float alpha = d.alpha;
+    const float cs = d.Chi ? ldexpf(1.0f, RSP_PLANE_EXP(d.c_scale_log2)) : 1.0f;
+    const bool c_f8 = RSP_PLANE_IS_F8(d.c_scale_log2);
+    half_t* const chi = reinterpret_cast<half_t*>(d.Chi);
+    half_t* const clo = reinterpret_cast<half_t*>(d.Clo);
+    const float rsc = d.res_hi ? ldexpf(1.0f, -RSP_PLANE_EXP(d.res_scale_log2)) : 1.0f;
+    const int colw = done.n0 + wn * 64 + 4 * hh;           // + j * 32 + 8 * q
+    f32x4 bias4[TN][4];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int col = colw + j * 32 + 8 * q;
+        bias4[j][q] = (d.bias && col < N) ? *reinterpret_cast<const f32x4*>(d.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    sfor<0, TM>([&](auto ic) {
+      constexpr int i = decltype(ic)::value;
+      const int row = done.m0 + wm * 128 + i * 32 + l31;
+      int cr = -1;
+      if (row < M) cr = d.c_rowmap ? d.c_rowmap[row] : row;
+      if (cr >= 0) {
+        int64_t rrow = cr;
+        if (d.res || d.res_hi) {
+          if (d.res_mod > 0) rrow = cr - p.fd_resmod.div(cr) * d.res_mod;
+          if (d.res_bmap) {
+            const int rb = p.fd_resb.div(cr);
+            rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (cr - rb * d.res_brows);
+          }
+        }
+        sfor<0, TN * 4>([&](auto jqc) {
+          constexpr int jq = decltype(jqc)::value, j = jq / 4, q = jq % 4;
+          const int col = colw + j * 32 + 8 * q;
+          if (col < N) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rsp_act(acc[i][j][4 * q + e] * alpha + bias4[j][q][e], d.act);
+            if (d.res_hi) {
+              const int64_t ro = ((int64_t)(col >> 5) * d.res_rows + rrow) * 32 + (col & 31);
+              const half4_t rh = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(d.res_hi) + ro);
+              const half4_t rl = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(d.res_lo) + ro);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += ((float)rh[e] + (float)rl[e]) * rsc;
+            }
+            if (d.res) {
+              const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + rrow * d.ldr + col);
+              v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
+            }
+            if (d.C && (d.c_ncols <= 0 || col < d.c_ncols)) *reinterpret_cast<f32x4*>(d.C + (int64_t)cr * d.ldc + col) = v;
+            if (d.Chi && col >= d.pl_col0) {
+              const int pch = col - d.pl_col0;
+              const int64_t po = ((int64_t)(pch >> 5) * d.c_rows + cr) * 32 + (pch & 31);
+              rsp_store_planes4(chi, clo, po, f32x4{v[0] * cs, v[1] * cs, v[2] * cs, v[3] * cs}, c_f8);
+            }
+          }
+        });
+      }
+    });
+  };
+
   // ---- persistent tile walk ----
-  const int xcd = blockIdx.x & 7, bl = blockIdx.x >> 3, nl = gridDim.x >> 3;
-  const int id_end = min((xcd + 1) * p.per_xcd, p.ntiles);
-  int id = xcd * p.per_xcd + bl;
-  if (id >= id_end) return;
+  const int xcd = blockIdx.x & 7;
+  const int id_base = xcd * p.per_xcd, id_end = min((xcd + 1) * p.per_xcd, p.ntiles);
+  auto next_id = [&]() -> int {                       // block-uniform: lane 0 of wave 0 draws, LDS-free broadcast
+    int v = 0;
+    if (tid == 0) v = (int)__hip_atomic_fetch_add(p.ticket + xcd, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  };
+  volatile int* s_next = reinterpret_cast<volatile int*>(smem + NS * STAGE);
+  auto draw = [&]() -> int {                          // called with no DMA in flight (kernel entry, end of a K loop)
+    if (tid == 0) *s_next = id_base + next_id();
+    __syncthreads();
+    const int v = *s_next;
+    __syncthreads();
+    return __builtin_amdgcn_readfirstlane(v);
+  };
+  auto finish = [&]() {                               // the last block of the launch re-arms the ticket slot
+    if (tid == 0) {
+      const unsigned dn = __hip_atomic_fetch_add(p.ticket + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (dn == gridDim.x - 1) {
+        for (int i = 0; i < 9; ++i) __hip_atomic_store(p.ticket + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  };
+  int id = draw();
+  if (id >= id_end) { finish(); return; }
   Tile cur = tile_setup(id);
   sfor<0, NS>([&](auto sc) { issue_stage(cur, decltype(sc)::value, decltype(sc)::value * STAGE); });
 
@@ -220,13 +312,13 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
     auto adv = [&]() { oc = on; on += STAGE; if (on == NS * STAGE) on = 0; };
     int t = 0;
     for (; t + 4 < nk; t += 2) {
-      step(f0, f1, cur, t, oc, on, T_{}, T_{}, std::integral_constant<int, NDMA>{}); adv();
-      step(f1, f0, cur, t + 1, oc, on, T_{}, T_{}, std::integral_constant<int, NDMA>{}); adv();
+      step(f0, f1, cur, t, oc, on, T_{}, T_{}, std::integral_constant<int, NDMA>{}, T_{}); adv();
+      step(f1, f0, cur, t + 1, oc, on, T_{}, T_{}, std::integral_constant<int, NDMA>{}, F_{}); adv();
     }
     // t = nk - 4: the last stage that still has a DMA to issue (nk - 1)
-    step(f0, f1, cur, t, oc, on, T_{}, T_{}, std::integral_constant<int, NDMA>{}); adv();
-    step(f1, f0, cur, t + 1, oc, on, T_{}, F_{}, std::integral_constant<int, NDMA>{}); adv();
-    step(f0, f1, cur, t + 2, oc, on, T_{}, F_{}, std::integral_constant<int, 0>{}); adv();
+    step(f0, f1, cur, t, oc, on, T_{}, T_{}, std::integral_constant<int, NDMA>{}, T_{}); adv();
+    step(f1, f0, cur, t + 1, oc, on, T_{}, F_{}, std::integral_constant<int, NDMA>{}, F_{}); adv();
+    step(f0, f1, cur, t + 2, oc, on, T_{}, F_{}, std::integral_constant<int, 0>{}, T_{}); adv();
     // last stage: its fragments are in f1; once every wave holds its own the ring is free for the next tile
     __builtin_amdgcn_s_waitcnt(WC_LGKM0);
     __builtin_amdgcn_s_barrier();
@@ -234,79 +326,155 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
     __builtin_amdgcn_sched_barrier(0);
 
     if constexpr (VAR & 32) ts1 = __builtin_amdgcn_s_memtime();
+    // The epilogue is VALU / VMEM work issued into the gaps of the co-resident block's MFMA stream; at equal priority
+    // the SIMD's arbiter gives the older wave's stream nearly every slot (measured, time stamps: the younger block's
+    // epilogue took 145k cycles against 19k alone).  An MFMA stream needs one issue slot in 32 cycles: it loses little
+    // when the epilogue wave goes first.
+    if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(3);
     const Tile done = cur;
-    id += nl;
+    id = draw();
     const bool more = id < id_end;
-    if (more) {
-      cur = tile_setup(id);
-      sfor<0, NS>([&](auto sc) { issue_stage(cur, decltype(sc)::value, decltype(sc)::value * STAGE); });
-    }
+    auto queue_next = [&]() {                         // the next tile's first three stages fly during the epilogue
+      if (more) sfor<0, NS>([&](auto sc) { issue_stage(cur, decltype(sc)::value, decltype(sc)::value * STAGE); });
+    };
 
     // ---- epilogue of tile `done`, straight from the (transposed) accumulators: lane = row, register quad = 4 columns ----
-    if constexpr (!(VAR & 8)) {
-      const float alpha = d.alpha;
-      const float cs = d.Chi ? ldexpf(1.0f, RSP_PLANE_EXP(d.c_scale_log2)) : 1.0f;
-      const bool c_f8 = RSP_PLANE_IS_F8(d.c_scale_log2);
-      half_t* const chi = reinterpret_cast<half_t*>(d.Chi);
-      half_t* const clo = reinterpret_cast<half_t*>(d.Clo);
-      const float rsc = d.res_hi ? ldexpf(1.0f, -RSP_PLANE_EXP(d.res_scale_log2)) : 1.0f;
-      const int colw = done.n0 + wn * 64 + 4 * hh;           // + j * 32 + 8 * q
-      f32x4 bias4[TN][4];
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int col = colw + j * 32 + 8 * q;
-          bias4[j][q] = (d.bias && col < N) ? *reinterpret_cast<const f32x4*>(d.bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-      sfor<0, TM>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        const int row = done.m0 + wm * 128 + i * 32 + l31;
-        int cr = -1;
-        if (row < M) cr = d.c_rowmap ? d.c_rowmap[row] : row;
-        if (cr >= 0) {
-          int64_t rrow = cr;
-          if (d.res || d.res_hi) {
-            if (d.res_mod > 0) rrow = cr - p.fd_resmod.div(cr) * d.res_mod;
-            if (d.res_bmap) {
-              const int rb = p.fd_resb.div(cr);
-              rrow = (int64_t)d.res_bmap[rb] * d.res_brows + (cr - rb * d.res_brows);
-            }
-          }
-          sfor<0, TN * 4>([&](auto jqc) {
-            constexpr int jq = decltype(jqc)::value, j = jq / 4, q = jq % 4;
-            const int col = colw + j * 32 + 8 * q;
-            if (col < N) {
-              f32x4 v;
-#pragma unroll
-              for (int e = 0; e < 4; ++e) v[e] = rsp_act(acc[i][j][4 * q + e] * alpha + bias4[j][q][e], d.act);
-              if (d.res_hi) {
-                const int64_t ro = ((int64_t)(col >> 5) * d.res_rows + rrow) * 32 + (col & 31);
-                const half4_t rh = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(d.res_hi) + ro);
-                const half4_t rl = *reinterpret_cast<const half4_t*>(reinterpret_cast<const half_t*>(d.res_lo) + ro);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += ((float)rh[e] + (float)rl[e]) * rsc;
-              }
-              if (d.res) {
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + rrow * d.ldr + col);
-                v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
-              }
-              if (d.C && (d.c_ncols <= 0 || col < d.c_ncols)) *reinterpret_cast<f32x4*>(d.C + (int64_t)cr * d.ldc + col) = v;
-              if (d.Chi && col >= d.pl_col0) {
-                const int pch = col - d.pl_col0;
-                const int64_t po = ((int64_t)(pch >> 5) * d.c_rows + cr) * 32 + (pch & 31);
-                rsp_store_planes4(chi, clo, po, f32x4{v[0] * cs, v[1] * cs, v[2] * cs, v[3] * cs}, c_f8);
-              }
-            }
-          });
-        }
-      });
-    } else {
+    if constexpr (VAR & 8) {
+      if (more) cur = tile_setup(id);
+      queue_next();
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(acc[i][j]));
+    } else if constexpr (EPI & E_GENERIC) {
+      if (more) cur = tile_setup(id);
+      queue_next();
+      epilogue_generic(done);
+    } else {
+      // Specialised form.  Host guarantees: N, c_ncols, pl_col0 multiples of 64 (a wave's 64 columns are all fp32
+      // output, all plane output, or both), act in {none, GELU per E_GELU}, no plane residual, no cat8 output, every
+      // tensor the epilogue touches < 2^31 bytes.  It is BRANCH-FREE: all memory operations are buffer operations --
+      // a row that is not stored (beyond M, c_rowmap < 0) carries an offset beyond the descriptor's range (stores are
+      // dropped, loads return 0), an absent bias / row map is a descriptor of 0 bytes.  Straight-line code lets hipcc
+      // count its waits (s_waitcnt vmcnt(N)), and vmcnt retires in order and counts stores, so ORDER matters: bias,
+      // destination rows and the next tile's source rows are loaded in one batch; the residual of row group i + 1 is
+      // requested BEFORE row group i is stored (waiting for it never waits for stores); the next tile's DMA is queued
+      // once no loaded value is pending (hipcc answers any use of a loaded value with vmcnt(0) while an LDS-DMA is in
+      // flight), i.e. before the stores of the last row group -- or, without a residual, before the whole epilogue.
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      const float alpha = d.alpha;
+      const float cs = (EPI & E_PL) ? ldexpf(1.0f, RSP_PLANE_EXP(d.c_scale_log2)) : 1.0f;
+      const int cols0 = done.n0 + wn * 64;                    // scalar: first column of this wave
+      const bool active = cols0 < N;                          // N % 64 == 0: all 64 columns or none
+      const bool do_c = (EPI & E_C) && active && (d.c_ncols <= 0 || cols0 < d.c_ncols);
+      const bool do_p = (EPI & E_PL) && active && cols0 >= d.pl_col0;
+      const int lane_c = 4 * hh;                              // + j * 32 + 8 * q: this lane's first column of a quad
+      const auto rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias), 0, d.bias ? N * 4 : 0, 0x00020000);
+      f32x4 bias4[TN][4];
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          bias4[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, (lane_c + j * 32 + 8 * q) * 4, cols0 * 4, 0));
+      const auto rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(d.c_rowmap), 0, d.c_rowmap ? M * 4 : 0, 0x00020000);
+      int crow[TM];                                           // destination row of this lane per row group, -1: none
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int row = done.m0 + wm * 128 + i * 32 + l31;
+        const int mapped = (int)__builtin_amdgcn_raw_buffer_load_b32(rM, row * 4, 0, 0);
+        crow[i] = row < M ? (d.c_rowmap ? mapped : row) : -1;
+      }
+      if (more) cur = tile_setup(id);                         // (its row-map loads join the batch)
+      if constexpr (!(EPI & E_RES)) queue_next();
+      // phase 1, in place: acc <- act(acc * alpha + bias)  (then the 32 bias registers are free for the residual)
+      sfor<0, TM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        sfor<0, TN * 4>([&](auto jqc) {
+          constexpr int jq = decltype(jqc)::value, j = jq / 4, q = jq % 4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = acc[i][j][4 * q + e] * alpha + bias4[j][q][e];
+            acc[i][j][4 * q + e] = (EPI & E_GELU) ? rsp_gelu(t) : t;
+          }
+        });
+      });
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));     // keep the phases apart (register pressure)
+      // phase 2: residual (requested one row group ahead, before the previous group's stores) and stores
+      const auto rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.res), 0, (EPI & E_RES) ? 0x7fffffff : 0, 0x00020000);
+      f32x4 rv[2][TN * 4];
+      auto res_load = [&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const int crc = max(crow[i], 0);                      // rows that are not stored read row 0 (never used)
+        int rrow = crc;
+        if (d.res_mod > 0) rrow = crc - p.fd_resmod.div(crc) * d.res_mod;
+        const int ro = (rrow * d.ldr + lane_c) * 4;           // (gathered residual rows, res_bmap: generic path)
+        sfor<0, TN * 4>([&](auto jqc) {
+          constexpr int jq = decltype(jqc)::value;
+          rv[i & 1][jq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, ro + ((jq / 4) * 32 + 8 * (jq % 4)) * 4, cols0 * 4, 0));
+        });
+      };
+      if constexpr (EPI & E_RES) res_load(std::integral_constant<int, 0>{});
+      // output descriptors: without a row map rows are relative to the tile (any tensor size), with one to the tensor
+      const int64_t c_row0 = d.c_rowmap ? 0 : done.m0;
+      const int c_rows_here = d.c_rowmap ? 0x7fffffff / max(d.ldc * 4, 1) : M - done.m0;
+      const auto rC = __builtin_amdgcn_make_buffer_rsrc(d.C ? d.C + c_row0 * d.ldc : nullptr, 0,
+                                                        do_c ? (int)min((int64_t)c_rows_here * d.ldc * 4, (int64_t)0x7fffffff) : 0, 0x00020000);
+      const int pl_bytes = do_p ? (int)(((int64_t)((N - d.pl_col0) >> 5) * d.c_rows) << 6) : 0;
+      const auto rH = __builtin_amdgcn_make_buffer_rsrc(d.Chi, 0, pl_bytes, 0x00020000);
+      const auto rL = __builtin_amdgcn_make_buffer_rsrc(d.Clo, 0, pl_bytes, 0x00020000);
+      const int pl_blk0 = (cols0 - d.pl_col0) >> 5;           // K block (of the plane tensor) of this wave's first column
+      sfor<0, TM>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        if constexpr ((EPI & E_RES) && i + 1 < TM) res_load(std::integral_constant<int, i + 1>{});
+        if constexpr (EPI & E_RES) {
+          sfor<0, TN * 4>([&](auto jqc) {
+            constexpr int jq = decltype(jqc)::value, j = jq / 4, q = jq % 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += rv[i & 1][jq][e];
+          });
+          if constexpr (i + 1 == TM) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));   // every loaded value consumed ...
+            queue_next();                                                        // ... before the DMA is queued
+          }
+        }
+        const int cr = crow[i];
+        // (no SGPR soffset on the 16-byte stores: with one, hipcc assumes the data registers may be overwritten by the
+        // very next VALU instruction, and the in-place plane split behind the store did overwrite them -- measured: a few
+        // fp32 outputs came out as value * plane scale)
+        const unsigned co = cr < 0 ? OOB : (unsigned)(((cr - (int)c_row0) * d.ldc + lane_c + cols0) * 4);
+        const unsigned po = cr < 0 ? OOB : (unsigned)(cr * 64 + lane_c * 2);
+        sfor<0, TN * 4>([&](auto jqc) {
+          constexpr int jq = decltype(jqc)::value, j = jq / 4, q = jq % 4;
+          const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          if constexpr ((EPI & E_C) && !(VAR & 2))
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rC, co + (j * 32 + 8 * q) * 4, 0, 0);
+          if constexpr ((EPI & E_C) && (VAR & 2)) asm volatile("" ::"v"(v));
+          if constexpr (EPI & E_PL) {
+            half4_t h4, l4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float x = v[e] * cs;
+              const float xh = __builtin_fminf(__builtin_fmaxf(x, -RSP_F16_MAX), RSP_F16_MAX);
+              h4[e] = (half_t)xh;
+              l4[e] = (half_t)__builtin_fminf(__builtin_fmaxf(x - (float)h4[e], -RSP_F16_MAX), RSP_F16_MAX);
+            }
+            const int so = ((pl_blk0 + j) * d.c_rows) << 6;   // scalar: K block of this quad, bytes
+            if constexpr (VAR & 2) {
+              asm volatile("" ::"v"(h4), "v"(l4));
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h4), rH, po + 16 * q, so, 0);
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l4), rL, po + 16 * q, so, 0);
+            }
+          }
+        });
+      });
     }
+    if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
     if constexpr (VAR & 32) {
       if (p.trace && tid == 0 && trace_n < 16) {
         unsigned long long* t = p.trace + ((size_t)blockIdx.x * 16 + trace_n) * 4;
@@ -317,10 +485,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
     }
     if (!more) break;
   }
+  finish();
 }
 
-template <int VAR>
+template <int VAR, int EPI>
 int launch_s2(const RspGemmDesc& d, hipStream_t s) {
+  static unsigned slot = 0;
+  static unsigned* tickets = nullptr;
+  if (!tickets && hipGetSymbolAddress(reinterpret_cast<void**>(&tickets), HIP_SYMBOL(g_s2_tickets)) != hipSuccess) return RSP_ELAUNCH;
   S2P p; p.d = d;
   p.fd_resmod = make_fastdiv(d.res_mod); p.fd_resb = make_fastdiv(d.res_brows);
   p.nbm = (d.M + BM - 1) / BM; p.nbn = (d.N + BN - 1) / BN;
@@ -331,8 +503,9 @@ int launch_s2(const RspGemmDesc& d, hipStream_t s) {
   p.group_m = (d.tile_hint >> 8) & 0xff;
   if (p.group_m == 0) p.group_m = 8;
   p.trace = g_s2_trace;
+  p.ticket = tickets + (size_t)(slot++ % TICKET_SLOTS) * TICKET_WORDS;
   int nblk = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;     // a multiple of 8: every XCD gets nblk / 8 walkers
-  hipLaunchKernelGGL((gemm_f16x3_s2_kernel<VAR>), dim3((unsigned)nblk), dim3(NTHR), 0, s, p);
+  hipLaunchKernelGGL((gemm_f16x3_s2_kernel<VAR, EPI>), dim3((unsigned)nblk), dim3(NTHR), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
@@ -355,17 +528,40 @@ bool rsp_gemm_s2_eligible(const RspGemmDesc& d) {
   return true;
 }
 
+// var: experiment switches of the kernel (0 = product); the epilogue specialisation follows from the descriptor
 int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s) {
-  switch (var) {
-    case 0: return launch_s2<0>(d, s);
-    case 1: return launch_s2<1>(d, s);
-    case 4: return launch_s2<4>(d, s);
-    case 8: return launch_s2<8>(d, s);
-    case 16: return launch_s2<16>(d, s);
-    case 32: return launch_s2<32>(d, s);
-    case 33: return launch_s2<33>(d, s);
-    default: return RSP_EINVAL;
-  }
+  // the branch-free epilogue addresses every tensor it touches with 32-bit buffer offsets
+  const long long GB2 = 1LL << 31;
+  const long long c_bytes = d.C ? (d.c_rowmap ? (long long)d.c_rows * d.ldc * 4 : 0) : 0;   // no row map: tile-relative
+  const long long pl_bytes = d.Chi ? (((long long)((d.N - d.pl_col0) >> 5) * d.c_rows) << 6) : 0;
+  const long long res_bytes = d.res ? (long long)(d.res_mod > 0 ? d.res_mod : (d.res_bmap ? 0 : (d.c_rowmap ? d.c_rows : d.M))) * d.ldr * 4 : 0;
+  const bool fast = !(d.N & 63) && !(d.c_ncols & 63) && !(d.pl_col0 & 63) && !d.res_hi &&
+                    (d.act == RSP_ACT_NONE || d.act == RSP_ACT_GELU) && !(d.Chi && RSP_PLANE_IS_F8(d.c_scale_log2)) &&
+                    !(d.c_rowmap && d.c_rows <= 0) && c_bytes < GB2 && pl_bytes < GB2 && res_bytes < GB2 &&
+                    !(d.res && d.res_bmap) &&      /* gathered residual rows: size unknown here, generic path */
+                    (long long)256 * d.ldc * 4 < GB2 && !(var & 64);
+  const int epi = !fast ? E_GENERIC
+                        : (d.res ? E_RES : 0) | (d.act == RSP_ACT_GELU ? E_GELU : 0) | (d.C ? E_C : 0) | (d.Chi ? E_PL : 0);
+  var &= 63;
+#define S2_CASE(V, E) if (var == V && epi == (E)) return launch_s2<V, (E)>(d, s)
+  S2_CASE(0, E_C);                 // plain
+  S2_CASE(0, E_C | E_RES);         // proj, lin2, patch embed
+  S2_CASE(0, E_C | E_PL);          // qkv (column ranges), fp32 + planes
+  S2_CASE(0, E_PL);                // planes only
+  S2_CASE(0, E_PL | E_GELU);       // lin1
+  S2_CASE(0, E_C | E_GELU);
+  S2_CASE(0, E_GENERIC);
+  S2_CASE(1, E_C | E_RES); S2_CASE(1, E_PL | E_GELU);          // epilogue priority
+  S2_CASE(2, E_C | E_RES); S2_CASE(2, E_PL | E_GELU); S2_CASE(2, E_PL); S2_CASE(8, E_PL);   // no stores
+  S2_CASE(4, E_C | E_RES); S2_CASE(4, E_PL | E_GELU);          // no DMA in the loop
+  S2_CASE(8, E_C | E_RES); S2_CASE(8, E_PL | E_GELU);          // no epilogue
+  S2_CASE(16, E_C | E_RES); S2_CASE(16, E_PL | E_GELU);        // cache-hot DMA sources
+  S2_CASE(32, E_C | E_RES); S2_CASE(32, E_PL | E_GELU);        // time stamps
+  S2_CASE(33, E_C | E_RES); S2_CASE(33, E_PL | E_GELU);        // time stamps + epilogue priority
+  S2_CASE(1, E_C); S2_CASE(1, E_C | E_PL);
+#undef S2_CASE
+  if (var != 0) return RSP_EINVAL;
+  return launch_s2<0, E_GENERIC>(d, s);       // any other combination of outputs
 }
 
 // tools only (not part of include/rsp_hip.h): device buffer [512][16][4] u64 for the time-stamp variant

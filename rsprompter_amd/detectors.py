@@ -10,7 +10,7 @@ import copy
 
 import torch
 
-from . import ops
+from . import debug, ops
 from .nnutil import HIPModule
 from .registry import MODELS
 from .structures import DetDataSample, InstanceData
@@ -135,7 +135,7 @@ class RSPrompterAnchor(BaseDetectorHIP):
     def predict(self, batch_inputs, batch_data_samples, rescale=True):
         """models.py:148-170."""
         x, image_embeddings, image_positional_embeddings = self.extract_feat(batch_inputs)
-        self._last_embeddings = image_embeddings       # kept by reference for the parity tests (no copy)
+        self._last_embeddings = debug.keep(image_embeddings)       # parity tests only (rsprompter_amd/debug.py)
         if batch_data_samples[0].get('proposals', None) is None:
             rpn_results_list = self.rpn_head.predict(x, batch_data_samples, rescale=False)
         else:

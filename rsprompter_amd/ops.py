@@ -350,6 +350,8 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.res_bmap, d.res_brows = _ptr(res_bmap), res_brows
     d.b_rows = getattr(w, 'b_rows', 0)
     d.tile_hint = tile_hint
+    if d.c_rows == 0:
+        d.c_rows = rows          # also bounds C when rows are scattered (c_rowmap)
     d.act = act
     d.a_scale_log2 = plane_word(a_scale_log2, w_f8)
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))

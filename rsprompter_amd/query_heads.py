@@ -18,7 +18,7 @@ import math
 
 import torch
 
-from . import ops
+from . import debug, ops
 from .anchor_heads import _metas_of, _sine_pe
 from .detectors import BaseDetectorHIP
 from .necks import conv3x3_weight
@@ -330,8 +330,9 @@ class _Mask2FormerCore(HIPModule):
             dec_kin.append(ops.add_rows(d, pos_tabs[i], vmod=pos_tabs[i].shape[0]))          # key + key_pos
         qf = self.query_feat.weight.detach().unsqueeze(0).expand(B, -1, -1).reshape(B * Nq, f).contiguous()
         qe = self.query_embed.weight.detach()
-        trace = dict(attn_masks=[], query_feats=[], mask_features=mask_features, memory=mem)
+        trace = dict(attn_masks=[], query_feats=[], mask_pred_plus=[], mask_features=mask_features, memory=mem)
         dn, mpp = self._head_light(qf, mf_planes, B, H0 * W0)
+        trace['mask_pred_plus'].append(mpp)
         for i in range(self.num_transformer_decoder_layers):
             lvl = i % self.num_transformer_feat_level
             h, w = shapes[lvl]
@@ -349,6 +350,7 @@ class _Mask2FormerCore(HIPModule):
             qf = ops.layernorm(qf, _g(L, 'norms.2').weight, _g(L, 'norms.2').bias, 1e-5)
             trace['query_feats'].append(qf)
             dn, mpp = self._head_light(qf, mf_planes, B, H0 * W0)
+            trace['mask_pred_plus'].append(mpp)
         return dn, mpp.view(B, Nq, H0, W0), trace
 
 
@@ -384,7 +386,7 @@ class Mask2FormerHead(_Mask2FormerCore):
         """maskformer_head.py:569-604; the bilinear up-sampling to batch_input_shape stays symbolic (LazyUpsampledMasks)."""
         metas = _metas_of(batch_data_samples)
         cls, mask_pred, trace = self(x, batch_data_samples)
-        self._last_trace = trace
+        self._last_trace = debug.keep(trace)
         size = metas[0].get('batch_input_shape', metas[0].get('pad_shape'))
         return cls, LazyUpsampledMasks(mask_pred, size[:2])
 
@@ -463,7 +465,7 @@ class RSMask2FormerHead(_Mask2FormerCore):
         """models.py:633-658."""
         metas = _metas_of(batch_data_samples)
         cls, mask_pred, trace = self(x, batch_data_samples, image_embeddings, image_positional_embeddings)
-        self._last_trace = trace
+        self._last_trace = debug.keep(trace)
         size = metas[0].get('batch_input_shape', metas[0].get('pad_shape'))
         return cls, LazyUpsampledMasks(mask_pred, size[:2])
 
@@ -555,7 +557,7 @@ class RSPrompterQuery(BaseDetectorHIP):
         x, emb, pe = self.extract_feat(batch_inputs)
         cls, masks = self.panoptic_head.predict(x, batch_data_samples, image_embeddings=emb,
                                                 image_positional_embeddings=pe)
-        self._last_head_out = (cls, masks)             # kept by reference for the parity tests (no copy)
+        self._last_head_out = debug.keep((cls, masks))     # parity tests only (rsprompter_amd/debug.py)
         results = self.panoptic_fusion_head.predict(cls, masks, batch_data_samples, rescale=rescale)
         for s, r in zip(batch_data_samples, results):       # maskformer.py:112-152
             if 'ins_results' in r:
@@ -614,7 +616,7 @@ class SAMSegMask2Former(BaseDetectorHIP):
         """maskformer.py:83-151."""
         x = self.extract_feat(batch_inputs)
         cls, masks = self.panoptic_head.predict(x, batch_data_samples)
-        self._last_head_out = (cls, masks)
+        self._last_head_out = debug.keep((cls, masks))
         results = self.panoptic_fusion_head.predict(cls, masks, batch_data_samples, rescale=rescale)
         for s, r in zip(batch_data_samples, results):
             if 'ins_results' in r:

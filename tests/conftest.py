@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    # the parity tests read intermediate tensors the predict path only keeps on request (rsprompter_amd/debug.py)
+    import rsprompter_amd.debug as dbg
+    dbg.KEEP_TRACES = True
 
 
 @pytest.fixture(scope='session')

@@ -49,40 +49,88 @@ def _samples(metas):
     return [DetDataSample(metainfo=dict(m)) for m in metas]
 
 
-def _check_query(model, oracle, imgs, metas, dev, tag):
+def _fp64_trace(oracle, x, metas):
+    """the oracle with every parameter / buffer / input in fp64: the function the reference's fp32 forward approximates"""
+    import copy
+    o64 = copy.deepcopy(oracle).double()
+    torch.set_default_dtype(torch.float64)          # glue helpers that create tensors follow the default dtype
+    try:
+        _, tr = o64.predict(x.double(), metas)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    return tr
+
+
+def _mask_flips(masks_a, masks_b, n_img):
+    """attention-mask decisions that differ, per decoder layer, and the queries they touch ([n_img, Nq] bool)"""
+    flips, touched = [], None
+    for a, b in zip(masks_a, masks_b):
+        nq = a.shape[-2]
+        ref_m = b.cpu().bool().view(n_img, -1, nq, b.shape[-1])[:, 0]
+        diff = a.cpu().bool().view(n_img, -1, nq, a.shape[-1])[:, 0] != ref_m
+        flips.append(int(diff.sum()))
+        touched = diff.any(-1) if touched is None else (touched | diff.any(-1))
+    return flips, touched
+
+
+def _check_query(model, oracle, imgs, metas, dev, tag, fp64_floor=False):
+    """fp64_floor: also run the oracle in fp64 and hold the HIP path to the floor the reference's OWN fp32 forward shows
+    against it (tools/parity_fp64_study.py, profiles/r3_parity_fp64_study_config4.json: on the configs[4] fixture the
+    fp32 reference differs from fp64 in 3 of 1.08 M attention-mask decisions, 3 queries touched, 1.38e-3 on those, 6e-5 on
+    all others): the masked decoder thresholds its auxiliary masks (sigmoid < 0.5, models.py:390), a logit within round-off
+    of 0 lands on either side, and a query that attends one key more or fewer moves by > 1e-3 -- for the reference too."""
     from oracle import glue
     x = glue.data_preprocess(imgs, MEAN, STD, True, 32)
     ref, tr = oracle.predict(x, metas)
     out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
+    n_img = len(imgs)
     # ---- free-running logits of EVERY query (no selection involved): SAM mask logits and class logits
     cls, lazy = model._last_head_out
-    e_mask = _maxerr(lazy.low_res, tr['mask_pred'])
+    ours = lazy.low_res.detach().float().cpu()
+    e_mask = _maxerr(ours, tr['mask_pred'])
     e_cls = _maxerr(cls, tr['cls_pred'])
     rng = float(tr['mask_pred'].abs().max())
-    print(f'{tag}: free-running SAM mask logits err {e_mask:.2e} (range {rng:.1f}), class logits err {e_cls:.2e}')
-    # per-query view + the discrete decisions upstream of the logits (models.py:381-392: attn_mask = sigmoid < 0.5)
-    per_q = (lazy.low_res.detach().float().cpu() - tr['mask_pred']).abs().flatten(2).amax(2)          # [B, Nq]
-    flips, flipped_q = [], torch.zeros_like(per_q, dtype=torch.bool)
-    for a, b in zip(model.panoptic_head._last_trace['attn_masks'], tr['attn_masks']):
-        nq = a.shape[-2]
-        ref_m = b.view(len(imgs), -1, nq, b.shape[-1])[:, 0]
-        diff = a.cpu().bool().view_as(ref_m) != ref_m
-        flips.append(int(diff.sum()))
-        flipped_q |= diff.any(-1)
+    print(f'{tag}: free-running SAM mask logits err {e_mask:.2e} (range {rng:.1f}), class logits err {e_cls:.2e} vs the fp32 oracle')
+    per_q = (ours - tr['mask_pred']).abs().flatten(2).amax(2)                                       # [B, Nq]
+    trace = model.panoptic_head._last_trace
+    flips, flipped_q = _mask_flips(trace['attn_masks'], tr['attn_masks'], n_img)
     top = per_q.flatten().topk(5).values.tolist()
-    print(f'{tag}: attention-mask bits that differ from the oracle per decoder layer: {flips} '
+    print(f'{tag}: attention-mask bits that differ from the fp32 oracle per decoder layer: {flips} '
           f'({int(flipped_q.sum())} queries touched); 5 largest per-query logit errors: {["%.2e" % v for v in top]}; '
           f'median {float(per_q.median()):.2e}')
-    # The masked decoder thresholds its auxiliary masks (sigmoid < 0.5 <=> logit < 0, models.py:390): a logit within the
-    # round-off of 0 lands on the other side -- a DISCRETE difference like a score tie in the anchor path.  How many:
-    # Nq x keys x layers = 100 x ~4300 x 6 = 2.6 M decisions per image, logits spread over +-5 (density ~0.1 per unit near
-    # 0), auxiliary-mask error ~2e-5 -> an expectation of ~5 differing bits (measured 4 and 5 on two runs of the ViT-H +
-    # LoRA fixture; 0-1 on the others).  The bound is the 99.9 % quantile of that Poisson count, not the observed value.
-    # A query whose attention mask differs in some layer attends one more / one fewer key, which moves its logits by more
-    # than round-off: such queries are held to 1e-2, every other query to the 1e-3 budget.
-    assert int(flipped_q.sum()) <= 12 and sum(flips) <= 14
-    assert float(per_q[~flipped_q].max()) < LOGIT_TOL and e_cls < LOGIT_TOL
-    assert float(per_q.max()) < 1e-2
+    if not fp64_floor:
+        # no decision may differ by more than the handful round-off explains (0-1 observed on these fixtures); queries
+        # with identical masks are held to the 1e-3 budget, a touched one to 1e-2
+        assert int(flipped_q.sum()) <= 4 and sum(flips) <= 6
+        assert float(per_q[~flipped_q].max()) < LOGIT_TOL and e_cls < LOGIT_TOL
+        assert float(per_q.max()) < 1e-2
+    else:
+        t64 = _fp64_trace(oracle, x, metas)
+        m64 = t64['mask_pred']
+        # (1) the reference's own fp32 forward against fp64 -- the floor, measured on this box
+        ref_flips, ref_touched = _mask_flips(tr['attn_masks'], t64['attn_masks'], n_img)
+        ref_pq = (tr['mask_pred'].double() - m64).abs().flatten(2).amax(2)
+        ref_aux = float((tr['mask_pred_plus_all'][0].double() - t64['mask_pred_plus_all'][0]).abs().max())
+        # (2) the HIP path against fp64
+        our_flips, our_touched = _mask_flips(trace['attn_masks'], t64['attn_masks'], n_img)
+        our_pq = (ours.double() - m64).abs().flatten(2).amax(2)
+        our_aux = float((trace['mask_pred_plus'][0].detach().cpu().double().reshape(t64['mask_pred_plus_all'][0].shape)
+                         - t64['mask_pred_plus_all'][0]).abs().max())
+        our_cls = float((cls.detach().cpu().double() - t64['cls_pred']).abs().max())
+        print(f'{tag}: vs the fp64 forward -- reference fp32: {sum(ref_flips)} decisions differ ({int(ref_touched.sum())} queries), '
+              f'worst touched {float(ref_pq[ref_touched].max()) if ref_touched.any() else 0.0:.2e}, worst untouched '
+              f'{float(ref_pq[~ref_touched].max()):.2e}, first auxiliary mask {ref_aux:.2e};  HIP: {sum(our_flips)} decisions '
+              f'({int(our_touched.sum())} queries), worst touched {float(our_pq[our_touched].max()) if our_touched.any() else 0.0:.2e}, '
+              f'worst untouched {float(our_pq[~our_touched].max()):.2e}, first auxiliary mask {our_aux:.2e}')
+        # the error that decides how many logits sit on the wrong side of 0 is in the reference's own class ...
+        assert our_aux <= 2.0 * ref_aux + 1e-5, (our_aux, ref_aux)
+        # ... hence so is the count: Poisson with about the reference's own mean (2x + 6 covers the 99.9 % quantile for
+        # means up to 10 and the one-sample estimate of the mean)
+        assert sum(our_flips) <= 2 * sum(ref_flips) + 6 and int(our_touched.sum()) <= 2 * int(ref_touched.sum()) + 6
+        # queries whose masks equal the fp64 run's in every layer: the north-star 1e-3, strictly; touched ones move by
+        # what one key more or fewer does (1.4e-3 for the reference itself on this fixture): 1e-2
+        assert float(our_pq[~our_touched].max()) < LOGIT_TOL and our_cls < LOGIT_TOL
+        assert float(our_pq.max()) < 1e-2
     for b in range(len(imgs)):
         pi, r = out[b].pred_instances, ref[b]
         assert pi.masks.dtype == torch.bool and tuple(pi.masks.shape) == tuple(r['masks'].shape)
@@ -125,7 +173,7 @@ def test_config4_query_vith_lora_nq100_whu(dev):
     assert any('lora_B.default' in k for k in model.state_dict())
     imgs = synth_images(1, seed=77)
     metas = synth_metas(1, ori_shape=(512, 512), scale_factor=(2.0, 2.0))
-    _check_query(model, oracle, imgs, metas, dev, 'configs[4] query ViT-H+LoRA')
+    _check_query(model, oracle, imgs, metas, dev, 'configs[4] query ViT-H+LoRA', fp64_floor=True)
 
 
 def test_query_nwpu_peft512_config(dev):
@@ -176,6 +224,77 @@ def test_config3_anchor_vith_batch2(dev):
     e_emb = _maxerr(model._last_embeddings, tr['image_embeddings'])
     print(f'configs[3]: image embedding err {e_emb:.2e}, worst matched mask-logit err {worst:.2e}')
     assert e_emb < LOGIT_TOL
+
+
+def test_config3_anchor_vith_bench_batch8(dev):
+    """The bench's own batch (bench.py default: rsprompter_anchor SAM ViT-H, 8 tiles per step, 800 prompt sets through
+    the SAM decoder): images 0, 3 and 7 of the free-running batch-8 step against the oracle run on those three tiles
+    (images are independent; the oracle cost is 3 tiles).  Round 1's ViT-H bench ran on NaN neck rows unnoticed because
+    no test looked at this configuration at this batch."""
+    from oracle import glue
+    from oracle.anchor import AnchorOracle
+    from rsprompter_amd.default_configs import rsprompter_anchor
+    from rsprompter_amd.synth import synth_images, synth_metas
+    B, pick = 8, [0, 3, 7]
+    oracle = AnchorOracle('huge', 10)
+    model = _build(rsprompter_anchor('huge', 10), oracle, dev)
+    imgs, metas = synth_images(B, seed=1234), synth_metas(B)
+    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
+    low = model.roi_head._last_mask_trace['mask_preds'].cpu()                # [sum k, 1, 256, 256], image-major
+    emb = model._last_embeddings.cpu()
+    ks = [int(o.pred_instances.labels.shape[0]) for o in out]
+    assert low.shape[0] == sum(ks) and bool(torch.isfinite(low).all()) and bool(torch.isfinite(emb).all())
+    x = glue.data_preprocess([imgs[b] for b in pick], MEAN, STD, True, 32)
+    ref, tr = oracle.predict(x, [metas[b] for b in pick])
+    ref0 = 0
+    for n, b in enumerate(pick):
+        pi, r = out[b].pred_instances, ref[n]
+        k = r['labels'].shape[0]
+        assert pi.labels.shape[0] == k
+        pairs = match_detections(pi.bboxes, pi.scores, pi.labels, r['bboxes'], r['scores'], r['labels'])
+        ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
+        o0 = sum(ks[:b])
+        e_low = _maxerr(low[o0 + ii], tr['low_res_masks'][ref0 + jj])
+        e_emb = _maxerr(emb[b], tr['image_embeddings'][n])
+        mism = float((pi.masks.cpu()[ii] != r['masks'][jj]).float().mean())
+        print(f'bench batch (anchor ViT-H, 8 tiles) img {b}: {k} dets, {len(pairs)} matched, low_res_masks err {e_low:.2e}, '
+              f'embedding err {e_emb:.2e}, mask pixel mismatch {mism:.2e}')
+        assert e_low < LOGIT_TOL and e_emb < LOGIT_TOL and mism < 1e-3
+        ref0 += k
+
+
+def test_config2_query_vitl_batch16_r1600(dev):
+    """BASELINE.json configs[2] at its own batch: 16 tiles x 100 queries = 1600 prompt sets through the two-way decoder
+    in ONE step; images 0 and 15 against the oracle run on those two tiles."""
+    from oracle import glue
+    from oracle.query import QueryOracle
+    from rsprompter_amd.default_configs import rsprompter_query
+    from rsprompter_amd.synth import synth_images, synth_metas
+    B, pick = 16, [0, 15]
+    oracle = QueryOracle('large', 1, 100, max_per_image=100)
+    model = _build(rsprompter_query('large', 1, (100, 5)), oracle, dev)
+    imgs = synth_images(B, seed=31)
+    metas = synth_metas(B, ori_shape=(512, 512), scale_factor=(2.0, 2.0))
+    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
+    cls, lazy = model._last_head_out
+    ours = lazy.low_res.detach().float().cpu()                               # [16, 100, 256, 256]
+    assert ours.shape[:2] == (B, 100) and bool(torch.isfinite(ours).all())
+    x = glue.data_preprocess([imgs[b] for b in pick], MEAN, STD, True, 32)
+    ref, tr = oracle.predict(x, [metas[b] for b in pick])
+    flips, touched = _mask_flips([m.view(B, -1, m.shape[-1])[pick] for m in model.panoptic_head._last_trace['attn_masks']],
+                                 tr['attn_masks'], len(pick))
+    per_q = (ours[pick] - tr['mask_pred']).abs().flatten(2).amax(2)
+    e_cls = _maxerr(cls[pick], tr['cls_pred'])
+    print(f'configs[2] at batch 16 (R = 1600), images {pick}: SAM mask logits err {float(per_q.max()):.2e} '
+          f'(untouched queries {float(per_q[~touched].max()):.2e}), class logits {e_cls:.2e}, attention-mask decisions that '
+          f'differ {flips}')
+    assert sum(flips) <= 6 and float(per_q[~touched].max()) < LOGIT_TOL and e_cls < LOGIT_TOL and float(per_q.max()) < 1e-2
+    for n, b in enumerate(pick):
+        pi, r = out[b].pred_instances, ref[n]
+        same = pi.query_indices.cpu().long() == r['query_indices']
+        assert int((~same).sum()) <= 4
+        mism = float((pi.masks.cpu()[same] != r['masks'][same]).float().mean())
+        assert mism < 1e-3
 
 
 def test_encoder_batch8_row_maps(dev):

@@ -47,14 +47,22 @@ def check():
     def run(name, fn):
         nonlocal ok_all
         ref = fn(0)
-        got = fn(S2)
-        torch.cuda.synchronize()
-        ok = same(ref, got)
-        if not ok and not isinstance(ref, (tuple, ops.Planes)):
-            bad = (ref != got)
-            print(f'   first mismatches at {bad.nonzero()[:4].tolist()}  max abs diff {float((ref - got).abs().max()):.3e}')
-        print(f'{"OK  " if ok else "FAIL"} {name}', flush=True)
-        ok_all &= ok
+        for tag, h in (('specialised', S2), ('generic', S2 + 64), ('specialised + epilogue priority', S2 + 1)):
+            try:
+                got = fn(h)
+            except RuntimeError:
+                continue                                   # that variant is not instantiated for this epilogue
+            torch.cuda.synchronize()
+            ok = same(ref, got)
+            if not ok:
+                flat = lambda o: [o] if isinstance(o, torch.Tensor) else ([o.hi, o.lo] if isinstance(o, ops.Planes) else sum([flat(x) for x in o], []))
+                for n_, (a_, b_) in enumerate(zip(flat(ref), flat(got))):
+                    bad = (a_ != b_)
+                    if bool(bad.any()):
+                        print(f'   part {n_} {tuple(a_.shape)}: {int(bad.sum())} of {bad.numel()} differ, first at '
+                              f'{bad.nonzero()[:3].tolist()}, ref {a_[bad][:3].tolist()} got {b_[bad][:3].tolist()}')
+            print(f'{"OK  " if ok else "FAIL"} {name} [{tag}]', flush=True)
+            ok_all &= ok
 
     # (a) plain, ragged M and N (N % 4 == 0), short K
     for (M, N, K) in [(1000, 384, 256), (257, 132, 64), (5000, 1280, 1280), (300, 64, 128), (256, 128, 96 + 32)]:
@@ -138,17 +146,21 @@ def time_all():
             (Mg, MLP, D, lambda h: ops.gemm(xg, w_lin1, act=ops.ACT_GELU, out_planes=True, out_f32=False, tile_hint=h)),
         'lin2 M=32768 N=1280 K=5120 +res': (Mg, D, MLP, lambda h: ops.gemm(xm, w_lin2, out=o_x, res=res, tile_hint=h)),
     }
-    variants = [('r2 auto', 0), ('r2 256x256', 17), ('s2', S2), ('s2 prio(hwid)', S2 + 1), ('s2 g4', S2 | 4 << 8),
-                ('s2 noDMA*', S2 + 4), ('s2 noEpi*', S2 + 8), ('s2 hotDMA*', S2 + 16), ('s2 trace', S2 + 32)]
+    variants = [('r2 auto', 0), ('r2 256x256', 17), ('s2', S2), ('s2 generic-epi', S2 + 64),
+                ('s2 epi-prio', S2 + 1), ('s2 noDMA*', S2 + 4), ('s2 noEpi*', S2 + 8), ('s2 hotDMA*', S2 + 16)]
+    only = {'qkv_window': ('r2 auto', 'r2 256x256', 's2', 's2 generic-epi', 's2 epi-prio'),
+            'qkv_global': ('r2 auto', 'r2 256x256', 's2', 's2 generic-epi', 's2 epi-prio')}   # variants exist for proj / lin shapes
     for name, (M, N, K, fn) in cases.items():
-        ms = timed_rounds({vn: (lambda h=h: fn(h)) for vn, h in variants})
+        vs = [(vn, h) for vn, h in variants if name.split(' ')[0] not in only or vn in only[name.split(' ')[0]]]
+        ms = timed_rounds({vn: (lambda h=h: fn(h)) for vn, h in vs})
         print(name + ':  ' + '  '.join(f'[{vn}] {t:.3f} ms {2.0 * M * N * K / t / 1e9:.0f}' for vn, t in ms.items()), flush=True)
     # long-K square: main loop only
     n = 8192
     a = ops.to_planes(torch.randn(n, n, device=dev))
     w = mk(n, n, bias=False)
     o = torch.empty(n, n, device=dev)
-    ms = timed_rounds({vn: (lambda h=h: ops.gemm(a, w, out=o, tile_hint=h)) for vn, h in variants}, rounds=3, iters=2)
+    vs = [(vn, h) for vn, h in variants if vn in ('r2 auto', 'r2 256x256', 's2', 's2 epi-prio')]     # plain epilogue: no variants
+    ms = timed_rounds({vn: (lambda h=h: ops.gemm(a, w, out=o, tile_hint=h)) for vn, h in vs}, rounds=3, iters=2)
     print('8192^3:  ' + '  '.join(f'[{vn}] {t:.3f} ms {2.0 * n ** 3 / t / 1e9:.0f}' for vn, t in ms.items()), flush=True)
 
 
@@ -211,7 +223,7 @@ def trace(hint=S2 + 32, shape='lin1'):
 if __name__ == '__main__':
     what = sys.argv[1] if len(sys.argv) > 1 else 'both'
     if what == 'trace':
-        trace(S2 + 32, 'lin1'); trace(S2 + 33, 'lin1'); trace(S2 + 32, 'proj')
+        trace(S2 + 32, 'lin1'); trace(S2 + 33, 'lin1'); trace(S2 + 33, 'proj')
         sys.exit(0)
     if what in ('check', 'both'):
         if not check() and what == 'both':
