@@ -309,9 +309,12 @@ def main():
                 d0['ms'] += v['ms']; d0['flops'] += v['flops']; d0['calls'] += v['calls']
         dom_name, dom = max(fam.items(), key=lambda kv: kv[1]['ms'])
         achieved = dom['flops'] / dom['ms'] / 1e9
-        attn = [v for k, v in agg.items() if k.startswith('attn_kernel<vit') or k.startswith('attn_global_kernel')]
+        attn = [v for k, v in agg.items() if k.startswith('attn_stream_kernel<vit') or k.startswith('attn_kernel<vit') or
+                k.startswith('attn_global_kernel')]
         attn_ms = sum(v['ms'] for v in attn)
         attn_tf = sum(v['flops'] for v in attn) / attn_ms / 1e9 if attn_ms else None
+        relpos_ms = sum(v['ms'] for k, v in agg.items() if k.startswith('vit_relpos'))
+        attn_tf_rel = sum(v['flops'] for v in attn) / (attn_ms + relpos_ms) / 1e9 if attn_ms else None
         value = world * B * args.steps / elapsed
         result = {
             'metric': 'images/sec (1024x1024 synthetic tiles, rsprompter_%s SAM-ViT-%s, full predict path)' % (args.model, args.arch[0].upper()),
@@ -334,7 +337,10 @@ def main():
                                  'FLOP (fp16x3), so its ceiling is peak/3 = 833 TFLOP/s'
                                  + (' (gemm_f16f8: 2 fp16 + 1 fp8 K=64 MFMA per 32 k = 2 units of matrix time, ceiling peak/2)' if args.f8corr else ''),
                          'frac_of_fp16x3_ceiling': round(achieved / (PEAK_F16_MFMA_TFLOPS / 3), 4)},
-            'roofline_attention': {'bound': 'mfma', 'kernel': 'attn_kernel<vit>', 'achieved': None if attn_tf is None else round(attn_tf, 2),
+            'roofline_attention': {'bound': 'mfma', 'kernel': 'attn_stream_kernel (window + global layers)',
+                                   'achieved': None if attn_tf is None else round(attn_tf, 2),
+                                   'achieved_incl_relpos_kernels': None if attn_tf_rel is None else round(attn_tf_rel, 2),
+                                   'ms_per_step': round(attn_ms, 3), 'relpos_ms_per_step': round(relpos_ms, 3),
                                    'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                    'frac': None if attn_tf is None else round(attn_tf / PEAK_F16_MFMA_TFLOPS, 4),
                                    'attention_gemm_gflop_per_image': ATTN_GEMM_GFLOP_PER_IMAGE[args.arch]},

@@ -149,6 +149,9 @@ typedef struct RspGemmDesc {
 } RspGemmDesc;
 
 int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream);
+/* 1 when rsp_gemm serves this descriptor with the two-blocks-per-CU persistent kernel (csrc/gemm_s2.hip), 0 when with   */
+/* one of the csrc/gemm_dma.hip / gemm.hip tiles (profiler labels; no device work)                                       */
+int rsp_gemm_uses_s2(const RspGemmDesc* desc);
 
 /* ------------------------------------------------------------------------ */
 /* LayerNorm over the last dim of a [rows, C] matrix (C % 4 == 0, C <= 2048). */

@@ -670,6 +670,7 @@ int launch_dma(const RspGemmDesc& d, hipStream_t s) {
 }  // namespace
 
 bool rsp_gemm_s2_eligible(const RspGemmDesc& d);                       // gemm_s2.hip
+int rsp_gemm_s2_auto(const RspGemmDesc& d);
 int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s);
 
 // called from rsp_gemm (gemm.hip) when the descriptor carries A planes
@@ -680,6 +681,9 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
     if (!rsp_gemm_s2_eligible(d)) return RSP_EINVAL;
     return rsp_gemm_s2_dispatch(d, (d.tile_hint & 0xff) - 40, s);
   }
+  // product rule (round 3): the two-blocks-per-CU persistent kernel wherever it has a specialised epilogue -- 7-20 %
+  // faster than the kernels below on the ViT-H encoder shapes (tools/gemm_s2_exp.py).  Tile hint 1 = "the round-2 rule".
+  if ((d.tile_hint & 0xff) == 0 && rsp_gemm_s2_auto(d)) return rsp_gemm_s2_dispatch(d, 0, s);
   if (d.ct_W > 0 && (d.res || d.res_hi)) return RSP_EINVAL;   // no caller needs a residual on a ConvTranspose
   if (d.res_hi && (!d.res_lo || d.res || d.res_rows <= 0 || (d.N & 3))) return RSP_EINVAL;
   if (d.hd_out && (!d.hd_hyper || d.ct_W <= 0 || d.N != (d.ct_dy < 0 ? 128 : 64) || d.hd_rows <= 0)) return RSP_EINVAL;
@@ -699,14 +703,14 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   // Tile rule (tools/gemm_sweep.py on MI355X; run-to-run spread is a few %): the register-pipelined loops win
   // everywhere; 256x256 needs >= 4 rounds of blocks over the 256 CUs, 256x128 >= 2, else 128x128 (2 blocks/CU).
   if (d.conv_k != 0) {   // implicit-GEMM convolutions: CONV instantiations of the same kernels
-    if (d.N > 128 && ((d.tile_hint & 0xff) == 17 || ((d.tile_hint & 0xff) == 0 && nblk(256, 256) >= 1024)))
+    if (d.N > 128 && ((d.tile_hint & 0xff) == 17 || ((d.tile_hint & 0xff) <= 1 && nblk(256, 256) >= 1024)))
       return launch_dma<256, 256, 2, 4, 2, 0, 0, 2, true>(d, s);
     if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 0, 0, 1, true>(d, s);
     if (d.N > 32) return launch_dma<128, 64, 2, 2, 3, 0, 0, 0, true>(d, s);
     return launch_dma<128, 32, 4, 1, 3, 0, 0, 0, true>(d, s);
   }
   int tile = d.tile_hint & 0xff;
-  if (tile == 0) {
+  if (tile <= 1) {
     // short K (<= 8 K tiles): the block is mostly prologue + epilogue, two 128x128 blocks per CU overlap them
     // (round 2, tools/gemm_sweep.py on the SAM-decoder shapes M = 3.3 M rows: with N = 256 the 256x256 tile reads every A
     // row once instead of twice and is 7-14 % faster even at 4-8 K tiles; N = 128 stays with 128x128)
@@ -732,7 +736,7 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (f8) {   // fp8-corrected product: the three tiles the rule above picks
     // with a third less matrix time per tile the big tile already pays from two rounds of blocks on, also at K = 1280
     // (proj shape, tools/gemm_f8_exp.py: 337 vs 301 TFLOP/s)
-    if ((d.tile_hint & 0xff) == 0 && d.N > 128 && nblk(256, 256) >= 512) tile = 17;
+    if ((d.tile_hint & 0xff) <= 1 && d.N > 128 && nblk(256, 256) >= 512) tile = 17;
     if (tile == 17 && d.N > 128) return launch_dma<256, 256, 2, 4, 2, 0, 0, 2, false, 0, true>(d, s);
     if ((tile == 18 || tile == 17) && d.N > 64) return launch_dma<256, 128, 4, 2, 2, 0, 0, 2, false, 0, true>(d, s);
     return launch_dma<128, 128, 2, 2, 2, 0, 0, 1, false, 0, true>(d, s);
@@ -766,4 +770,13 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 0, 0, 1>(d, s);
   if (d.N > 32) return launch_dma<128, 64, 2, 2, 3>(d, s);
   return launch_dma<128, 32, 4, 1, 3>(d, s);
+}
+
+// which kernel rsp_gemm runs for a descriptor of the plane path (profiler labels, tools): 1 = gemm_s2 (two blocks per
+// CU, 256 x 128), 0 = one of this file's tiles
+extern "C" int rsp_gemm_uses_s2(const RspGemmDesc* d) {
+  if (!d || !(d->Ahi && d->Alo)) return 0;
+  const int h = d->tile_hint & 0xff;
+  if (h >= 40 && h < 168) return 1;
+  return h == 0 && rsp_gemm_s2_auto(*d);
 }

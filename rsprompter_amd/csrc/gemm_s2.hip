@@ -61,7 +61,7 @@ __device__ unsigned g_s2_tickets[TICKET_SLOTS * TICKET_WORDS];
 
 // epilogue specialisations (EPI template argument): bit flags of what the tile's outputs need; E_GENERIC = everything at
 // run time (all modes of the descriptor, slow: branches per 4 outputs)
-constexpr int E_RES = 1, E_GELU = 2, E_C = 4, E_PL = 8, E_GENERIC = 64;
+constexpr int E_RES = 1, E_GELU = 2, E_C = 4, E_PL = 8, E_RMAP = 16, E_GENERIC = 64;
 
 template <int I, int N, class F>
 __device__ __forceinline__ void sfor(F&& f) {
@@ -353,70 +353,68 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
     } else {
       // Specialised form.  Host guarantees: N, c_ncols, pl_col0 multiples of 64 (a wave's 64 columns are all fp32
       // output, all plane output, or both), act in {none, GELU per E_GELU}, no plane residual, no cat8 output, every
-      // tensor the epilogue touches < 2^31 bytes.  It is BRANCH-FREE: all memory operations are buffer operations --
-      // a row that is not stored (beyond M, c_rowmap < 0) carries an offset beyond the descriptor's range (stores are
-      // dropped, loads return 0), an absent bias / row map is a descriptor of 0 bytes.  Straight-line code lets hipcc
-      // count its waits (s_waitcnt vmcnt(N)), and vmcnt retires in order and counts stores, so ORDER matters: bias,
-      // destination rows and the next tile's source rows are loaded in one batch; the residual of row group i + 1 is
-      // requested BEFORE row group i is stored (waiting for it never waits for stores); the next tile's DMA is queued
-      // once no loaded value is pending (hipcc answers any use of a loaded value with vmcnt(0) while an LDS-DMA is in
-      // flight), i.e. before the stores of the last row group -- or, without a residual, before the whole epilogue.
+      // tensor the epilogue touches < 2^31 bytes.
+      //   * The accumulators hold one output ROW per lane: stored as they are, every store / residual load instruction
+      //     touches 32 rows with 16-32 bytes each (measured: the stores of a GELU + plane epilogue cost 10 % of the
+      //     GEMM, the residual loads of the proj epilogue 16 %).  Each wave therefore turns its tile by 90 degrees
+      //     through a PRIVATE 8 KB piece of the (now idle) ring, 32 rows at a time: ds_write_b128 of the quads, XOR
+      //     swizzle of the 16-byte unit with row & 7 (conflict free both ways), read back with 16 lanes per row -- a wave
+      //     instruction then moves 4 rows x 256 contiguous bytes (fp32) or 2 x 256 contiguous bytes (a plane).  No
+      //     block barrier is involved: one wave's LDS operations execute in order.
+      //   * BRANCH-FREE: all memory operations are buffer operations -- a row that is not stored (beyond M,
+      //     c_rowmap < 0) carries an offset beyond the descriptor's range (stores are dropped, loads return 0), an absent
+      //     bias / row map is a descriptor of 0 bytes.  Straight-line code lets hipcc count its waits, and vmcnt retires
+      //     in order and counts stores, so ORDER matters: the destination rows and the residual of row group i + 1 are
+      //     requested BEFORE row group i is stored (waiting for them never waits for stores).
+      //   * The next tile's DMA is queued once every wave has read its last piece back (one barrier) and no loaded
+      //     value is pending (hipcc answers any use of a loaded value with vmcnt(0) while an LDS-DMA is in flight).
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      constexpr int NG = 8;                                   // read-back groups per 32-row pass: 4 rows x 64 columns
       const float alpha = d.alpha;
       const float cs = (EPI & E_PL) ? ldexpf(1.0f, RSP_PLANE_EXP(d.c_scale_log2)) : 1.0f;
       const int cols0 = done.n0 + wn * 64;                    // scalar: first column of this wave
       const bool active = cols0 < N;                          // N % 64 == 0: all 64 columns or none
       const bool do_c = (EPI & E_C) && active && (d.c_ncols <= 0 || cols0 < d.c_ncols);
       const bool do_p = (EPI & E_PL) && active && cols0 >= d.pl_col0;
-      const int lane_c = 4 * hh;                              // + j * 32 + 8 * q: this lane's first column of a quad
+      const int lr0 = lane >> 4, c4 = (lane & 15) * 4;        // read-back mapping: row g * 4 + lr0, columns c4 .. c4 + 3
+      unsigned char* const et = smem + wave * (32 * 256);     // this wave's transposition piece
+      const int wr_off = l31 * 256;                           // write side: row l31, unit (j*8 + 2q + hh) ^ (l31 & 7)
+      const int rd_off = lr0 * 256;                           // read side: row g*4 + lr0, unit (c4 / 4) ^ (row & 7)
       const auto rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.bias), 0, d.bias ? N * 4 : 0, 0x00020000);
-      f32x4 bias4[TN][4];
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          bias4[j][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, (lane_c + j * 32 + 8 * q) * 4, cols0 * 4, 0));
+      const f32x4 bias4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rB, (cols0 + c4) * 4, 0, 0));
       const auto rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<int32_t*>(d.c_rowmap), 0, d.c_rowmap ? M * 4 : 0, 0x00020000);
-      int crow[TM];                                           // destination row of this lane per row group, -1: none
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int row = done.m0 + wm * 128 + i * 32 + l31;
-        const int mapped = (int)__builtin_amdgcn_raw_buffer_load_b32(rM, row * 4, 0, 0);
-        crow[i] = row < M ? (d.c_rowmap ? mapped : row) : -1;
-      }
-      if (more) cur = tile_setup(id);                         // (its row-map loads join the batch)
-      if constexpr (!(EPI & E_RES)) queue_next();
-      // phase 1, in place: acc <- act(acc * alpha + bias)  (then the 32 bias registers are free for the residual)
-      sfor<0, TM>([&](auto ic) {
-        constexpr int i = decltype(ic)::value;
-        sfor<0, TN * 4>([&](auto jqc) {
-          constexpr int jq = decltype(jqc)::value, j = jq / 4, q = jq % 4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float t = acc[i][j][4 * q + e] * alpha + bias4[j][q][e];
-            acc[i][j][4 * q + e] = (EPI & E_GELU) ? rsp_gelu(t) : t;
-          }
-        });
-      });
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));     // keep the phases apart (register pressure)
-      // phase 2: residual (requested one row group ahead, before the previous group's stores) and stores
       const auto rR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(d.res), 0, (EPI & E_RES) ? 0x7fffffff : 0, 0x00020000);
-      f32x4 rv[2][TN * 4];
+      const int row_w = done.m0 + wm * 128 + lr0;             // + i * 32 + g * 4
+      // destination rows: without a row map (E_RMAP clear) plain arithmetic; with one, ALL of the tile's are requested
+      // up front (32 registers): a request issued between two passes would be waited for behind the previous pass's
+      // stores
+      int crow_m[(EPI & E_RMAP) ? TM : 1][NG];
+      if constexpr (EPI & E_RMAP) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int g = 0; g < NG; ++g)
+            crow_m[i][g] = (int)__builtin_amdgcn_raw_buffer_load_b32(rM, (row_w + i * 32 + g * 4) * 4, 0, 0);
+      }
+      auto crow_of = [&](auto ic, int g) -> int {             // -1: nothing stored for this row
+        constexpr int i = decltype(ic)::value;
+        const int row = row_w + i * 32 + g * 4;
+        if constexpr (EPI & E_RMAP) return row < M ? crow_m[i][g] : -1;
+        else return row < M ? row : -1;
+      };
+      f32x4 rv[2][NG];
       auto res_load = [&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        const int crc = max(crow[i], 0);                      // rows that are not stored read row 0 (never used)
-        int rrow = crc;
-        if (d.res_mod > 0) rrow = crc - p.fd_resmod.div(crc) * d.res_mod;
-        const int ro = (rrow * d.ldr + lane_c) * 4;           // (gathered residual rows, res_bmap: generic path)
-        sfor<0, TN * 4>([&](auto jqc) {
-          constexpr int jq = decltype(jqc)::value;
-          rv[i & 1][jq] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, ro + ((jq / 4) * 32 + 8 * (jq % 4)) * 4, cols0 * 4, 0));
-        });
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int crc = max(crow_of(ic, g), 0);             // rows that are not stored read row 0 (never used)
+          int rrow = crc;
+          if (d.res_mod > 0) rrow = crc - p.fd_resmod.div(crc) * d.res_mod;
+          rv[i & 1][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rR, (rrow * d.ldr + cols0 + c4) * 4, 0, 0));
+        }
       };
+      if (more) cur = tile_setup(id);                         // (its row-map loads join the batch)
       if constexpr (EPI & E_RES) res_load(std::integral_constant<int, 0>{});
       // output descriptors: without a row map rows are relative to the tile (any tensor size), with one to the tensor
       const int64_t c_row0 = d.c_rowmap ? 0 : done.m0;
@@ -426,52 +424,72 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
       const int pl_bytes = do_p ? (int)(((int64_t)((N - d.pl_col0) >> 5) * d.c_rows) << 6) : 0;
       const auto rH = __builtin_amdgcn_make_buffer_rsrc(d.Chi, 0, pl_bytes, 0x00020000);
       const auto rL = __builtin_amdgcn_make_buffer_rsrc(d.Clo, 0, pl_bytes, 0x00020000);
-      const int pl_blk0 = (cols0 - d.pl_col0) >> 5;           // K block (of the plane tensor) of this wave's first column
+      // plane offset of this lane's 4 columns: K block (cols0 - pl_col0) / 32 + c4 / 32, 8 bytes at (c4 & 31) * 2
+      const int pl_lane = (((cols0 - d.pl_col0) >> 5) + (c4 >> 5)) * (d.c_rows << 6) + (c4 & 31) * 2;
       sfor<0, TM>([&](auto ic) {
         constexpr int i = decltype(ic)::value;
-        if constexpr ((EPI & E_RES) && i + 1 < TM) res_load(std::integral_constant<int, i + 1>{});
-        if constexpr (EPI & E_RES) {
-          sfor<0, TN * 4>([&](auto jqc) {
-            constexpr int jq = decltype(jqc)::value, j = jq / 4, q = jq % 4;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += rv[i & 1][jq][e];
-          });
-          if constexpr (i + 1 == TM) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(acc[i][j]));   // every loaded value consumed ...
-            queue_next();                                                        // ... before the DMA is queued
-          }
-        }
-        const int cr = crow[i];
-        // (no SGPR soffset on the 16-byte stores: with one, hipcc assumes the data registers may be overwritten by the
-        // very next VALU instruction, and the in-place plane split behind the store did overwrite them -- measured: a few
-        // fp32 outputs came out as value * plane scale)
-        const unsigned co = cr < 0 ? OOB : (unsigned)(((cr - (int)c_row0) * d.ldc + lane_c + cols0) * 4);
-        const unsigned po = cr < 0 ? OOB : (unsigned)(cr * 64 + lane_c * 2);
+        // (1) this pass's 32 x 64 accumulators -> LDS, row-major, swizzled
         sfor<0, TN * 4>([&](auto jqc) {
           constexpr int jq = decltype(jqc)::value, j = jq / 4, q = jq % 4;
           const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-          if constexpr ((EPI & E_C) && !(VAR & 2))
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rC, co + (j * 32 + 8 * q) * 4, 0, 0);
-          if constexpr ((EPI & E_C) && (VAR & 2)) asm volatile("" ::"v"(v));
+          *reinterpret_cast<f32x4*>(et + wr_off + (((j * 8 + 2 * q + hh) ^ (l31 & 7)) << 4)) = v;
+        });
+        // (3) read back: 4 rows x 64 columns per instruction
+        f32x4 x[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int lr = g * 4 + lr0;
+          x[g] = *reinterpret_cast<const f32x4*>(et + rd_off + g * 1024 + ((((c4 >> 2)) ^ (lr & 7)) << 4));
+        }
+        if constexpr (i + 1 == TM) {                          // every wave has its last piece: the ring is free
+          asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+          __builtin_amdgcn_s_waitcnt(WC_LGKM0);
+          __builtin_amdgcn_s_barrier();
+        }
+        // (4) value = act(acc * alpha + bias) + residual
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float t = x[g][e] * alpha + bias4[e];
+            x[g][e] = (EPI & E_GELU) ? rsp_gelu(t) : t;
+          }
+          if constexpr (EPI & E_RES) x[g] += rv[i & 1][g];
+        }
+        // (the residual of the NEXT pass is requested before this pass stores)
+        if constexpr (i + 1 < TM) {
+          if constexpr (EPI & E_RES) res_load(std::integral_constant<int, i + 1>{});
+        } else {
+          asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
+          queue_next();                                       // every loaded value has been consumed
+        }
+        // (5) stores
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+          const int cr = crow_of(ic, g);
+          if constexpr ((EPI & E_C) && !(VAR & 2)) {
+            const unsigned co = cr < 0 ? OOB : (unsigned)(((cr - (int)c_row0) * d.ldc + cols0 + c4) * 4);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x[g]), rC, co, 0, 0);
+          }
           if constexpr (EPI & E_PL) {
             half4_t h4, l4;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float x = v[e] * cs;
-              const float xh = __builtin_fminf(__builtin_fmaxf(x, -RSP_F16_MAX), RSP_F16_MAX);
-              h4[e] = (half_t)xh;
-              l4[e] = (half_t)__builtin_fminf(__builtin_fmaxf(x - (float)h4[e], -RSP_F16_MAX), RSP_F16_MAX);
+              const float y = x[g][e] * cs;
+              const float yh = __builtin_fminf(__builtin_fmaxf(y, -RSP_F16_MAX), RSP_F16_MAX);
+              h4[e] = (half_t)yh;
+              l4[e] = (half_t)__builtin_fminf(__builtin_fmaxf(y - (float)h4[e], -RSP_F16_MAX), RSP_F16_MAX);
             }
-            const int so = ((pl_blk0 + j) * d.c_rows) << 6;   // scalar: K block of this quad, bytes
             if constexpr (VAR & 2) {
               asm volatile("" ::"v"(h4), "v"(l4));
             } else {
-              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h4), rH, po + 16 * q, so, 0);
-              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l4), rL, po + 16 * q, so, 0);
+              const unsigned po = cr < 0 ? OOB : (unsigned)(cr * 64 + pl_lane);
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h4), rH, po, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l4), rL, po, 0, 0);
             }
           }
-        });
+          if constexpr ((EPI & E_C) && (VAR & 2)) asm volatile("" ::"v"(x[g]));
+        }
       });
     }
     if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
@@ -528,24 +546,42 @@ bool rsp_gemm_s2_eligible(const RspGemmDesc& d) {
   return true;
 }
 
-// var: experiment switches of the kernel (0 = product); the epilogue specialisation follows from the descriptor
-int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s) {
+// the epilogue specialisation that serves this descriptor (E_GENERIC: only the run-time form does)
+static int s2_epilogue_of(const RspGemmDesc& d) {
   // the branch-free epilogue addresses every tensor it touches with 32-bit buffer offsets
   const long long GB2 = 1LL << 31;
   const long long c_bytes = d.C ? (d.c_rowmap ? (long long)d.c_rows * d.ldc * 4 : 0) : 0;   // no row map: tile-relative
   const long long pl_bytes = d.Chi ? (((long long)((d.N - d.pl_col0) >> 5) * d.c_rows) << 6) : 0;
-  const long long res_bytes = d.res ? (long long)(d.res_mod > 0 ? d.res_mod : (d.res_bmap ? 0 : (d.c_rowmap ? d.c_rows : d.M))) * d.ldr * 4 : 0;
+  const long long res_bytes = d.res ? (long long)(d.res_mod > 0 ? d.res_mod : (d.c_rowmap ? d.c_rows : d.M)) * d.ldr * 4 : 0;
   const bool fast = !(d.N & 63) && !(d.c_ncols & 63) && !(d.pl_col0 & 63) && !d.res_hi &&
                     (d.act == RSP_ACT_NONE || d.act == RSP_ACT_GELU) && !(d.Chi && RSP_PLANE_IS_F8(d.c_scale_log2)) &&
                     !(d.c_rowmap && d.c_rows <= 0) && c_bytes < GB2 && pl_bytes < GB2 && res_bytes < GB2 &&
                     !(d.res && d.res_bmap) &&      /* gathered residual rows: size unknown here, generic path */
-                    (long long)256 * d.ldc * 4 < GB2 && !(var & 64);
-  const int epi = !fast ? E_GENERIC
-                        : (d.res ? E_RES : 0) | (d.act == RSP_ACT_GELU ? E_GELU : 0) | (d.C ? E_C : 0) | (d.Chi ? E_PL : 0);
+                    (long long)256 * d.ldc * 4 < GB2;
+  if (!fast) return E_GENERIC;
+  return (d.res ? E_RES : 0) | (d.act == RSP_ACT_GELU ? E_GELU : 0) | (d.C ? E_C : 0) | (d.Chi ? E_PL : 0) |
+         (d.c_rowmap ? E_RMAP : 0);
+}
+
+// 1: this kernel is the product choice for the descriptor (eligible, a specialised epilogue exists, enough tiles to fill
+// the 512 block slots once); 0: stay with gemm_dma.hip
+int rsp_gemm_s2_auto(const RspGemmDesc& d) {
+  if (!rsp_gemm_s2_eligible(d)) return 0;
+  const int e = s2_epilogue_of(d);
+  const bool have = e == E_C || e == (E_C | E_RES) || e == (E_C | E_RES | E_RMAP) || e == (E_C | E_PL) || e == E_PL ||
+                    e == (E_PL | E_GELU) || e == (E_C | E_GELU);
+  const long long nt = (long long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  return have && nt >= 256 && d.K >= 128;
+}
+
+// var: experiment switches of the kernel (0 = product); the epilogue specialisation follows from the descriptor
+int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s) {
+  const int epi = (var & 64) ? E_GENERIC : s2_epilogue_of(d);
   var &= 63;
 #define S2_CASE(V, E) if (var == V && epi == (E)) return launch_s2<V, (E)>(d, s)
   S2_CASE(0, E_C);                 // plain
-  S2_CASE(0, E_C | E_RES);         // proj, lin2, patch embed
+  S2_CASE(0, E_C | E_RES);         // proj (global layers), lin2, patch embed
+  S2_CASE(0, E_C | E_RES | E_RMAP); // proj of a windowed layer (row scatter)
   S2_CASE(0, E_C | E_PL);          // qkv (column ranges), fp32 + planes
   S2_CASE(0, E_PL);                // planes only
   S2_CASE(0, E_PL | E_GELU);       // lin1
@@ -561,6 +597,7 @@ int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s) {
   S2_CASE(1, E_C); S2_CASE(1, E_C | E_PL);
 #undef S2_CASE
   if (var != 0) return RSP_EINVAL;
+  if (epi & E_RMAP) return launch_s2<0, E_GENERIC>(d, s);
   return launch_s2<0, E_GENERIC>(d, s);       // any other combination of outputs
 }
 

@@ -153,6 +153,9 @@ class PackedWeight:
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
 
 
+# RSP_GEMM_RULE=r2: every GEMM by the round-2 tile rule (csrc/gemm_dma.hip) instead of the two-blocks-per-CU kernel
+# (csrc/gemm_s2.hip) -- A/B switch for tools and bench.py --gemm-r2; results are bit-identical either way
+GEMM_ROUND2_RULE = os.environ.get('RSP_GEMM_RULE', '') == 'r2'
 PLANE_F8 = 0x100        # include/rsp_hip.h "Plane format word"
 # Opt-in fast mode (RSP_F8CORR=1, or set ops.F8_CORR before the model is built / first run): the four big GEMMs of every
 # encoder block run fp16 hi.hi + ONE fp8 MFMA carrying both correction terms (2 units of matrix time instead of 3).
@@ -245,6 +248,8 @@ def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30, f8=False):
     nblk = lambda bm, bn: -(-n // bn) * -(-m // bm)
     small = '128x128' if n > 64 else ('128x64' if n > 32 else '128x32')
     hint &= 0xff
+    if hint == 1:
+        hint = 0                     # "the round-2 rule"
     if hint in (3, 9, 10, 11, 15, 17, 31):
         return '256x256'
     if hint in (2, 4, 12, 13, 16, 18, 19, 32):
@@ -349,7 +354,7 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.res_mod = res_mod
     d.res_bmap, d.res_brows = _ptr(res_bmap), res_brows
     d.b_rows = getattr(w, 'b_rows', 0)
-    d.tile_hint = tile_hint
+    d.tile_hint = tile_hint if (tile_hint or not GEMM_ROUND2_RULE) else 1
     if d.c_rows == 0:
         d.c_rows = rows          # also bounds C when rows are scattered (c_rowmap)
     d.act = act
@@ -357,6 +362,8 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
     tile = _dma_tile_name(m, n, tile_hint, conv is not None, w.K, w_f8) if is_planes else ('128x128' if n > 64 else ('128x64' if n > 32 else '128x32'))
     kname = ('gemm_f16f8_dma_kernel' if w_f8 else 'gemm_f16x3_dma_kernel') if is_planes else 'gemm_f16x3_kernel'
+    if is_planes and _prof is not None and _lib_real.load().rsp_gemm_uses_s2(d):
+        kname, tile = 'gemm_f16x3_s2_kernel', '256x128'         # the kernel rsp_gemm really launches (profiler label)
     _timed(f'{kname}<{tile}>', 2.0 * m * n * w.K, 4.0 * (m * w.K + m * n) + 4.0 * n * w.K,
            lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm"),
            detail=f'M={m} N={n} K={w.K}' + (' conv' if conv is not None else ''))
@@ -416,7 +423,7 @@ def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False, f8=Fals
     if kv.f8:
         raise ValueError('K | V planes are consumed as fp16 hi / lo planes (qkv GEMM: out_f8=False)')
     kind = 'global' if T >= 1024 else 'window'
-    _timed('attn_global_kernel<vit>' if kind == 'global' else 'attn_kernel<vit,window>', 4.0 * Bp * nh * T * T * dh, 0,
+    _timed(f'attn_stream_kernel<vit,{kind}>', 4.0 * Bp * nh * T * T * dh, 0,
            lambda: _lib.check(lib.rsp_vit_attention_planes(q.data_ptr(), q.stride(0), kv.hi.data_ptr(), kv.lo.data_ptr(),
                                                            kv.rows, kv.scale_log2, rel.data_ptr(), _ptr(out), hi, lo, e,
                                                            Bp, S, nh, dh, scale, _stream()),

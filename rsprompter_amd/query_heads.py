@@ -330,9 +330,9 @@ class _Mask2FormerCore(HIPModule):
             dec_kin.append(ops.add_rows(d, pos_tabs[i], vmod=pos_tabs[i].shape[0]))          # key + key_pos
         qf = self.query_feat.weight.detach().unsqueeze(0).expand(B, -1, -1).reshape(B * Nq, f).contiguous()
         qe = self.query_embed.weight.detach()
-        trace = dict(attn_masks=[], query_feats=[], mask_pred_plus=[], mask_features=mask_features, memory=mem)
+        trace = dict(attn_masks=[], query_feats=[], mask_pred_plus_all=[], mask_features=mask_features, memory=mem)
         dn, mpp = self._head_light(qf, mf_planes, B, H0 * W0)
-        trace['mask_pred_plus'].append(mpp)
+        trace['mask_pred_plus_all'].append(mpp)
         for i in range(self.num_transformer_decoder_layers):
             lvl = i % self.num_transformer_feat_level
             h, w = shapes[lvl]
@@ -350,7 +350,7 @@ class _Mask2FormerCore(HIPModule):
             qf = ops.layernorm(qf, _g(L, 'norms.2').weight, _g(L, 'norms.2').bias, 1e-5)
             trace['query_feats'].append(qf)
             dn, mpp = self._head_light(qf, mf_planes, B, H0 * W0)
-            trace['mask_pred_plus'].append(mpp)
+            trace['mask_pred_plus_all'].append(mpp)
         return dn, mpp.view(B, Nq, H0, W0), trace
 
 

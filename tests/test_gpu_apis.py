@@ -104,3 +104,79 @@ def test_inference_detector_on_real_image_matches_oracle(dev, tmp_path):
     p0 = res['predictions'][0]
     assert set(p0) == {'labels', 'scores', 'bboxes', 'masks'} and len(p0['masks']) == len(p0['labels'])
     assert p0['masks'][0]['size'] == [160, 256] and isinstance(p0['masks'][0]['counts'], bytes)
+
+
+def test_init_detector_from_config_file_checkpoints_and_jpeg(dev, tmp_path):
+    """SURVEY.md §8 f3 + f2 on the device (mmdet/apis/inference.py:26-193, loader semantics models.py:777-783, 840-851):
+    a config FILE (python, `_base_` inheritance) whose SAM sub-modules point at an HF-layout `model.safetensors` through
+    init_cfg=Pretrained, a trained-detector mmengine `.pth` on top, `init_detector(config, checkpoint, 'cuda:0')`, and
+    `inference_detector` on a JPEG file that both sides decode -- against the oracle loaded with the same tensors."""
+    import rsprompter_amd as ra
+    from PIL import Image
+    from safetensors.torch import save_file
+    from oracle import glue
+    from oracle import pipeline as op
+    from oracle.anchor import AnchorOracle
+    from rsprompter_amd import apis
+    from rsprompter_amd.default_configs import rsprompter_anchor
+    from rsprompter_amd.synth import synth_state_dict
+    # ---- the tensors: detector weights (seed 0), but the SAM encoder as "pretrained" HF weights of ANOTHER seed, so the
+    # test tells whether init_cfg loaded them (they are then overwritten by the trained checkpoint, like the reference)
+    oracle = AnchorOracle('base', 10)
+    sd = synth_state_dict(oracle, seed=0)
+    oracle.load_state_dict(sd)
+    sd_pre = synth_state_dict(oracle, seed=5)
+    hf = {k[len('backbone.'):]: v.contiguous() for k, v in sd_pre.items() if k.startswith('backbone.vision_encoder.')}
+    hf_dir = tmp_path / 'sam-vit-base'
+    hf_dir.mkdir()
+    save_file(hf, str(hf_dir / 'model.safetensors'))                       # HF layout: keys start with vision_encoder.
+    ckpt = str(tmp_path / 'epoch_1.pth')
+    torch.save(dict(meta=dict(epoch=1, dataset_meta=dict(classes=[f'c{i}' for i in range(10)])),
+                    state_dict={('module.' + k if i % 2 else k): v for i, (k, v) in enumerate(sd.items())}), ckpt)
+    # ---- the config as files: a base file + a child that overrides the pretrained path (mmengine `_base_` semantics)
+    model_cfg = rsprompter_anchor('base', 10)
+    (tmp_path / 'base_cfg.py').write_text(
+        'crop_size = (1024, 1024)\n'
+        f'model = {model_cfg!r}\n'
+        'test_dataloader = dict(dataset=dict(pipeline=[\n'
+        "    dict(type='LoadImageFromFile', backend_args=None, to_float32=True),\n"
+        "    dict(type='Resize', scale=crop_size, keep_ratio=True),\n"
+        f"    dict(type='Pad', size=crop_size, pad_val=dict(img={PAD!r}, masks=0)),\n"
+        "    dict(type='PackDetInputs', meta_keys=('img_id', 'img_path', 'ori_shape', 'img_shape', 'scale_factor'))]))\n")
+    (tmp_path / 'child_cfg.py').write_text(
+        "_base_ = ['base_cfg.py']\n"
+        f"model = dict(backbone=dict(init_cfg=dict(type='Pretrained', checkpoint={str(hf_dir)!r})))\n")
+    # ---- (1) init_cfg alone: the encoder must carry the seed-5 tensors, everything else its constructor defaults
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m_pre = apis.init_detector(str(tmp_path / 'child_cfg.py'), None, device=dev)
+    got = m_pre.state_dict()
+    k0 = 'backbone.vision_encoder.layers.3.attn.qkv.weight'
+    assert torch.equal(got[k0].cpu(), sd_pre[k0]) and not torch.equal(got[k0].cpu(), sd[k0])
+    # ---- (2) with the trained checkpoint (module.-prefixed keys mixed in): every tensor equals the oracle's
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = apis.init_detector(str(tmp_path / 'child_cfg.py'), ckpt, device=dev)
+    got = model.state_dict()
+    assert all(torch.equal(got[k].cpu(), v) for k, v in sd.items())
+    assert next(model.parameters()).device.type == 'cuda' and not model.training and model.cfg is not None
+    # ---- (3) a JPEG on disk, decoded by the product's loader; the oracle gets the pixels of the same file
+    bgr = _image()
+    jpg = str(tmp_path / 'crop.jpg')
+    Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(jpg, quality=92)
+    with Image.open(jpg) as im:
+        dec = np.ascontiguousarray(np.asarray(im.convert('RGB'))[:, :, ::-1])
+    assert dec.shape == bgr.shape and int(np.abs(dec.astype(int) - bgr.astype(int)).max()) > 0      # really lossy
+    inp, meta = op.run_test_pipeline(dec)
+    x = glue.data_preprocess([torch.from_numpy(inp)], MEAN, STD, True, 32)
+    ref, _ = oracle.predict(x, [dict(meta, batch_input_shape=(1024, 1024), img_id=0)])
+    r = ref[0]
+    out = apis.inference_detector(model, jpg)
+    pi = out.pred_instances
+    assert pi.labels.shape[0] == r['labels'].shape[0] and out.metainfo['img_path'] == jpg
+    pairs = match_detections(pi.bboxes, pi.scores, pi.labels, r['bboxes'], r['scores'], r['labels'])
+    ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
+    mism = float((pi.masks.cpu()[ii] != r['masks'][jj]).float().mean())
+    print(f'init_detector(config file, .pth) + inference_detector(JPEG): {pi.labels.shape[0]} dets, {len(pairs)} matched, '
+          f'mask mismatch {mism:.2e}')
+    assert mism < 1e-3

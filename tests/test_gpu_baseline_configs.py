@@ -114,7 +114,7 @@ def _check_query(model, oracle, imgs, metas, dev, tag, fp64_floor=False):
         # (2) the HIP path against fp64
         our_flips, our_touched = _mask_flips(trace['attn_masks'], t64['attn_masks'], n_img)
         our_pq = (ours.double() - m64).abs().flatten(2).amax(2)
-        our_aux = float((trace['mask_pred_plus'][0].detach().cpu().double().reshape(t64['mask_pred_plus_all'][0].shape)
+        our_aux = float((trace['mask_pred_plus_all'][0].detach().cpu().double().reshape(t64['mask_pred_plus_all'][0].shape)
                          - t64['mask_pred_plus_all'][0]).abs().max())
         our_cls = float((cls.detach().cpu().double() - t64['cls_pred']).abs().max())
         print(f'{tag}: vs the fp64 forward -- reference fp32: {sum(ref_flips)} decisions differ ({int(ref_touched.sum())} queries), '

@@ -25,7 +25,7 @@ fns = {
     'proj res, no stores*': lambda: ops.gemm(xg, wp, out=o_x, res=res, tile_hint=S2 + 2),
     'proj no epilogue*': lambda: ops.gemm(xg, wp, out=o_x, res=res, tile_hint=S2 + 8),
     'proj no res': lambda: ops.gemm(xg, wp, out=o_x, tile_hint=S2),
-    'proj r2': lambda: ops.gemm(xg, wp, out=o_x, res=res, tile_hint=0),
+    'proj r2': lambda: ops.gemm(xg, wp, out=o_x, res=res, tile_hint=1),
 }
 ms = timed_rounds(fns)
 for k, t in ms.items():
