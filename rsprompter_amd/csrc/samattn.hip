@@ -649,8 +649,12 @@ extern "C" int rsp_sam_i2t_fused(const RspI2tFusedDesc* d, rsp_stream_t stream) 
   p.pscale = ldexpf(1.0f, RSP_PLANE_EXP(d->out_scale_log2)); p.out_rows = (int64_t)d->R * d->N;
   p.T = d->T; p.N = d->N; p.scale = d->scale;
   hipStream_t s = (hipStream_t)stream;
-  static const bool valu_form = getenv("RSP_I2T_VALU") != nullptr;     // A/B switch for tools: the round-2 VALU kernel
-  if (!valu_form) {
+  // The matrix-core form is correct (same unit tests) but not yet the faster one: 4.9 / 6.8 ms against 3.8 / 4.2 ms of
+  // the VALU form at R = 800 (profiles/r3_i2t_mfma_vs_valu.txt) -- hipcc spills ~250 registers around its position
+  // loop (800 B of scratch per lane), and with 156 KB of LDS one block per CU hides no latency.  Opt-in until that is
+  // fixed: RSP_I2T_MFMA=1.
+  const bool mfma_form = getenv("RSP_I2T_MFMA") != nullptr;      // read per call: the tests run both forms
+  if (mfma_form) {
     dim3 grid2((d->N + F2_POS - 1) / F2_POS, d->R);
     if (d->T <= 8) hipLaunchKernelGGL((sam_i2t_fused_mfma_kernel<4>), grid2, dim3(F2_THREADS), 0, s, p);
     else hipLaunchKernelGGL((sam_i2t_fused_mfma_kernel<5>), grid2, dim3(F2_THREADS), 0, s, p);
