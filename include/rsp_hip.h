@@ -32,6 +32,7 @@ extern "C" {
 #define RSP_ACT_RELU 1
 #define RSP_ACT_GELU 2    /* exact erf GELU (torch nn.GELU default) */
 #define RSP_ACT_SIGMOID 3
+#define RSP_ACT_RELU_POST 4   /* C = relu(alpha*acc + bias + res): the ReLU after the shortcut of a ResNet block */
 
 typedef void* rsp_stream_t;
 
@@ -342,6 +343,31 @@ int rsp_hyper_mask(const float* up, const float* hyper, float* out, int32_t R, i
 int rsp_mask_post(const float* low_res, float* sig_ws, int32_t k, int32_t h, int32_t w, int32_t Hb, int32_t Wb,
                   int32_t crop_h, int32_t crop_w, int32_t out_h, int32_t out_w, float thr,
                   uint8_t* out_mask, float* out_prob, rsp_stream_t stream);
+/* SAMDet.predict (models.py:1185-1206): the same resize -> crop -> resize chain on the raw low-res logits */
+/* [k, h, w] of the SAM decoder, then `> thr` (strict; the reference uses 0).  out_val optional.           */
+int rsp_mask_post_logits(const float* low_res, int32_t k, int32_t h, int32_t w, int32_t Hb, int32_t Wb,
+                         int32_t crop_h, int32_t crop_w, int32_t out_h, int32_t out_w, float thr,
+                         uint8_t* out_mask, float* out_val, rsp_stream_t stream);
+
+/* ------------------------------------------------------------------------ */
+/* SAMDet (models.py:1061-1215): FasterRCNN R50-FPN detector + SAM box prompts  */
+/* ------------------------------------------------------------------------ */
+/* ResNet stem (mmdet/models/backbones/resnet.py:640-647): conv1 7x7 s2 p3 (3 -> 64) + eval-mode bn1 folded   */
+/* into w / bias + ReLU.  x [B,3,H,W] fp32 NCHW, w [147][64] (tap = (c*7 + ky)*7 + kx), y [B,Ho,Wo,64] NHWC.  */
+int rsp_resnet_stem(const float* x, const float* w, const float* bias, float* y, int32_t B, int32_t H, int32_t W,
+                    rsp_stream_t stream);
+/* nn.MaxPool2d(k, stride s, padding p) on channels-last data (resnet.py:598: k3 s2 p1); C % 4 == 0          */
+int rsp_maxpool_nhwc(const float* x, float* y, int32_t B, int32_t H, int32_t W, int32_t C, int32_t k, int32_t s,
+                     int32_t p, rsp_stream_t stream);
+/* FPN top-down step (mmdet/models/necks/fpn.py:190-204): dst [B,H,W,C] += nearest-upsampled src [B,h,w,C]   */
+int rsp_upsample_nearest_add(const float* src, float* dst, int32_t B, int32_t h, int32_t w, int32_t H, int32_t W,
+                             int32_t C, rsp_stream_t stream);
+/* HF SamPromptEncoder._embed_boxes (transformers 4.38.1 modeling_sam.py:647-656): boxes [n,4] (x1,y1,x2,y2 in  */
+/* input pixels) -> sparse prompt embeddings out [n, 2, 2*num_pos_feats]; gauss [2, num_pos_feats] is the shared */
+/* positional_embedding, pe_top_left / pe_bottom_right are point_embed[2] / point_embed[3] [2*num_pos_feats].    */
+int rsp_sam_embed_boxes(const float* boxes, const float* gauss, const float* pe_top_left,
+                        const float* pe_bottom_right, float* out, int32_t n, int32_t num_pos_feats,
+                        int32_t input_h, int32_t input_w, rsp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */
 /* Query prompter (RSMask2FormerHead + MSDeformAttnPixelDecoder + fusion head)  */
@@ -431,6 +457,9 @@ int rsp_add_rows(const float* x, const float* v, float* y, int64_t rows, int32_t
 int rsp_sincos_pairs(const float* x, float* y, int64_t n_out, rsp_stream_t stream);
 /* out[i, j] = boxes[i, j] / sf4[j]   (bboxes /= scale_factor, models.py:1763-1764); sf4 is a HOST pointer */
 int rsp_div_boxes(const float* boxes, float* out, int64_t n, const float* sf4, rsp_stream_t stream);
+/* scale_boxes (structures/bbox/transforms.py:391-414): out = boxes * (f0, f1, f2, f3); the R-CNN head's rescale   */
+/* multiplies by fp32(1 / scale_factor) (bbox_head.py:549-552).  f4: HOST float[4].  In place allowed.               */
+int rsp_scale_boxes(const float* boxes, float* out, int64_t n, const float* f4 /*host*/, rsp_stream_t stream);
 /* bool bytes -> bits (little-endian in a byte) : the payload of the multi-GPU result all-gather,  */
 /* replacing CocoMetric's per-rank RLE + mmengine collect_results (coco_metric.py:356-391).       */
 int rsp_pack_bits(const uint8_t* src, uint8_t* dst, int64_t n_bits, rsp_stream_t stream);

@@ -116,14 +116,20 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, iou_threshold, max_num
 
 
 def bbox_head_predict_single(roi, cls_score, bbox_pred, img_shape, num_classes, score_thr, iou_threshold, max_per_img,
-                             stds=(0.1, 0.1, 0.2, 0.2)):
-    """BBoxHead._predict_by_feat_single (bbox_head.py:476-571), class-specific regression, rescale=False:
+                             stds=(0.1, 0.1, 0.2, 0.2), scale_factor=None):
+    """BBoxHead._predict_by_feat_single (bbox_head.py:476-571), class-specific regression (scale_factor=None: rescale=False):
     softmax scores, per-class delta decode of the repeated RoIs, multiclass NMS.  roi [n,5], cls_score [n,nc+1],
     bbox_pred [n,nc*4] -> dets [k,5], labels [k], flat (roi, class) candidate index [k]."""
     n = roi.shape[0]
     scores = torch.softmax(cls_score, dim=-1)
     bboxes = delta2bbox(roi[:, 1:].repeat_interleave(num_classes, dim=0), bbox_pred.view(-1, 4), stds=stds,
-                        max_shape=img_shape).view(n, -1)
+                        max_shape=img_shape)
+    if scale_factor is not None and bboxes.size(0) > 0:
+        # rescale=True (bbox_head.py:549-552 + scale_boxes, structures/bbox/transforms.py:391-414): a python reciprocal,
+        # then an fp32 product, before the NMS
+        inv = [1 / s for s in scale_factor]
+        bboxes = bboxes * bboxes.new_tensor(inv).repeat((1, int(bboxes.size(-1) / 2)))
+    bboxes = bboxes.view(n, -1)
     return multiclass_nms(bboxes, scores, score_thr, iou_threshold, max_per_img)
 
 

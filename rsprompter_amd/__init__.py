@@ -10,7 +10,7 @@ CPU or PyTorch-eager fallback.
 from .registry import MODELS, TASK_UTILS  # noqa: F401
 from .config import Config, ConfigDict  # noqa: F401
 from .structures import DetDataSample, InstanceData  # noqa: F401
-from . import sam_encoder, sam_decoder, necks, anchor_heads, detectors, query_heads  # noqa: F401  (registration)
+from . import sam_encoder, sam_decoder, necks, anchor_heads, detectors, query_heads, samdet  # noqa: F401  (registration)
 
 __version__ = '0.1.0'
 

@@ -137,6 +137,7 @@ PROTOTYPES = {
     "rsp_add_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "rsp_sincos_pairs": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rsp_div_boxes": (c_int, [c_void_p, c_void_p, c_int64, ctypes.POINTER(c_float), c_void_p]),
+    "rsp_scale_boxes": (c_int, [c_void_p, c_void_p, c_int64, ctypes.POINTER(c_float), c_void_p]),
     "rsp_pack_bits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rsp_groupnorm_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                    c_int, c_float, c_int, c_void_p]),
@@ -153,6 +154,13 @@ PROTOTYPES = {
     "rsp_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rsp_gemm_uses_s2": (c_int, [ctypes.POINTER(RspGemmDesc)]),
     "rsp_rle_to_string": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "rsp_mask_post_logits": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
+                                     c_void_p, c_void_p, c_void_p]),
+    "rsp_resnet_stem": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rsp_maxpool_nhwc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rsp_upsample_nearest_add": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "rsp_sam_embed_boxes": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                    c_void_p]),
 }
 
 _lib = None

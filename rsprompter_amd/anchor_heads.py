@@ -479,7 +479,6 @@ class RSPrompterAnchorRoIPromptHead(HIPModule):
 
     def predict_bbox(self, x, batch_img_metas, rpn_results_list, rcnn_test_cfg, rescale=False, pes=None):
         """standard_roi_head.py:293-363 + bbox_head.py:476-571 + multiclass_nms."""
-        assert not rescale
         proposals = [r.bboxes for r in rpn_results_list]
         rois = self._rois(proposals)
         dev = rois.device
@@ -495,7 +494,8 @@ class RSPrompterAnchorRoIPromptHead(HIPModule):
         out = ops.bbox_post(head, self.bbox_head.LD, rois, roi_start, _img_hw(batch_img_metas, dev), nc,
                             float(rcnn_test_cfg['score_thr']), self.bbox_head.bbox_coder.stds,
                             self.bbox_head.bbox_coder.max_ratio, float(nms['iou_threshold']),
-                            int(rcnn_test_cfg['max_per_img']))
+                            int(rcnn_test_cfg['max_per_img']),
+                            scale_factors=[m['scale_factor'] for m in batch_img_metas] if rescale else None)
         kept = out['count'].tolist()            # host sync of the R-CNN stage
         res = []
         for b, k in enumerate(kept):

@@ -226,6 +226,27 @@ extern "C" int rsp_div_boxes(const float* boxes, float* out, int64_t n, const fl
 }
 
 namespace {
+__global__ void scale_boxes_kernel(const float* __restrict__ b, float* __restrict__ o, int64_t n4, float s0, float s1,
+                                   float s2, float s3) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const int j = (int)(i & 3);
+  o[i] = b[i] * (j == 0 ? s0 : (j == 1 ? s1 : (j == 2 ? s2 : s3)));
+}
+}  // namespace
+
+/* scale_boxes (mmdet/structures/bbox/transforms.py:391-414): boxes * factor.repeat(2); the R-CNN head's rescale
+   multiplies by fp32(1 / scale_factor) (bbox_head.py:549-552), which is not the same rounding as a division */
+extern "C" int rsp_scale_boxes(const float* boxes, float* out, int64_t n, const float* f4, rsp_stream_t stream) {
+  if (!boxes || !out || !f4 || n < 0) return RSP_EINVAL;
+  if (n == 0) return RSP_OK;
+  hipLaunchKernelGGL(scale_boxes_kernel, dim3((unsigned)((n * 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes,
+                     out, n * 4, f4[0], f4[1], f4[2], f4[3]);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+namespace {
 // bool bytes -> bits, little-endian within a byte (== numpy.packbits(bitorder='little'))
 __global__ __launch_bounds__(256) void pack_bits_kernel(const uint8_t* __restrict__ src,
                                                         uint8_t* __restrict__ dst, int64_t nbytes_out) {

@@ -227,6 +227,7 @@ __global__ __launch_bounds__(256) void gemm_f16x3_kernel(const GemmP p) {
         if (d.bias) v += d.bias[col];
         v = rsp_act(v, d.act);
         if (d.res) v += d.res[rrow * d.ldr + col];
+        v = rsp_act_post(v, d.act);
         if (d.C) d.C[(int64_t)crow * d.ldc + col] = v;
         if (d.Chi) {
           half_t h, l;

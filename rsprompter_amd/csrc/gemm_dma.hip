@@ -620,6 +620,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
             for (int e = 0; e < nv; ++e) v[e] += rp[e];
           }
         }
+        if (d.act == RSP_ACT_RELU_POST) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rsp_act_post(v[e], d.act);
+        }
         if (d.C && (d.c_ncols <= 0 || col < d.c_ncols)) {
           float* cp = d.C + (int64_t)crow * d.ldc + ccol;
           if (vec) *reinterpret_cast<f32x4*>(cp) = v;

@@ -251,6 +251,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
               const f32x4 rv = *reinterpret_cast<const f32x4*>(d.res + rrow * d.ldr + col);
               v[0] += rv[0]; v[1] += rv[1]; v[2] += rv[2]; v[3] += rv[3];
             }
+            if (d.act == RSP_ACT_RELU_POST) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = rsp_act_post(v[e], d.act);
+            }
             if (d.C && (d.c_ncols <= 0 || col < d.c_ncols)) *reinterpret_cast<f32x4*>(d.C + (int64_t)cr * d.ldc + col) = v;
             if (d.Chi && col >= d.pl_col0) {
               const int pch = col - d.pl_col0;

@@ -90,6 +90,11 @@ __device__ __forceinline__ float rsp_act(float v, int act) {
   }
 }
 
+// RSP_ACT_RELU_POST acts after the residual has been added (rsp_act leaves the value alone for it)
+__device__ __forceinline__ float rsp_act_post(float v, int act) {
+  return (act == RSP_ACT_RELU_POST && v < 0.f) ? 0.f : v;
+}
+
 __device__ __forceinline__ float rsp_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

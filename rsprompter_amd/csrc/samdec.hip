@@ -49,6 +49,7 @@ struct MaskPostP {
   float* prob;        // optional [k, oh, ow]
   int k, h, w, Hb, Wb, ch, cw, oh, ow;
   float thr;
+  int strict;         // 1: value > thr (SAMDet, models.py:1206), 0: value >= thr (models.py:1779)
 };
 
 __global__ __launch_bounds__(256) void sigmoid_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const MaskPostP p) {
       for (int e = 0; e < 4; ++e) v[e] = pixel(oy, ox + e);
       uint32_t bits = 0;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) bits |= (v[e] >= p.thr ? 1u : 0u) << (8 * e);
+      for (int e = 0; e < 4; ++e) bits |= ((p.strict ? v[e] > p.thr : v[e] >= p.thr) ? 1u : 0u) << (8 * e);
       const int64_t o = (int64_t)m * total + (int64_t)oy * p.ow + ox;
       *reinterpret_cast<uint32_t*>(p.out + o) = bits;
       if (p.prob) *reinterpret_cast<f32x4*>(p.prob + o) = f32x4{v[0], v[1], v[2], v[3]};
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256) void mask_post_kernel(const MaskPostP p) {
        i += (int64_t)gridDim.x * blockDim.x) {
     const int oy = (int)(i / p.ow), ox = (int)(i - (int64_t)oy * p.ow);
     const float val = pixel(oy, ox);
-    p.out[(int64_t)m * total + i] = val >= p.thr ? 1 : 0;
+    p.out[(int64_t)m * total + i] = (p.strict ? val > p.thr : val >= p.thr) ? 1 : 0;
     if (p.prob) p.prob[(int64_t)m * total + i] = val;
   }
 }
@@ -119,6 +120,20 @@ extern "C" int rsp_hyper_mask(const float* up, const float* hyper, float* out, i
   return RSP_OK;
 }
 
+namespace {
+int launch_mask_post(const MaskPostP& p, hipStream_t stream) {
+  if ((int64_t)p.oh * p.ow > 0x7fffffffLL) return RSP_EINVAL;
+  int64_t gx = ((int64_t)p.oh * p.ow / ((p.ow & 3) == 0 ? 4 : 1) + 255) / 256;
+  if (gx > 4096) gx = 4096;
+  if (p.ch == p.oh && p.cw == p.ow)
+    hipLaunchKernelGGL((mask_post_kernel<true>), dim3((unsigned)gx, p.k), dim3(256), 0, stream, p);
+  else
+    hipLaunchKernelGGL((mask_post_kernel<false>), dim3((unsigned)gx, p.k), dim3(256), 0, stream, p);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+}  // namespace
+
 extern "C" int rsp_mask_post(const float* low_res, float* sig_ws, int32_t k, int32_t h, int32_t w, int32_t Hb,
                              int32_t Wb, int32_t crop_h, int32_t crop_w, int32_t out_h, int32_t out_w, float thr,
                              uint8_t* out_mask, float* out_prob, rsp_stream_t stream) {
@@ -134,16 +149,22 @@ extern "C" int rsp_mask_post(const float* low_res, float* sig_ws, int32_t k, int
   }
   MaskPostP p;
   p.low = sig_ws; p.out = out_mask; p.prob = out_prob; p.k = k; p.h = h; p.w = w; p.Hb = Hb; p.Wb = Wb;
-  p.ch = crop_h; p.cw = crop_w; p.oh = out_h; p.ow = out_w; p.thr = thr;
-  if ((int64_t)out_h * out_w > 0x7fffffffLL) return RSP_EINVAL;
-  int64_t gx = ((int64_t)out_h * out_w / ((out_w & 3) == 0 ? 4 : 1) + 255) / 256;
-  if (gx > 4096) gx = 4096;
-  if (crop_h == out_h && crop_w == out_w)
-    hipLaunchKernelGGL((mask_post_kernel<true>), dim3((unsigned)gx, k), dim3(256), 0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL((mask_post_kernel<false>), dim3((unsigned)gx, k), dim3(256), 0, (hipStream_t)stream, p);
-  RSP_CHECK_LAUNCH();
-  return RSP_OK;
+  p.ch = crop_h; p.cw = crop_w; p.oh = out_h; p.ow = out_w; p.thr = thr; p.strict = 0;
+  return launch_mask_post(p, (hipStream_t)stream);
+}
+
+// SAMDet.predict (models.py:1185-1206): the same resize -> crop -> resize chain on the raw logits, then `> thr` (thr = 0)
+extern "C" int rsp_mask_post_logits(const float* low_res, int32_t k, int32_t h, int32_t w, int32_t Hb, int32_t Wb,
+                                    int32_t crop_h, int32_t crop_w, int32_t out_h, int32_t out_w, float thr,
+                                    uint8_t* out_mask, float* out_val, rsp_stream_t stream) {
+  if (!low_res || !out_mask || k < 0 || h <= 0 || w <= 0 || Hb <= 0 || Wb <= 0 || crop_h <= 0 || crop_w <= 0 ||
+      crop_h > Hb || crop_w > Wb || out_h <= 0 || out_w <= 0)
+    return RSP_EINVAL;
+  if (k == 0) return RSP_OK;
+  MaskPostP p;
+  p.low = low_res; p.out = out_mask; p.prob = out_val; p.k = k; p.h = h; p.w = w; p.Hb = Hb; p.Wb = Wb;
+  p.ch = crop_h; p.cw = crop_w; p.oh = out_h; p.ow = out_w; p.thr = thr; p.strict = 1;
+  return launch_mask_post(p, (hipStream_t)stream);
 }
 
 

@@ -219,3 +219,31 @@ def samseg_mask2former(arch='base', num_classes=10, num_queries=70, pretrain_nam
                 panoptic_fusion_head=dict(type='MaskFormerFusionHead', num_things_classes=num_classes, num_stuff_classes=0,
                                           loss_panoptic=None, init_cfg=None),
                 train_cfg=q['train_cfg'], test_cfg=q['test_cfg'])
+
+
+def samdet(arch='base', num_classes=10, pretrain_name=None, ckpt=None):
+    """configs/rsprompter/_base_/samdet.py:38-178 merged with samdet-<dataset>.py: Faster R-CNN R50-FPN
+    detector + the HF SamModel prompted with its boxes."""
+    name = pretrain_name or f'work_dirs/sam_cache/sam_vit_{arch}'
+    a = rsprompter_anchor(arch, num_classes, (100, 5), pretrain_name, ckpt)
+    rpn = copy.deepcopy(a['rpn_head'])
+    rpn['anchor_generator'] = dict(type='AnchorGenerator', scales=[8], ratios=[0.5, 1.0, 2.0], strides=[4, 8, 16, 32, 64])
+    train_cfg = copy.deepcopy(a['train_cfg'])
+    train_cfg['rcnn']['assigner']['match_low_quality'] = False
+    train_cfg['rcnn']['sampler']['num'] = 512
+    del train_cfg['rcnn']['mask_size']
+    test_cfg = copy.deepcopy(a['test_cfg'])
+    del test_cfg['rcnn']['mask_thr_binary']
+    detector = dict(
+        type='FasterRCNN',
+        backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                      norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch',
+                      init_cfg=dict(type='Pretrained', checkpoint='torchvision://resnet50')),
+        neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5),
+        rpn_head=rpn,
+        roi_head=dict(type='StandardRoIHead', bbox_roi_extractor=a['roi_head']['bbox_roi_extractor'],
+                      bbox_head=a['roi_head']['bbox_head']),
+        train_cfg=train_cfg, test_cfg=test_cfg)
+    return dict(type='SAMDet', data_preprocessor=a['data_preprocessor'], detector=detector,
+                segmentor=dict(type='RSSamModel', hf_pretrain_name=name,
+                               init_cfg=dict(type='Pretrained', checkpoint=ckpt or f'{name}/pytorch_model.bin')))

@@ -8,7 +8,7 @@ import torch
 
 from . import _lib as _lib_real
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_RELU_POST = 0, 1, 2, 3, 4
 # Power-of-two pre-scale of activation planes (x * 2^e is what gets split into fp16 hi + lo).  e = 2 keeps |x| < 16376
 # exactly representable (the split saturates beyond, rsp_common.h) -- headroom for the outlier activations of real SAM
 # checkpoints (MLP hidden layer, residual stream) and for the RSFeatureAggregator's running sum over 16 layers, which
@@ -819,6 +819,75 @@ def mask_post(low_res, batch_input_shape, crop_hw, out_hw, thr, want_prob=False)
     return (out, prob) if want_prob else out
 
 
+def mask_post_logits(low_res, img_shape, crop_hw, out_hw, thr=0.0, want_val=False):
+    """SAMDet.predict (models.py:1185-1206): low_res [k, h, w] logits -> bool [k, out_h, out_w] = resized logits > thr."""
+    lib = _lib.load()
+    k, h, w = low_res.shape
+    if not low_res.is_contiguous():
+        raise ValueError("mask_post_logits expects contiguous logits")
+    out = torch.empty((k, out_hw[0], out_hw[1]), dtype=torch.bool, device=low_res.device)
+    val = torch.empty((k, out_hw[0], out_hw[1]), dtype=torch.float32, device=low_res.device) if want_val else None
+    _lib.check(lib.rsp_mask_post_logits(low_res.data_ptr(), k, h, w, img_shape[0], img_shape[1], crop_hw[0], crop_hw[1],
+                                        out_hw[0], out_hw[1], thr, out.data_ptr(), _ptr(val), _stream()),
+               "rsp_mask_post_logits")
+    return (out, val) if want_val else out
+
+
+def resnet_stem(x, w_taps, bias):
+    """x [B,3,H,W] fp32 NCHW -> relu(bn(conv7x7 s2 p3)) as NHWC [B,Ho,Wo,64] (resnet.py:640-647)."""
+    lib = _lib.load()
+    _chk_f32(x, "x")
+    if x.dim() != 4 or x.shape[1] != 3 or not x.is_contiguous():
+        raise ValueError("resnet_stem expects a contiguous [B,3,H,W] tensor")
+    B, _, H, W = x.shape
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty((B, Ho, Wo, 64), dtype=torch.float32, device=x.device)
+    _timed('stem_conv_kernel', 2.0 * B * Ho * Wo * 64 * 147, 4.0 * (x.numel() + y.numel()),
+           lambda: _lib.check(lib.rsp_resnet_stem(x.data_ptr(), w_taps.data_ptr(), bias.data_ptr(), y.data_ptr(), B, H, W,
+                                                  _stream()), "rsp_resnet_stem"))
+    return y
+
+
+def maxpool_nhwc(x, k=3, s=2, p=1):
+    lib = _lib.load()
+    _chk_f32(x, "x")
+    if x.dim() != 4 or not x.is_contiguous():
+        raise ValueError("maxpool_nhwc expects a contiguous NHWC tensor")
+    B, H, W, C = x.shape
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    y = torch.empty((B, Ho, Wo, C), dtype=torch.float32, device=x.device)
+    _timed('maxpool_kernel', 0, 4.0 * (x.numel() + y.numel()),
+           lambda: _lib.check(lib.rsp_maxpool_nhwc(x.data_ptr(), y.data_ptr(), B, H, W, C, k, s, p, _stream()),
+                              "rsp_maxpool_nhwc"))
+    return y
+
+
+def upsample_nearest_add_(dst, src):
+    """dst [B,H,W,C] += F.interpolate(src [B,h,w,C], size=(H,W), mode='nearest')  (fpn.py:190-204), in place."""
+    lib = _lib.load()
+    _chk_f32(dst, "dst"); _chk_f32(src, "src")
+    if not (dst.is_contiguous() and src.is_contiguous()) or dst.shape[0] != src.shape[0] or dst.shape[3] != src.shape[3]:
+        raise ValueError("upsample_nearest_add_ expects contiguous NHWC tensors of the same batch and channels")
+    B, H, W, C = dst.shape
+    _timed('upsample_add_kernel', 0, 4.0 * (2 * dst.numel() + src.numel()),
+           lambda: _lib.check(lib.rsp_upsample_nearest_add(src.data_ptr(), dst.data_ptr(), B, src.shape[1], src.shape[2], H,
+                                                           W, C, _stream()), "rsp_upsample_nearest_add"))
+    return dst
+
+
+def sam_embed_boxes(boxes, gauss, pe_top_left, pe_bottom_right, input_size):
+    """boxes [n,4] -> [n, 2, 2F] sparse prompt embeddings (HF SamPromptEncoder._embed_boxes)."""
+    lib = _lib.load()
+    boxes = boxes.contiguous()
+    _chk_f32(boxes, "boxes")
+    n, F = boxes.shape[0], gauss.shape[1]
+    out = torch.empty((n, 2, 2 * F), dtype=torch.float32, device=boxes.device)
+    _lib.check(lib.rsp_sam_embed_boxes(boxes.data_ptr(), gauss.data_ptr(), pe_top_left.data_ptr(),
+                                       pe_bottom_right.data_ptr(), out.data_ptr(), n, F, input_size[0], input_size[1],
+                                       _stream()), "rsp_sam_embed_boxes")
+    return out
+
+
 class RpnSelector:
     """rpn_topk -> rpn_decode -> batched_nms on the device (rpn_head.py:134-304)."""
 
@@ -882,8 +951,11 @@ def batched_nms(cand, B, cap, iou_thr, max_out):
     return dict(boxes=ob, scores=os_, ids=oi, src=osrc, count=keep_cnt, keep=keep, cand_count=cnt)
 
 
-def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, max_ratio, iou_thr, max_out):
-    """R-CNN head post-processing + multiclass NMS (bbox_head.py:476-571, bbox_nms.py:12-105)."""
+def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, max_ratio, iou_thr, max_out,
+              scale_factors=None):
+    """R-CNN head post-processing + multiclass NMS (bbox_head.py:476-571, bbox_nms.py:12-105).
+    scale_factors: per image (w, h) -- `rescale=True` (bbox_head.py:549-554): the decoded, clipped boxes are divided by the
+    scale factor BEFORE the NMS, as the reference does."""
     import ctypes
     lib = _lib.load()
     dev = head.device
@@ -900,6 +972,12 @@ def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, m
     _lib.check(lib.rsp_bbox_post(head.data_ptr(), ld, rois.data_ptr(), rs.data_ptr(), img_hw.data_ptr(), B,
                                  num_classes, score_thr, std4, max_ratio, cap, *[c.data_ptr() for c in cand],
                                  _stream()), "rsp_bbox_post")
+    if scale_factors is not None:
+        for b, sf in enumerate(scale_factors):
+            inv = (1 / float(sf[0]), 1 / float(sf[1]))          # bbox_head.py:550: python reciprocal, then an fp32 product
+            arr = (ctypes.c_float * 4)(inv[0], inv[1], inv[0], inv[1])
+            bx = cand[0][b]
+            _lib.check(lib.rsp_scale_boxes(bx.data_ptr(), bx.data_ptr(), bx.shape[0], arr, _stream()), "rsp_scale_boxes")
     return batched_nms(cand, B, cap, iou_thr, max_out)
 
 
@@ -911,6 +989,17 @@ def div_boxes(boxes, sf4):
     out = torch.empty_like(boxes)
     arr = (ctypes.c_float * 4)(*[float(v) for v in sf4])
     _lib.check(lib.rsp_div_boxes(boxes.data_ptr(), out.data_ptr(), boxes.shape[0], arr, _stream()), "rsp_div_boxes")
+    return out
+
+
+def scale_boxes(boxes, f4):
+    """boxes [k,4] * (f0, f1, f2, f3) in fp32 (scale_boxes, structures/bbox/transforms.py:391-414)."""
+    import ctypes
+    lib = _lib.load()
+    boxes = boxes.contiguous()
+    out = torch.empty_like(boxes)
+    arr = (ctypes.c_float * 4)(*[float(v) for v in f4])
+    _lib.check(lib.rsp_scale_boxes(boxes.data_ptr(), out.data_ptr(), boxes.shape[0], arr, _stream()), "rsp_scale_boxes")
     return out
 
 

@@ -348,6 +348,21 @@ class RSSamMaskDecoder(HIPModule):
         return self.mask_decoder(*args, **kwargs)
 
 
+def image_wide_table(G, size):
+    """models.py:85-95 + HF:552-566 for the [2, F] Gaussian matrix G: logical [1, 2F, size, size] table on G's device
+    (constant preparation on the host, exactly the reference's fp32 expression)."""
+    g = G.detach().float().cpu()
+    grid = torch.ones((size, size), dtype=torch.float32)
+    y = (grid.cumsum(dim=0) - 0.5) / size
+    x = (grid.cumsum(dim=1) - 0.5) / size
+    c = torch.stack([x, y], dim=-1)
+    c = 2 * c - 1
+    c = c @ g
+    c = 2 * np.pi * c
+    pe = torch.cat([torch.sin(c), torch.cos(c)], dim=-1)          # [size, size, 2F] == NHWC
+    return nchw_view(pe.unsqueeze(0).contiguous().to(G.device))
+
+
 class _PosEmb(HIPModule):
     def __init__(self):
         super().__init__()
@@ -373,16 +388,7 @@ class RSSamPositionalEmbedding(HIPModule):
         G = self.shared_image_embedding.positional_embedding
         key = (size, G.data_ptr(), G._version)
         if key not in self._cache:
-            g = G.detach().float().cpu()
-            grid = torch.ones((size, size), dtype=torch.float32)
-            y = (grid.cumsum(dim=0) - 0.5) / size
-            x = (grid.cumsum(dim=1) - 0.5) / size
-            c = torch.stack([x, y], dim=-1)
-            c = 2 * c - 1
-            c = c @ g
-            c = 2 * np.pi * c
-            pe = torch.cat([torch.sin(c), torch.cos(c)], dim=-1)          # [size, size, 256] == NHWC
-            self._cache = {key: nchw_view(pe.unsqueeze(0).contiguous().to(G.device))}
+            self._cache = {key: image_wide_table(G, size)}
         return self._cache[key]
 
     def forward(self, input_coords, input_shape=None):

@@ -136,3 +136,29 @@ def test_reference_samseg_mask2former_configs_build(fname, nc, nq):
         m = ra.build_model(cfg)
     assert type(m).__name__ == 'SAMSegMask2Former' and type(m.panoptic_head).__name__ == 'Mask2FormerHead'
     assert m.panoptic_head.num_transformer_decoder_layers == 9 and m.panoptic_head.pixel_decoder.feat == 256
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='reference checkout not available')
+@pytest.mark.parametrize('fname,nc', [('samdet-nwpu.py', 10), ('samdet-ssdd.py', 1), ('samdet-whu.py', 1)])
+def test_reference_samdet_configs_build(fname, nc):
+    """SAMDet (Faster R-CNN R50-FPN + HF SamModel) builds from the reference's config files unchanged."""
+    import rsprompter_amd as ra
+    from rsprompter_amd.default_configs import samdet
+    cfg = ra.Config.fromfile(os.path.join(REF, fname))
+    assert _norm(cfg.model) == _norm(samdet('base', nc))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        m = ra.build_model(cfg)
+    assert type(m).__name__ == 'SAMDet' and type(m.detector).__name__ == 'FasterRCNN'
+    assert type(m.detector.backbone).__name__ == 'ResNet' and type(m.detector.neck).__name__ == 'FPN'
+    assert m.detector.rpn_head.num_base_priors == 3 and m.detector.roi_head.mask_head is None
+    assert m.detector.roi_head.bbox_head.num_classes == nc and m.test_cfg is None
+    keys = set(m.state_dict())
+    for k in ['detector.backbone.layer4.2.bn3.running_var', 'detector.backbone.layer1.0.downsample.0.weight',
+              'detector.neck.fpn_convs.3.conv.bias', 'detector.roi_head.bbox_head.fc_reg.weight',
+              'segmentor.sam_model.prompt_encoder.point_embed.3.weight',
+              'segmentor.sam_model.prompt_encoder.shared_embedding.positional_embedding',
+              'segmentor.sam_model.shared_image_embedding.positional_embedding',
+              'segmentor.sam_model.vision_encoder.layers.11.attn.rel_pos_w',
+              'segmentor.sam_model.mask_decoder.output_hypernetworks_mlps.3.proj_out.bias']:
+        assert k in keys, k

@@ -1,0 +1,202 @@
+"""-m gpu: `SAMDet` (models.py:1061-1215) on the HIP kernels against its CPU oracle (oracle/samdet.py; ResNet /
+FPN / the predict glue pinned on the real resnet.py / fpn.py / models.py by tests/golden/make_golden_samdet.py)."""
+import os
+import sys
+import warnings
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import torch_ops_mock as mock  # noqa: E402   (plain-torch fp32 statements of the ops, the checker here)
+from _match import match_detections  # noqa: E402
+
+MEAN = [123.675, 116.28, 103.53]
+STD = [58.395, 57.12, 57.375]
+
+
+def _err(a, b):
+    return float((a.detach().cpu().double() - b.detach().cpu().double()).abs().max())
+
+
+def test_resnet_leaf_kernels(dev):
+    """stem conv 7x7 s2 (+ folded BN + ReLU), MaxPool2d(3, 2, 1), FPN nearest top-down add -- odd sizes included."""
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (B, H, W) in ((2, 75, 106), (1, 64, 64), (1, 33, 257)):
+        x = torch.randn(B, 3, H, W, generator=g)
+        w = torch.randn(147, 64, generator=g) / 12
+        b = torch.randn(64, generator=g) * 0.1
+        got = ops.resnet_stem(x.to(dev), w.to(dev), b.to(dev))
+        want = mock.resnet_stem(x, w, b)
+        assert got.shape == want.shape
+        assert _err(got, want) < 2e-5 * max(1.0, float(want.abs().max()))
+        p = ops.maxpool_nhwc(got, 3, 2, 1)
+        wp = mock.maxpool_nhwc(want, 3, 2, 1)
+        assert p.shape == wp.shape and _err(p, wp) < 2e-5 * max(1.0, float(want.abs().max()))
+    for (h, w, H, W) in ((5, 7, 10, 14), (3, 4, 5, 7), (16, 16, 32, 32), (3, 5, 7, 11)):
+        src = torch.randn(2, h, w, 256, generator=g)
+        dst = torch.randn(2, H, W, 256, generator=g)
+        got = ops.upsample_nearest_add_(dst.clone().to(dev), src.to(dev))
+        want = mock.upsample_nearest_add_(dst.clone(), src)
+        assert torch.equal(got.cpu(), want)
+
+
+def test_gemm_relu_after_residual(dev):
+    """RSP_ACT_RELU_POST = relu(A W^T + bias + res) on every GEMM path a Bottleneck's conv3 can take."""
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(6)
+    for (M, N, K) in ((300, 256, 64), (5000, 256, 64), (70000, 256, 64), (70000, 512, 128), (3000, 1024, 256),
+                      (40, 2048, 512)):
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g) * 0.1
+        r = torch.randn(M, N, generator=g)
+        got = ops.gemm(a.to(dev), ops.PackedWeight(w.to(dev), b.to(dev)), res=r.to(dev), act=ops.ACT_RELU_POST)
+        want = F.relu(a.double() @ w.double().t() + b.double() + r.double())
+        assert float((got.cpu() == 0).float().mean()) > 0.2          # the ReLU really acted
+        assert _err(got, want) < 2e-5, (M, N, K)
+    # strided 1x1 convolution (the downsample branch) and the 3x3 stride-2 convolution
+    x = torch.randn(2, 19, 27, 256, generator=g)
+    w1 = torch.randn(512, 256, generator=g) / 16
+    got = ops.gemm(x.to(dev), ops.PackedWeight(w1.to(dev), None), conv=(1, 2, 0))
+    want = F.conv2d(x.permute(0, 3, 1, 2), w1.view(512, 256, 1, 1), stride=2).permute(0, 2, 3, 1).reshape(-1, 512)
+    assert got.shape == want.shape and _err(got, want) < 2e-5
+    w3 = torch.randn(128, 3, 3, 128, generator=g) / 34
+    x3 = torch.randn(2, 19, 27, 128, generator=g)
+    got = ops.gemm(x3.to(dev), ops.PackedWeight(w3.reshape(128, -1).to(dev), None), act=ops.ACT_RELU, conv=(3, 2, 1))
+    want = F.relu(F.conv2d(x3.permute(0, 3, 1, 2), w3.permute(0, 3, 1, 2), stride=2, padding=1)).permute(0, 2, 3, 1)
+    assert _err(got, want.reshape(-1, 128)) < 2e-5
+
+
+def test_box_prompt_mask_post_and_scale_boxes(dev):
+    from oracle import hf_sam
+    from rsprompter_amd import ops
+    g = torch.Generator().manual_seed(7)
+    shared = hf_sam.build_positional_embedding('base')
+    boxes = torch.rand(37, 4, generator=g) * 1000
+    boxes[:, 2:] = boxes[:, :2] + torch.rand(37, 2, generator=g) * 300
+    tl, br = torch.randn(1, 256, generator=g), torch.randn(1, 256, generator=g)
+    G = shared.positional_embedding.detach()
+    got = ops.sam_embed_boxes(boxes.to(dev), G.to(dev), tl.to(dev), br.to(dev), (1024, 1024))
+    # HF's own expression (modeling_sam.py:647-656 over :552-566)
+    with torch.no_grad():
+        ce = shared((boxes + 0.5).reshape(1, -1, 2, 2), (1024, 1024))[0]
+    ce[:, 0, :] += tl[0]
+    ce[:, 1, :] += br[0]
+    # HF initialises the Gaussian matrix with scale = hidden_size // 2, so the sin / cos arguments reach thousands of
+    # radians here: a few ulp of the fp32 argument (fused or unfused 2-term dot product) is all two evaluations can agree to
+    arg = float(((2 * (boxes + 0.5).reshape(-1, 2) / 1024 - 1) @ G).abs().max()) * 6.2832
+    tol = 8 * 2.0 ** -24 * arg + 1e-5
+    print(f'box prompt: max |argument| {arg:.0f} rad, tolerance {tol:.1e}, err {_err(got, ce):.1e}')
+    assert got.shape == ce.shape and _err(got, ce) < tol
+    assert _err(got, mock.sam_embed_boxes(boxes, G, tl, br, (1024, 1024))) < tol
+    G1 = torch.randn(2, 128, generator=g)                                 # checkpoint-like magnitude (std 1)
+    got = ops.sam_embed_boxes(boxes.to(dev), G1.to(dev), tl.to(dev), br.to(dev), (1024, 1024))
+    assert _err(got, mock.sam_embed_boxes(boxes, G1, tl, br, (1024, 1024))) < 2e-5
+    for (k, img, crop, out) in ((3, (768, 1024), (768, 1024), (300, 400)), (2, (1024, 1024), (1024, 1024), (512, 512)),
+                                (1, (1024, 1024), (1000, 900), (333, 301)), (4, (1024, 1024), (1024, 1024), (1024, 1024))):
+        low = F.avg_pool2d(torch.randn(k, 1, 256, 256, generator=g), 9, 1, 4)[:, 0] * 20
+        m, v = ops.mask_post_logits(low.to(dev), img, crop, out, 0.0, want_val=True)
+        wm, wv = mock.mask_post_logits(low, img, crop, out, 0.0, want_val=True)
+        assert _err(v, wv) < 1e-4
+        mism = (m.cpu() != wm)
+        assert float(mism.float().mean()) < 1e-4 and bool((wv[mism].abs() < 1e-4).all())
+    b = torch.rand(11, 4, generator=g) * 500
+    f = (1 / 2.56, 1 / 1.7, 1 / 2.56, 1 / 1.7)
+    assert torch.equal(ops.scale_boxes(b.to(dev), f).cpu(), b * torch.tensor(f, dtype=torch.float32))
+
+
+def test_resnet50_fpn_modules_match_real_classes(dev):
+    """the HIP ResNet-50 + FPN modules on the inputs / weights of the golden run of the REAL mmdet classes."""
+    from rsprompter_amd.samdet import FPN, ResNet
+    from rsprompter_amd.synth import synth_state_dict
+    g = torch.load(os.path.join(HERE, 'golden', 'reference_vectors_samdet.pt'), weights_only=False)['resnet_fpn']
+    net = ResNet(depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                 norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch',
+                 init_cfg=dict(type='Pretrained', checkpoint='torchvision://resnet50'))
+    neck = FPN(in_channels=[256, 512, 1024, 2048], out_channels=256, num_outs=5)
+    assert sorted((k, tuple(v.shape)) for k, v in net.state_dict().items()) == sorted(g['backbone_keys'])
+    assert sorted((k, tuple(v.shape)) for k, v in neck.state_dict().items()) == sorted(g['neck_keys'])
+    net.load_state_dict(synth_state_dict(net, g['seed'][0]), strict=True)
+    neck.load_state_dict(synth_state_dict(neck, g['seed'][1]), strict=True)
+    net, neck = net.to(dev), neck.to(dev)
+    seed, shape = g['x']
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+    c = net(x.to(dev))
+    p = neck(c)
+    cs, fs = g['strides']
+    assert [tuple(t.shape) for t in c] == g['c_shapes'] and [tuple(t.shape) for t in p] == g['p_shapes']
+    for i, (got, want) in enumerate(zip(c, g['c'])):
+        e, s = _err(got[:, ::cs], want), float(want.abs().max())
+        print(f'C{i + 2}: err {e:.2e} (range {s:.1f})')
+        assert e < 2e-4 * max(1.0, s)
+    for i, (got, want) in enumerate(zip(p, g['p'])):
+        e, s = _err(got[:, ::fs], want), float(want.abs().max())
+        print(f'P{i + 2}: err {e:.2e} (range {s:.1f})')
+        assert e < 2e-4 * max(1.0, s)
+
+
+def test_samdet_end_to_end(dev):
+    import rsprompter_amd as ra
+    from oracle import glue
+    from oracle.samdet import SAMDetOracle
+    from rsprompter_amd.default_configs import samdet
+    from rsprompter_amd.structures import DetDataSample, InstanceData
+    from rsprompter_amd.synth import synth_images, synth_metas, synth_state_dict
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        model = ra.build_model(samdet('base', 10))
+    oracle = SAMDetOracle('base', 10)
+    oracle.load_state_dict(synth_state_dict(oracle, 0))
+    sd = oracle.state_dict()
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    model = model.to(dev)
+    imgs = synth_images(2)
+    metas = synth_metas(2, ori_shape=(400, 400), scale_factor=(2.56, 2.56))
+    x = glue.data_preprocess(imgs, MEAN, STD, True, 32)
+    ref, tr = oracle.predict(x, metas)
+    # stage checks on the oracle's intermediates, then the free-running pipeline
+    fp = model.detector.extract_feat(x.to(dev))
+    for i, (a, b) in enumerate(zip(fp, tr['fpn'])):
+        e, s = _err(a, b), float(b.abs().max())
+        print(f'FPN level {i}: err {e:.2e} (range {s:.1f})')
+        assert e < 2e-4 * max(1.0, s)
+    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs],
+                               data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
+    total = 0
+    for b in range(2):
+        pi, r = out[b].pred_instances, ref[b]
+        assert tuple(pi.masks.shape[1:]) == (400, 400) and pi.masks.dtype == torch.bool
+        pairs = match_detections(pi.bboxes, pi.scores, pi.labels, r['bboxes'], r['scores'], r['labels'])
+        assert len(pairs) >= r['labels'].shape[0] - 2 and abs(pi.labels.shape[0] - r['labels'].shape[0]) <= 2
+        ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
+        total += len(pairs)
+        if len(pairs):
+            eb = _err(pi.bboxes[ii], r['bboxes'][jj])
+            mism = float((pi.masks.cpu()[ii] != r['masks'][jj]).float().mean())
+            print(f'SAMDet img {b}: {pi.labels.shape[0]} dets, {len(pairs)} matched, box err {eb:.2e}, mask mismatch {mism:.2e}')
+            assert eb < 5e-2 and mism < 1e-3
+    assert total > 0
+    # ground-truth boxes as prompts (`oracle_on`, models.py:1090-1153)
+    model.test_cfg = dict(oracle_on=True)
+    gt = [torch.tensor([[20.0, 30.0, 200.0, 260.0], [300.0, 100.0, 390.0, 380.0], [0.0, 0.0, 399.0, 399.0]]),
+          torch.zeros((0, 4))]
+    samples = []
+    for m, gb in zip(metas, gt):
+        s = DetDataSample(metainfo=dict(m))
+        s.gt_instances = InstanceData()
+        s.gt_instances.bboxes, s.gt_instances.labels = gb, torch.arange(gb.shape[0])
+        samples.append(s)
+    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=samples))
+    ref, tr = oracle.predict(x, metas, gt_boxes=gt)
+    low = model._last_seg['low_res']
+    e = _err(low, tr['seg'][0]['low_res'])
+    print(f'SAM low-res mask logits err {e:.2e} (range {float(tr["seg"][0]["low_res"].abs().max()):.1f})')
+    assert e < 2e-3
+    assert float((out[0].pred_instances.masks.cpu() != ref[0]['masks']).float().mean()) < 1e-3
+    assert tuple(out[1].pred_instances.masks.shape) == (0, 400, 400)

@@ -21,7 +21,8 @@ def mocked(monkeypatch):
     import rsprompter_amd.sam_encoder as se
     import rsprompter_amd.detectors as det
     import rsprompter_amd.query_heads as qh
-    for m in (ah, necks, sd, se, det, qh):
+    import rsprompter_amd.samdet as sdet
+    for m in (ah, necks, sd, se, det, qh, sdet):
         monkeypatch.setattr(m, 'ops', mock)
     return mock
 
@@ -312,3 +313,57 @@ def test_samseg_mask2former_end_to_end_host_logic(mocked):
     assert int((~same).sum()) <= 2                      # only exact-tie swaps (see tests/_match.py)
     assert _err(pi.scores[same], r['scores'][same]) < 1e-4
     assert float((pi.masks[same] != r['masks'][same]).float().mean()) < 1e-3
+
+
+def test_samdet_end_to_end_host_logic(mocked):
+    """SAMDet.test_step (ResNet-50 + FPN + RPN(3 anchors) + StandardRoIHead(bbox, rescale=True) + the HF
+    SamModel prompted with the boxes + mask post-processing) through the op stand-ins against oracle/samdet.py (ResNet /
+    FPN / the predict glue pinned on the real files); built from the reference's own config file when present."""
+    import os
+    import warnings
+    import rsprompter_amd as ra
+    from _match import match_detections
+    from oracle import glue
+    from oracle.samdet import SAMDetOracle
+    from rsprompter_amd.default_configs import samdet
+    from rsprompter_amd.structures import DetDataSample
+    from rsprompter_amd.synth import synth_images, synth_metas, synth_state_dict
+    ref_cfg = '/root/reference/configs/rsprompter/samdet-nwpu.py'
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        if os.path.exists(ref_cfg):
+            cfg = ra.Config.fromfile(ref_cfg)
+            assert cfg.model.type == 'SAMDet' and cfg.model.detector.backbone.type == 'ResNet'
+            model = ra.build_model(cfg)
+        else:
+            model = ra.build_model(samdet('base', 10))
+    oracle = SAMDetOracle('base', 10)
+    oracle.load_state_dict(synth_state_dict(oracle, 0))
+    sd = oracle.state_dict()            # the two tied positional-embedding keys now hold one tensor, as in a checkpoint
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    imgs = synth_images(1)
+    metas = synth_metas(1, ori_shape=(512, 512), scale_factor=(2.0, 2.0))
+    x = glue.data_preprocess(imgs, [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], True, 32)
+    ref, _ = oracle.predict(x, metas)
+    out = model.test_step(dict(inputs=imgs, data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
+    pi, r = out[0].pred_instances, ref[0]
+    assert r['labels'].shape[0] > 0
+    assert pi.masks.dtype == torch.bool and tuple(pi.masks.shape) == tuple(r['masks'].shape)
+    pairs = match_detections(pi.bboxes, pi.scores, pi.labels, r['bboxes'], r['scores'], r['labels'])
+    ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
+    assert len(pairs) >= r['labels'].shape[0] - 2
+    assert _err(pi.bboxes[ii], r['bboxes'][jj]) < 1e-2
+    assert float((pi.masks[ii] != r['masks'][jj]).float().mean()) < 1e-3
+    # `oracle_on` (models.py:1090-1153): ground-truth boxes as prompts
+    from rsprompter_amd.structures import InstanceData
+    model.test_cfg = dict(oracle_on=True)
+    gt = torch.tensor([[20.0, 30.0, 200.0, 260.0], [300.0, 100.0, 480.0, 400.0]])
+    s = DetDataSample(metainfo=dict(metas[0]))
+    s.gt_instances = InstanceData()
+    s.gt_instances.bboxes, s.gt_instances.labels = gt, torch.tensor([3, 5])
+    out = model.test_step(dict(inputs=imgs, data_samples=[s]))
+    ref, _ = oracle.predict(x, metas, gt_boxes=[gt])
+    pi = out[0].pred_instances
+    assert torch.equal(pi.labels, torch.tensor([3, 5])) and torch.equal(pi.scores, torch.ones(2))
+    assert float((pi.masks != ref[0]['masks']).float().mean()) < 1e-3

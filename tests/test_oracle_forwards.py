@@ -156,3 +156,37 @@ def test_mask2former_head_matches_real_class():
     for a, b in zip(tr['mask_pred_all'], g['mask_pred_all']):
         assert err(a[:, :, ::2, ::2], b) < 2e-4
     assert err(mask, g['mask_pred']) < 2e-4
+
+
+@torch.no_grad()
+def test_samdet_resnet_fpn_and_predict_glue_match_real_files():
+    """oracle/samdet.py against the REAL mmdet ResNet-50 / FPN classes and the REAL SAMDet.predict (models.py:1155-1213)
+    run in the build container (tests/golden/make_golden_samdet.py)."""
+    import numpy as np
+    from oracle import samdet
+    from rsprompter_amd.synth import synth_state_dict
+    g = torch.load(os.path.join(os.path.dirname(GOLD), 'reference_vectors_samdet.pt'), weights_only=False)
+    r = g['resnet_fpn']
+    net = load(samdet.ResNet(50), dict(keys=r['backbone_keys'], seed=r['seed'][0]))
+    neck = load(samdet.FPN(), dict(keys=r['neck_keys'], seed=r['seed'][1]))
+    c = net(rnd(r['x']))
+    p = neck(c)
+    cs, fs = r['strides']
+    assert [tuple(t.shape) for t in c] == r['c_shapes'] and [tuple(t.shape) for t in p] == r['p_shapes']
+    for got, want in zip(c, r['c']):
+        assert err(got[:, ::cs], want) < 1e-4 * max(1.0, float(want.abs().max()))
+    for got, want in zip(p, r['p']):
+        assert err(got[:, ::fs], want) < 1e-4 * max(1.0, float(want.abs().max()))
+    s = g['samdet_predict']
+    sam = samdet.build_sam_model('base')
+    sam.load_state_dict(synth_state_dict(sam, s['seed']))
+    imgs = rnd(s['imgs'])
+    for img, meta, boxes, packed, shape in zip(imgs, s['metas'], s['boxes'], s['masks'], s['shapes']):
+        if boxes.shape[0] == 0:
+            assert shape[0] == 0
+            continue
+        sf = boxes.new_tensor(meta['scale_factor']).repeat((1, 2))
+        masks, _ = samdet.sam_box_masks(sam, img, boxes * sf, meta)
+        want = torch.from_numpy(np.unpackbits(packed.numpy())[:int(np.prod(shape))].reshape(shape)).bool()
+        assert tuple(masks.shape) == shape
+        assert float((masks != want).float().mean()) < 1e-4

@@ -9,7 +9,7 @@ import math
 import torch
 import torch.nn.functional as F
 
-ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID = 0, 1, 2, 3
+ACT_NONE, ACT_RELU, ACT_GELU, ACT_SIGMOID, ACT_RELU_POST = 0, 1, 2, 3, 4
 DEFAULT_A_SCALE_LOG2 = 6
 F8_CORR = True          # the flag only travels through the host wiring here (planes are fp32 tensors in the mock)
 
@@ -19,7 +19,7 @@ def require_device(dev):
 
 
 def _act(x, act):
-    return {0: lambda t: t, 1: F.relu, 2: F.gelu, 3: torch.sigmoid}[act](x)
+    return {0: lambda t: t, 1: F.relu, 2: F.gelu, 3: torch.sigmoid, 4: lambda t: t}[act](x)      # 4: after the residual
 
 
 class PackedWeight:
@@ -63,6 +63,8 @@ def gemm(a, w, *, out=None, bias='auto', res=None, act=0, a_rowmap=None, c_rowma
         if res_bmap is not None:
             rr = res_bmap.long()[rr // res_brows] * res_brows + rr % res_brows
         y = y + res[rr]
+    if act == ACT_RELU_POST:
+        y = F.relu(y)
     out[crow[keep]] = y[keep]
     if c_ncols or pl_col0:       # column-range outputs: fp32 = first c_ncols columns, "planes" = columns from pl_col0 on
         return out[:, :c_ncols].contiguous(), out[:, pl_col0:].contiguous()
@@ -260,6 +262,47 @@ def div_boxes(boxes, sf4):
     return boxes / torch.tensor([float(v) for v in sf4])
 
 
+def scale_boxes(boxes, f4):
+    return boxes * torch.tensor([float(v) for v in f4])
+
+
+def mask_post_logits(low_res, img_shape, crop_hw, out_hw, thr=0.0, want_val=False):
+    """models.py:1185-1206: bilinear to img_shape -> crop -> bilinear to ori_shape -> > thr (on the logits)"""
+    if low_res.shape[0] == 0:
+        return torch.zeros((0, out_hw[0], out_hw[1]), dtype=torch.bool)
+    p = F.interpolate(low_res[:, None], size=tuple(img_shape), mode='bilinear', align_corners=False)
+    p = p[..., :crop_hw[0], :crop_hw[1]]
+    p = F.interpolate(p, size=tuple(out_hw), mode='bilinear', align_corners=False)[:, 0]
+    return (p > thr, p) if want_val else p > thr
+
+
+def resnet_stem(x, w_taps, bias):
+    w = w_taps.t().reshape(64, 3, 7, 7)
+    return F.relu(F.conv2d(x, w, bias, stride=2, padding=3)).permute(0, 2, 3, 1).contiguous()
+
+
+def maxpool_nhwc(x, k=3, s=2, p=1):
+    return F.max_pool2d(x.permute(0, 3, 1, 2), k, s, p).permute(0, 2, 3, 1).contiguous()
+
+
+def upsample_nearest_add_(dst, src):
+    dst += F.interpolate(src.permute(0, 3, 1, 2), size=dst.shape[1:3], mode='nearest').permute(0, 2, 3, 1)
+    return dst
+
+
+def sam_embed_boxes(boxes, gauss, pe_top_left, pe_bottom_right, input_size):
+    """HF SamPromptEncoder._embed_boxes + SamPositionalEmbedding.forward"""
+    c = (boxes + 0.5).reshape(-1, 2, 2).clone()
+    c[..., 0] = c[..., 0] / input_size[1]
+    c[..., 1] = c[..., 1] / input_size[0]
+    c = (2 * c - 1) @ gauss
+    c = 2 * math.pi * c
+    e = torch.cat([torch.sin(c), torch.cos(c)], -1)
+    e[:, 0] += pe_top_left.reshape(-1)
+    e[:, 1] += pe_bottom_right.reshape(-1)
+    return e
+
+
 def preprocess(imgs, mean, std, swap_rb, pad_divisor=1, pad_value=0.0, device=None):
     from oracle import glue
     return glue.data_preprocess(list(imgs), list(mean), list(std), bool(swap_rb), pad_divisor, pad_value)
@@ -307,7 +350,8 @@ class RpnSelector:
         return _padded(rows, self.max_per_img, B)
 
 
-def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, max_ratio, iou_thr, max_out):
+def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, max_ratio, iou_thr, max_out,
+              scale_factors=None):
     from oracle import glue
     B, nc = img_hw.shape[0], num_classes
     rows = []
@@ -319,7 +363,8 @@ def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, m
         dets, labels, cand = glue.bbox_head_predict_single(rois[r0:r1], head[r0:r1, :nc + 1].contiguous(),
                                                            head[r0:r1, nc + 1:5 * nc + 1].contiguous(),
                                                            (int(img_hw[b, 0]), int(img_hw[b, 1])), nc, score_thr, iou_thr,
-                                                           max_out, stds=tuple(stds))
+                                                           max_out, stds=tuple(stds),
+                                                           scale_factor=None if scale_factors is None else scale_factors[b])
         rows.append((dets[:, :4], dets[:, 4], labels, cand))
     return _padded(rows, max_out, B)
 
