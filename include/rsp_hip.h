@@ -457,6 +457,12 @@ int rsp_add_rows(const float* x, const float* v, float* y, int64_t rows, int32_t
 int rsp_sincos_pairs(const float* x, float* y, int64_t n_out, rsp_stream_t stream);
 /* out[i, j] = boxes[i, j] / sf4[j]   (bboxes /= scale_factor, models.py:1763-1764); sf4 is a HOST pointer */
 int rsp_div_boxes(const float* boxes, float* out, int64_t n, const float* sf4, rsp_stream_t stream);
+/* Rows of a GEMM output that the GEMM does not write because their A row is zero (window padding of window_partition,  */
+/* HF:913-915: qkv(0) = bias): C[rows[i], 0:c_ncols) = bias and the planes of columns [pl_col0, N) (KB32, c_rows rows,    */
+/* format word c_scale_log2 as in RspGemmDesc) = split(bias * 2^e) -- what the GEMM epilogue writes for alpha*0 + bias.    */
+int rsp_fill_bias_rows(const float* bias, const int32_t* rows, int32_t n_rows, int32_t N, float* C, int32_t ldc,
+                       int32_t c_ncols, uint16_t* Chi, uint16_t* Clo, int64_t c_rows, int32_t pl_col0,
+                       int32_t c_scale_log2, rsp_stream_t stream);
 /* scale_boxes (structures/bbox/transforms.py:391-414): out = boxes * (f0, f1, f2, f3); the R-CNN head's rescale   */
 /* multiplies by fp32(1 / scale_factor) (bbox_head.py:549-552).  f4: HOST float[4].  In place allowed.               */
 int rsp_scale_boxes(const float* boxes, float* out, int64_t n, const float* f4 /*host*/, rsp_stream_t stream);

@@ -137,6 +137,8 @@ PROTOTYPES = {
     "rsp_add_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "rsp_sincos_pairs": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rsp_div_boxes": (c_int, [c_void_p, c_void_p, c_int64, ctypes.POINTER(c_float), c_void_p]),
+    "rsp_fill_bias_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int64,
+                                   c_int, c_int, c_void_p]),
     "rsp_scale_boxes": (c_int, [c_void_p, c_void_p, c_int64, ctypes.POINTER(c_float), c_void_p]),
     "rsp_pack_bits": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     "rsp_groupnorm_nhwc": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

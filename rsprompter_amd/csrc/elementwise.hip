@@ -226,6 +226,43 @@ extern "C" int rsp_div_boxes(const float* boxes, float* out, int64_t n, const fl
 }
 
 namespace {
+// rows[i] of a GEMM output that the GEMM itself does not write (zero A rows: window padding) = bias: fp32 columns
+// [0, c_ncols) of C and the plane columns [pl_col0, N) -- exactly what alpha * 0 + bias gives in the GEMM epilogue
+__global__ __launch_bounds__(256) void fill_bias_rows_kernel(const float* __restrict__ bias, const int32_t* __restrict__ rows,
+                                                             int n_rows, int N, float* __restrict__ C, int ldc, int c_ncols,
+                                                             half_t* __restrict__ hi, half_t* __restrict__ lo, int64_t c_rows,
+                                                             int pl_col0, float cs, bool f8) {
+  const int q4 = N >> 2;
+  const int64_t total = (int64_t)n_rows * q4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % q4) * 4;
+    const int64_t r = rows[i / q4];
+    const f32x4 b = bias ? *reinterpret_cast<const f32x4*>(bias + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (C && (c_ncols <= 0 || col < c_ncols)) *reinterpret_cast<f32x4*>(C + r * ldc + col) = b;
+    if (hi && col >= pl_col0) {
+      const int pch = col - pl_col0;
+      const int64_t po = ((int64_t)(pch >> 5) * c_rows + r) * 32 + (pch & 31);
+      rsp_store_planes4(hi, lo, po, f32x4{b[0] * cs, b[1] * cs, b[2] * cs, b[3] * cs}, f8);
+    }
+  }
+}
+}  // namespace
+
+extern "C" int rsp_fill_bias_rows(const float* bias, const int32_t* rows, int32_t n_rows, int32_t N, float* C, int32_t ldc,
+                                  int32_t c_ncols, uint16_t* Chi, uint16_t* Clo, int64_t c_rows, int32_t pl_col0,
+                                  int32_t c_scale_log2, rsp_stream_t stream) {
+  if (!rows || n_rows < 0 || N <= 0 || (N & 3) || (c_ncols & 3) || (pl_col0 & 31) || pl_col0 < 0 || (C && ldc < (c_ncols > 0 ? c_ncols : N)) ||
+      (Chi && (!Clo || c_rows <= 0)) || !RSP_PLANE_WORD_VALID(c_scale_log2))
+    return RSP_EINVAL;
+  if (n_rows == 0 || (!C && !Chi)) return RSP_OK;
+  hipLaunchKernelGGL(fill_bias_rows_kernel, dim3(grid_for((int64_t)n_rows * (N >> 2))), dim3(256), 0, (hipStream_t)stream,
+                     bias, rows, n_rows, N, C, ldc, c_ncols, reinterpret_cast<half_t*>(Chi), reinterpret_cast<half_t*>(Clo),
+                     c_rows, pl_col0, ldexpf(1.0f, RSP_PLANE_EXP(c_scale_log2)), RSP_PLANE_IS_F8(c_scale_log2));
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+namespace {
 __global__ void scale_boxes_kernel(const float* __restrict__ b, float* __restrict__ o, int64_t n4, float s0, float s1,
                                    float s2, float s3) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

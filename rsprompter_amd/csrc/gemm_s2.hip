@@ -572,7 +572,7 @@ static int s2_epilogue_of(const RspGemmDesc& d) {
 int rsp_gemm_s2_auto(const RspGemmDesc& d) {
   if (!rsp_gemm_s2_eligible(d)) return 0;
   const int e = s2_epilogue_of(d);
-  const bool have = e == E_C || e == (E_C | E_RES) || e == (E_C | E_RES | E_RMAP) || e == (E_C | E_PL) || e == E_PL ||
+  const bool have = e == E_C || e == (E_C | E_RES) || e == (E_C | E_RES | E_RMAP) || e == (E_C | E_PL) || e == (E_C | E_PL | E_RMAP) || e == E_PL ||
                     e == (E_PL | E_GELU) || e == (E_C | E_GELU);
   const long long nt = (long long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
   return have && nt >= 256 && d.K >= 128;
@@ -587,6 +587,7 @@ int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s) {
   S2_CASE(0, E_C | E_RES);         // proj (global layers), lin2, patch embed
   S2_CASE(0, E_C | E_RES | E_RMAP); // proj of a windowed layer (row scatter)
   S2_CASE(0, E_C | E_PL);          // qkv (column ranges), fp32 + planes
+  S2_CASE(0, E_C | E_PL | E_RMAP); // qkv of a windowed layer: token rows scattered to window order
   S2_CASE(0, E_PL);                // planes only
   S2_CASE(0, E_PL | E_GELU);       // lin1
   S2_CASE(0, E_C | E_GELU);

@@ -992,6 +992,20 @@ def div_boxes(boxes, sf4):
     return out
 
 
+def fill_bias_rows(bias, rows, N, out=None, planes=None, c_ncols=0, pl_col0=0):
+    """rows (int32 indices) of a GEMM output the GEMM did not write because their A row is zero (window padding): fp32
+    columns [0, c_ncols or N) of `out` = bias, plane columns [pl_col0, N) = split(bias)  (HF:913-915: qkv(0) = bias)."""
+    lib = _lib.load()
+    n = int(rows.shape[0])
+    if n == 0:
+        return
+    _lib.check(lib.rsp_fill_bias_rows(_ptr(bias), rows.data_ptr(), n, N, _ptr(out), out.stride(0) if out is not None else 0,
+                                      c_ncols, planes.hi.data_ptr() if planes is not None else None,
+                                      planes.lo.data_ptr() if planes is not None else None,
+                                      planes.rows if planes is not None else 0, pl_col0,
+                                      planes.word if planes is not None else 0, _stream()), "rsp_fill_bias_rows")
+
+
 def scale_boxes(boxes, f4):
     """boxes [k,4] * (f0, f1, f2, f3) in fp32 (scale_boxes, structures/bbox/transforms.py:391-414)."""
     import ctypes

@@ -165,8 +165,12 @@ class SamVisionEncoderHIP(HIPModule):
         b = idx // (w * w * nw * nw)
         y, x = wy * w + iy, wx * w + ix
         src = torch.where((y < g) & (x < g), b * g * g + y * g + x, torch.full_like(idx, -1))
-        m = src.to(torch.int32).to(device)
-        self._maps[key] = (m, nw)
+        # the inverse: token row -> its row in window order (every token lies in exactly one window), and the padded rows
+        real = src >= 0
+        tok2win = torch.empty(B * g * g, dtype=torch.int64)
+        tok2win[src[real]] = idx[real]
+        self._maps[key] = (src.to(torch.int32).to(device), nw, tok2win.to(torch.int32).to(device),
+                           idx[~real].to(torch.int32).to(device))
         return self._maps[key]
 
     # ------------------------------------------------------------------ forward
@@ -201,15 +205,22 @@ class SamVisionEncoderHIP(HIPModule):
             if S == g:  # global attention layer
                 q, kv = ops.gemm(xn, L['qkv'], out_planes=True, c_ncols=D, pl_col0=D)
                 Bp, rowmap = B, None
-            else:       # windowed: partition is a row gather in the qkv GEMM (pad rows -> bias only, HF:913-915)
-                rowmap, nw = self._window_map(B, x.device)
+            else:
+                # windowed: window_partition (HF:900-922) is a row SCATTER in the qkv GEMM's epilogue -- the GEMM runs over
+                # the B * T real tokens only; the padded rows of the windows (16 % at 1024 px: zero tokens, so qkv = bias,
+                # HF:913-915) are filled with the bias by a copy kernel instead of being multiplied
+                _, nw, tok2win, pad_rows = self._window_map(B, x.device)
                 Bp = B * nw * nw
-                q, kv = ops.gemm(xn, L['qkv'], a_rowmap=rowmap, M=Bp * S * S, out_planes=True, c_ncols=D, pl_col0=D)
+                q, kv = ops.gemm(xn, L['qkv'], c_rowmap=tok2win, out_rows=Bp * S * S, out_planes=True, c_ncols=D,
+                                 pl_col0=D)
+                ops.fill_bias_rows(L['qkv'].bias, pad_rows, 3 * D, out=q, planes=kv, c_ncols=D, pl_col0=D)
+                rowmap = tok2win
             rel = ops.vit_relpos(q, L['rph'], L['rpw'], Bp, S, nh, dh, q_ld=D)
             att = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=True, f8=f8)
             qkv = (q, kv)
-            # proj + window_unpartition + crop + residual (HF:830, 924-952, 969)
-            x1 = ops.gemm(att, L['proj'], res=x, c_rowmap=rowmap, out_rows=B * T)
+            # proj + window_unpartition + crop + residual (HF:830, 924-952, 969): a row GATHER of the real tokens from
+            # window order (the padded rows are never multiplied)
+            x1 = ops.gemm(att, L['proj'], res=x, a_rowmap=rowmap, M=B * T)
             del qkv, rel, att, xn
             xn2 = ops.layernorm(x1, L['ln2'][0], L['ln2'][1], self.eps, planes=True, f32=False, f8=f8)
             hmid = ops.gemm(xn2, L['lin1'], act=ops.ACT_GELU, out_planes=True, out_f32=False, out_f8=f8)

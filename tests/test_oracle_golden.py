@@ -85,13 +85,18 @@ def test_window_and_relpos_semantics_match_vit_sam_source(gold):
         enc = SamVisionEncoderHIP('t', image_size=320)   # 20x20 grid, window 14 -> 2x2 windows with padding
     finally:
         SAM_ARCH.pop('t')
-    m, nw = enc._window_map(2, torch.device('cpu'))
+    m, nw = enc._window_map(2, torch.device('cpu'))[:2]
     x = w['x'].reshape(-1, 8)
     rows = torch.where((m >= 0)[:, None], x[m.clamp(min=0).long()], torch.zeros(1))
     assert nw == 2 and torch.equal(rows.view(-1, 14, 14, 8), w['windows'])
     back = torch.zeros_like(x)
     back[m[m >= 0].long()] = w['windows'].reshape(-1, 8)[m >= 0]
     assert torch.equal(back.view(2, 20, 20, 8), w['back'])
+    # the inverse map the GEMMs use (qkv scatters token rows to window order, proj gathers them back) and the pad rows
+    _, _, tok2win, pad_rows = enc._window_map(2, torch.device('cpu'))
+    assert torch.equal(m[tok2win.long()].long(), torch.arange(2 * 400))
+    assert torch.equal(pad_rows.long(), (m < 0).nonzero()[:, 0]) and tok2win.shape[0] + pad_rows.shape[0] == m.shape[0]
+    assert torch.equal(w['windows'].reshape(-1, 8)[tok2win.long()], x)
     rp = gold['rel_pos']
     idx = torch.arange(14)[:, None] - torch.arange(14)[None, :] + 13
     assert torch.equal(resize_rel_pos(rp['rel_pos'], 14)[idx], rp['same'])

@@ -262,6 +262,14 @@ def div_boxes(boxes, sf4):
     return boxes / torch.tensor([float(v) for v in sf4])
 
 
+def fill_bias_rows(bias, rows, N, out=None, planes=None, c_ncols=0, pl_col0=0):
+    r = rows.long()
+    if out is not None:
+        out[r] = bias[:c_ncols or N]
+    if planes is not None:
+        planes[r] = bias[pl_col0:]
+
+
 def scale_boxes(boxes, f4):
     return boxes * torch.tensor([float(v) for v in f4])
 

@@ -28,6 +28,15 @@ def window_map(B, g=64, w=14):
     return src.to(torch.int32).to(dev)
 
 
+def window_inverse(rm):
+    """token row -> window-order row, and the padded window rows (the maps SamVisionEncoderHIP uses since round 3)"""
+    rm = rm.long().cpu()
+    real = rm >= 0
+    t2w = torch.empty(int(real.sum()), dtype=torch.int64)
+    t2w[rm[real]] = torch.arange(rm.numel())[real]
+    return t2w.to(torch.int32).to(dev), torch.arange(rm.numel())[~real].to(torch.int32).to(dev)
+
+
 def mk(n, k, bias=True):
     return ops.PackedWeight(torch.randn(n, k) / k ** 0.5, torch.randn(n) * 0.05 if bias else None, device=dev)
 
@@ -80,8 +89,26 @@ def check():
     run('qkv windowed: a_rowmap, q fp32 + K|V planes (c_ncols / pl_col0)',
         lambda h: ops.gemm(xp, wq, a_rowmap=rm, M=Mwin, out_planes=True, c_ncols=D, pl_col0=D, tile_hint=h))
     run('qkv global: q fp32 + K|V planes', lambda h: ops.gemm(xp, wq, out_planes=True, c_ncols=D, pl_col0=D, tile_hint=h))
+    t2w, pads = window_inverse(rm)
+
+    def qkv_scatter(h):
+        q, kv = ops.gemm(xp, wq, c_rowmap=t2w, out_rows=Mwin, out_planes=True, c_ncols=D, pl_col0=D, tile_hint=h)
+        ops.fill_bias_rows(wq.bias, pads, 3 * D, out=q, planes=kv, c_ncols=D, pl_col0=D)
+        return q, kv
+    run('qkv windowed, scatter form: c_rowmap to window order + bias fill of the padded rows', qkv_scatter)
+    ref_q, ref_kv = ops.gemm(xp, wq, a_rowmap=rm, M=Mwin, out_planes=True, c_ncols=D, pl_col0=D, tile_hint=1)
+    got_q, got_kv = qkv_scatter(0)
+    ok = same((ref_q, ref_kv), (got_q, got_kv))
+    print(f'{"OK  " if ok else "FAIL"} qkv windowed: scatter form == gather form (padded rows multiplied), bit for bit', flush=True)
+    ok_all &= ok
     att = ops.to_planes(torch.randn(Mwin, D, device=dev))
     wp = mk(D, D)
+    run('proj windowed, gather form: a_rowmap from window order + fp32 residual',
+        lambda h: ops.gemm(att, wp, res=x, a_rowmap=t2w, M=B * 4096, tile_hint=h))
+    ok = torch.equal(ops.gemm(att, wp, res=x, a_rowmap=t2w, M=B * 4096),
+                     ops.gemm(att, wp, res=x, c_rowmap=rm, out_rows=B * 4096, out=torch.zeros(B * 4096, D, device=dev), tile_hint=1))
+    print(f'{"OK  " if ok else "FAIL"} proj windowed: gather form == scatter form, bit for bit', flush=True)
+    ok_all &= ok
     run('proj windowed: c_rowmap scatter + fp32 residual',
         lambda h: ops.gemm(att, wp, res=x, c_rowmap=rm, out_rows=B * 4096, out=torch.zeros(B * 4096, D, device=dev), tile_hint=h))
     # (c) lin1 / lin2
@@ -131,12 +158,17 @@ def time_all():
     xm = ops.to_planes(torch.randn(Mg, MLP, device=dev))
     res = torch.randn(Mg, D, device=dev)
     rm = window_map(8)
+    t2w, _ = window_inverse(rm)
     w_qkv, w_proj, w_lin1, w_lin2 = mk(3 * D, D), mk(D, D), mk(MLP, D), mk(D, MLP)
     o_x = torch.empty(Mg, D, device=dev)
     att_w = ops.to_planes(torch.randn(Mw, D, device=dev))
     cases = {
         'qkv_window M=39200 N=3840 K=1280 (rowmap, q f32 + KV planes)':
             (Mw, 3 * D, D, lambda h: ops.gemm(xg, w_qkv, a_rowmap=rm, M=Mw, out_planes=True, c_ncols=D, pl_col0=D, tile_hint=h)),
+        'qkv_window_scatter M=32768 N=3840 K=1280 (token rows -> window order, q f32 + KV planes)':
+            (Mg, 3 * D, D, lambda h: ops.gemm(xg, w_qkv, c_rowmap=t2w, out_rows=Mw, out_planes=True, c_ncols=D, pl_col0=D, tile_hint=h)),
+        'proj_window_gather M=32768 N=1280 K=1280 +res (A rows from window order)':
+            (Mg, D, D, lambda h: ops.gemm(att_w, w_proj, res=res, a_rowmap=t2w, M=Mg, out=o_x, tile_hint=h)),
         'qkv_global M=32768 N=3840 K=1280':
             (Mg, 3 * D, D, lambda h: ops.gemm(xg, w_qkv, out_planes=True, c_ncols=D, pl_col0=D, tile_hint=h)),
         'proj_window M=39200 N=1280 K=1280 +res scatter':
@@ -148,7 +180,9 @@ def time_all():
     }
     variants = [('product', 0), ('r2 auto', 1), ('r2 256x256', 17), ('s2', S2), ('s2 generic-epi', S2 + 64),
                 ('s2 epi-prio', S2 + 1), ('s2 noDMA*', S2 + 4), ('s2 noEpi*', S2 + 8), ('s2 hotDMA*', S2 + 16)]
-    only = {'qkv_window': ('product', 'r2 auto', 'r2 256x256', 's2', 's2 generic-epi', 's2 epi-prio'),
+    only = {'qkv_window_scatter': ('product', 'r2 auto', 'r2 256x256', 's2', 's2 generic-epi'),
+            'proj_window_gather': ('product', 'r2 auto', 'r2 256x256', 's2', 's2 generic-epi'),
+            'qkv_window': ('product', 'r2 auto', 'r2 256x256', 's2', 's2 generic-epi', 's2 epi-prio'),
             'qkv_global': ('product', 'r2 auto', 'r2 256x256', 's2', 's2 generic-epi', 's2 epi-prio')}   # variants exist for proj / lin shapes
     for name, (M, N, K, fn) in cases.items():
         vs = [(vn, h) for vn, h in variants if name.split(' ')[0] not in only or vn in only[name.split(' ')[0]]]
