@@ -348,144 +348,149 @@ __global__ __launch_bounds__(1024) void sam_i2t_fused_kernel(const I2tFusedP p) 
 // Round 3: the same fused block with the out_proj-folded product ON THE MATRIX CORES.
 //   out[pos, c] = sum_k P[pos, k] * Vp[k, c],  k = (token t, head h) = 8 t + h  (K = 8 T <= 80), c = 256 channels
 // is a [positions x 80] x [80 x 256] matrix product; the VALU form above spends 80 x (9 LDS reads + 16 packed FMAs) per
-// position on it (measured: 4.2 ms per call at R = 800, VALU / LDS-issue bound, 5x its HBM time).  Here:
-//   * block = 8 waves, Vp as fp16 (hi, lo) planes in LDS in MFMA A-fragment order [k step][32-channel block][32][16]
-//     (32-byte rows, chunk swizzled with bit 3 of the row like the GEMM ring), scale chosen per block from max |Vp|;
-//   * a wave takes 32 consecutive positions; its lanes are (position, token parity): lane (p, hh) owns the scores of
-//     tokens 2 tt + hh for all 8 heads, so the softmax needs ONE exchange with lane p + 32 (max and sum), and the
-//     probabilities of token 2 s + hh, heads 0..7 ARE the B fragment of k step s (k = 16 s + 8 hh + h): P never moves;
-//   * O^T = Vp^T P^T in fp16x3 (v_mfma_f32_32x32x16_f16, 8 channel blocks x K/16 steps x 3), fp32 accumulate;
-//   * global memory is only touched in ROW layout (16 lanes x 16 B per position row: q, residual, result): the q rows
-//     and the 256-channel results pass through a per-wave 8 KB LDS piece (64 columns at a time, XOR swizzle) on their
-//     way to / from the position-per-lane layout the matrix product wants -- same trick as the GEMM epilogue;
-//   * LayerNorm statistics in row layout: 16 values per lane and row, 4 DPP-class exchanges over the row's 16 lanes.
-constexpr int F2_THREADS = 512, F2_POS = 1024;            // positions of one RoI per block
+// position on it (measured: 4.2 ms per call at R = 800, VALU / LDS-issue bound, 5x its HBM time).  On the matrix cores
+// it is 0.4 TFLOP of fp16x3 per call -- a quarter of a millisecond -- and the kernel becomes the HBM stream it should be.
+// Block = 8 waves, one RoI, rounds of 256 positions; the waves change roles inside a round:
+//   A  wave w = POSITION GROUP w (32 positions): q rows are read in row layout (16 lanes x 16 B per row) and turned to
+//      the position-per-lane layout through the wave's LDS piece; lane (p, hh) owns the scores of tokens 2 tt + hh for
+//      all 8 heads, so the softmax needs one exchange with lane p + 32, and the probabilities of token 2 s + hh, heads
+//      0..7 ARE the B fragment of k step s (k = 16 s + 8 hh + h).  They go to LDS as fp16 (hi, lo) fragments, 16 bytes
+//      per lane -- over the same piece that turned the q rows.
+//   B  wave w = CHANNEL BLOCK w (32 of the 256 output channels): its Vp^T fragments (the A operand: 5 k steps x (hi, lo)
+//      = 40 registers) are built ONCE per block, straight into registers -- lane (c, hh) needs Vp[t = 2 s + hh][h][c] =
+//      v[t, head h] . Wo[c, head h], i.e. its own row of Wo and the RoI's T value rows; no Vp table in LDS.  Every wave
+//      multiplies ALL 8 position groups: O^T[g] = Vp^T P[g]^T, 8 x 5 x 3 MFMAs, B fragments by ds_read_b128.
+//      (The first version gave each wave all 256 channels of its own positions: 128 accumulators + 128 row-layout
+//      values + fragments streamed from LDS, ~250 spilled registers, slower than the VALU form.)
+//   C  in the accumulator layout (lane = position, 16 of the wave's 32 channels per half wave): + out_proj bias +
+//      residual, LayerNorm statistics as partial sums over the wave's 32 channels, combined across the 8 waves through
+//      LDS (two passes like rsp_layernorm: mean, then centred squares), normalise, fp16 planes out: 8 bytes per lane,
+//      the 4 stores of a lane complete its 64-byte plane row.
+constexpr int F2_THREADS = 512, F2_RPOS = 256, F2_POS = 1024;   // threads, positions per round, positions per block
 typedef float f32x16_t __attribute__((ext_vector_type(16)));
 
-template <int NKS>     // K steps of 16 = ceil(8 T / 16): T <= 8 -> 4, T <= 10 -> 5
+// NKS: K steps of 16 = ceil(8 T / 16): T <= 8 -> 4, T <= 10 -> 5.  RES_F32: the residual is an fp32 [rows, 256] tensor
+// (layer 0: the per-image source rows), else fp16 planes (layer 1: the previous layer's output).  Planes out only.
+template <int NKS, bool RES_F32>
 __global__ __launch_bounds__(F2_THREADS) void sam_i2t_fused_mfma_kernel(const I2tFusedP p) {
   constexpr int TT = 2 * NKS;                               // token slots (T <= TT)
-  constexpr int VP_PL = NKS * 8 * 32 * 32;                  // bytes of one Vp plane
-  // transposition piece of a wave: 32 rows of 64 floats, rows PADDED to 272 bytes -- conflict free for the 16-byte
-  // writes (8 rows per LDS cycle land 4 banks apart) and the position-per-lane reads, one 2-way conflict in 16 for the
-  // row reads; every address is base + row * 272 + constant (an XOR swizzle gave dozens of distinct lane-dependent
-  // addresses, all hoisted out of the position loop and spilled)
-  constexpr int TBR = 272, TBW = 32 * TBR;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * VP_PL + 8 * TBW + TT * W * 4 + 3 * CO * 4 + 64];
-  unsigned char* const sVh = smem;
-  unsigned char* const sVl = smem + VP_PL;
-  unsigned char* const tb_all = smem + 2 * VP_PL;
-  float* const sK = reinterpret_cast<float*>(smem + 2 * VP_PL + 8 * TBW);
-  float* const sBo = sK + TT * W;
+  // a wave's LDS piece: first the 32 x 64-float transposition rows (padded to 272 bytes: conflict free for the 16-byte
+  // row writes and the position-per-lane reads), then the P fragments of its position group ([k step][plane][lane] x 16 B)
+  constexpr int TBR = 272, TBW = 32 * TBR, PGB = NKS * 2 * 1024;
+  constexpr int REG = PGB > TBW ? PGB : TBW;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * REG + (2 * TT * W + 3 * CO + 2 * 8 * 8 * 32 + 16) * 4];
+  float* const sK = reinterpret_cast<float*>(smem + 8 * REG);
+  float* const sV = sK + TT * W;
+  float* const sBo = sV + TT * W;
   float* const sG = sBo + CO;
   float* const sB = sG + CO;
-  float* const sRed = sB + CO;
+  float* const sSum = sB + CO;                              // [group][wave][position]
+  float* const sSq = sSum + 8 * 8 * 32;
+  float* const sRed = sSq + 8 * 8 * 32;
   const int r = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, l31 = lane & 31;
   const int T = p.T, N = p.N;
   if (tid < CO) { sBo[tid] = p.bo[tid]; sG[tid] = p.gamma[tid]; sB[tid] = p.beta[tid]; }
-  for (int i = tid; i < TT * W; i += F2_THREADS)
-    sK[i] = i < T * W ? p.k[(int64_t)r * T * W + i] * (p.scale * LOG2E) : 0.f;
-  // ---- Vp[k][c] = sum_{d in head h} v[t][d] Wo[c][d]: 40 (32) values per thread, block maximum, planes ----
-  constexpr int NVP = NKS * 16 * CO / F2_THREADS;
-  float vp[NVP];
-  float vmax = 0.f;
+  for (int i = tid; i < TT * W; i += F2_THREADS) {
+    const bool ok = i < T * W;
+    sK[i] = ok ? p.k[(int64_t)r * T * W + i] * (p.scale * LOG2E) : 0.f;
+    sV[i] = ok ? p.v[(int64_t)r * T * W + i] : 0.f;
+  }
+  __syncthreads();
+  // ---- A fragments: Vp[t][h][c] = sum_{d in head h} v[t][d] Wo[c][d] for c = 32 wave + l31, t = 2 s + hh ----
+  half8_t ah[NKS], al[NKS];
+  float unscale;
+  {
+    float vp[NKS][8];
+    const float* wr = p.wo + (int64_t)(wave * 32 + l31) * W;
+    float vmax = 0.f;
 #pragma unroll
-  for (int n = 0; n < NVP; ++n) {
-    const int i = tid + n * F2_THREADS;
-    const int c = i & (CO - 1), k = i >> 8, h = k & 7, t = k >> 3;
-    float a = 0.f;
-    if (t < T) {
-      const float* wr = p.wo + (int64_t)c * W + h * DH;
-      const float* vr = p.v + ((int64_t)r * T + t) * W + h * DH;
+    for (int h = 0; h < 8; ++h) {
+      f32x4 w4[4];
 #pragma unroll
-      for (int d4 = 0; d4 < 4; ++d4) {
-        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wr + 4 * d4);
-        const f32x4 v4 = *reinterpret_cast<const f32x4*>(vr + 4 * d4);
-        a += w4[0] * v4[0] + w4[1] * v4[1] + w4[2] * v4[2] + w4[3] * v4[3];
+      for (int u = 0; u < 4; ++u) w4[u] = *reinterpret_cast<const f32x4*>(wr + h * DH + 4 * u);
+#pragma unroll
+      for (int s_ = 0; s_ < NKS; ++s_) {
+        const float* vr = sV + (2 * s_ + hh) * W + h * DH;
+        float a = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const f32x4 v4 = *reinterpret_cast<const f32x4*>(vr + 4 * u);
+          a += w4[u][0] * v4[0] + w4[u][1] * v4[1] + w4[u][2] * v4[2] + w4[u][3] * v4[3];
+        }
+        vp[s_][h] = a;
+        vmax = fmaxf(vmax, fabsf(a));
       }
     }
-    vp[n] = a;
-    vmax = fmaxf(vmax, fabsf(a));
-  }
-  vmax = rsp_wave_max(vmax);
-  if (lane == 0) sRed[wave] = vmax;
-  __syncthreads();
-  float bm = sRed[0];
+    vmax = rsp_wave_max(vmax);
+    if (lane == 0) sRed[wave] = vmax;
+    __syncthreads();
+    float bm = sRed[0];
 #pragma unroll
-  for (int w = 1; w < 8; ++w) bm = fmaxf(bm, sRed[w]);
-  // power-of-two scale that puts max |Vp| near 2^13 (hi stays far inside the fp16 range, lo stays normal)
-  int ve = 0;
-  if (bm > 0.f) { int ex; frexpf(bm, &ex); ve = 13 - ex; }
-  ve = max(-24, min(24, ve));
-  const float vs = ldexpf(1.0f, ve);
+    for (int w = 1; w < 8; ++w) bm = fmaxf(bm, sRed[w]);
+    // power-of-two scale that puts max |Vp| near 2^13 (hi stays far inside the fp16 range, lo stays normal)
+    int ve = 0;
+    if (bm > 0.f) { int ex; frexpf(bm, &ex); ve = 13 - ex; }
+    ve = max(-24, min(24, ve));
+    const float vs = ldexpf(1.0f, ve);
+    unscale = ldexpf(1.0f, -(14 + ve));
 #pragma unroll
-  for (int n = 0; n < NVP; ++n) {
-    const int i = tid + n * F2_THREADS;
-    const int c = i & (CO - 1), k = i >> 8;
-    const int s_ = k >> 4, kk = k & 15, j = c >> 5, cc = c & 31;
-    const int off = ((s_ * 8 + j) * 32 + cc) * 32 + ((((kk >> 3) ^ ((cc >> 3) & 1))) << 4) + (kk & 7) * 2;
-    half_t hi, lo;
-    rsp_split1(vp[n] * vs, hi, lo);
-    *reinterpret_cast<half_t*>(sVh + off) = hi;
-    *reinterpret_cast<half_t*>(sVl + off) = lo;
+    for (int s_ = 0; s_ < NKS; ++s_)
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        half_t a, b;
+        rsp_split1(vp[s_][h] * vs, a, b);
+        ah[s_][h] = a; al[s_][h] = b;
+      }
   }
-  __syncthreads();
-  const float unscale = ldexpf(1.0f, -(14 + ve));
   const int64_t qb = p.q_map ? p.q_map[r] : r;
   const int64_t rb = p.res_map ? p.res_map[r] : r;
-  unsigned char* const tb = tb_all + wave * TBW;            // this wave's transposition piece
+  unsigned char* const piece = smem + wave * REG;           // this wave's piece (phase A)
   const int p_blk = blockIdx.x * F2_POS;
+  const int lr0 = lane >> 4, c4 = (lane & 15) * 4;          // row layout: row g * 4 + lr0, columns c4 .. c4 + 3
+  const int ch0 = wave * 32 + 4 * hh;                       // phase C: this lane's channels are ch0 + 8 a + e
 
-  for (int grp = wave; grp < F2_POS / 32; grp += 8) {
-    const int p_base = p_blk + grp * 32;
-    if (p_base >= N) break;                                 // wave-uniform
-    asm volatile("" ::: "memory");                          // K / Vp stay in LDS: no hoisting of their reads out of the loop
-    // lane-constant addresses are RE-derived in every iteration from an opaque copy of the lane id: hoisted to the
-    // kernel entry, the dozens of them are spilled around this loop (cdna_hip_programming.md, persistent-attention note)
-    int lane_ = lane;
-    asm volatile("" : "+v"(lane_));
-    const int hh = lane_ >> 5, l31 = lane_ & 31;
-    const int lr0 = lane_ >> 4, c4 = (lane_ & 15) * 4;      // row layout: row g * 4 + lr0, columns c4 .. c4 + 3
-    unsigned char* const tb_row = tb + lr0 * TBR + c4 * 4;  // row layout: + g * 4 * TBR
-    unsigned char* const tb_pos = tb + l31 * TBR;           // position-per-lane layout: + unit * 16
-    const int a_off = l31 * 32 + ((hh ^ ((l31 >> 3) & 1)) << 4);
-    // ---- scores: s[tt][h] = q[pos, head h] . K[token 2 tt + hh, head h]  (log2 domain, scale folded into K) ----
-    float sc[NKS][8];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {                         // q rows, coalesced: 4 rows x 256 B per instruction
-        const int lr = g * 4 + lr0, pos = p_base + lr;
-        f32x4 x = {0.f, 0.f, 0.f, 0.f};
-        if (pos < N) x = *reinterpret_cast<const f32x4*>(p.q + (qb * N + pos) * (int64_t)W + half * 64 + c4);
-        *reinterpret_cast<f32x4*>(tb_row + g * 4 * TBR) = x;
-      }
-#pragma unroll
-      for (int hl = 0; hl < 4; ++hl) {
-        const int h = half * 4 + hl;
-        f32x4 qv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) qv[u] = *reinterpret_cast<const f32x4*>(tb_pos + (hl * 4 + u) * 16);
-#pragma unroll
-        for (int tt = 0; tt < NKS; ++tt) {
-          const float* kr = sK + (2 * tt + hh) * W + h * DH;
-          float a = 0.f;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const f32x4 kk = *reinterpret_cast<const f32x4*>(kr + 4 * u);
-            a += qv[u][0] * kk[0] + qv[u][1] * kk[1] + qv[u][2] * kk[2] + qv[u][3] * kk[3];
-          }
-          sc[tt][h] = (2 * tt + hh < T) ? a : -INFINITY;
-        }
-        __builtin_amdgcn_sched_barrier(0);                  // one head's K reads in flight at a time (register pressure)
-      }
-    }
-    // ---- softmax over the 2 NKS token slots of every head: 5 here, 5 in lane + 32; probabilities * 2^14, split ----
-    half8_t ph[NKS], pl[NKS];
+  for (int rd = 0; rd < F2_POS / F2_RPOS; ++rd) {
+    const int p_round = p_blk + rd * F2_RPOS;
+    if (p_round >= N) break;                                // block-uniform
+    asm volatile("" ::: "memory");                          // K stays in LDS: no hoisting of its reads out of the round loop
+    // ================= phase A: scores + softmax of position group `wave`, P fragments -> LDS =================
     {
-      float inv[8], mx[8];
+      const int p_base = p_round + wave * 32;
+      unsigned char* const tb_row = piece + lr0 * TBR + c4 * 4;     // row layout: + g * 4 * TBR
+      unsigned char* const tb_pos = piece + l31 * TBR;              // position-per-lane layout: + unit * 16
+      float sc[NKS][8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {                       // q rows, coalesced: 4 rows x 256 B per instruction
+          const int pos = min(p_base + g * 4 + lr0, N - 1);     // rows past N: a valid row, results never stored
+          const f32x4 x = *reinterpret_cast<const f32x4*>(p.q + (qb * N + pos) * (int64_t)W + half * 64 + c4);
+          *reinterpret_cast<f32x4*>(tb_row + g * 4 * TBR) = x;
+        }
+#pragma unroll
+        for (int hl = 0; hl < 4; ++hl) {
+          const int h = half * 4 + hl;
+          f32x4 qv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) qv[u] = *reinterpret_cast<const f32x4*>(tb_pos + (hl * 4 + u) * 16);
+#pragma unroll
+          for (int tt = 0; tt < NKS; ++tt) {
+            const float* kr = sK + (2 * tt + hh) * W + h * DH;
+            float a = 0.f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const f32x4 kk = *reinterpret_cast<const f32x4*>(kr + 4 * u);
+              a += qv[u][0] * kk[0] + qv[u][1] * kk[1] + qv[u][2] * kk[2] + qv[u][3] * kk[3];
+            }
+            sc[tt][h] = (2 * tt + hh < T) ? a : -INFINITY;
+          }
+          __builtin_amdgcn_sched_barrier(0);                // one head's K reads in flight at a time (register pressure)
+        }
+      }
+      // softmax over the 2 NKS token slots of every head: NKS here, NKS in lane + 32; probabilities * 2^14, split
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
         float m = sc[0][h];
@@ -496,104 +501,122 @@ __global__ __launch_bounds__(F2_THREADS) void sam_i2t_fused_mfma_kernel(const I2
 #pragma unroll
         for (int tt = 0; tt < NKS; ++tt) { sc[tt][h] = __builtin_amdgcn_exp2f(sc[tt][h] - m); sm += sc[tt][h]; }
         sm += __shfl_xor(sm, 32, 64);
-        mx[h] = m;
-        inv[h] = 16384.0f / sm;
+        const float inv = 16384.0f / sm;
+#pragma unroll
+        for (int tt = 0; tt < NKS; ++tt) sc[tt][h] *= inv;
       }
 #pragma unroll
-      for (int tt = 0; tt < NKS; ++tt)
+      for (int tt = 0; tt < NKS; ++tt) {
+        half8_t ph, pl;
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
           half_t a, b;
-          rsp_split1(sc[tt][h] * inv[h], a, b);
-          ph[tt][h] = a; pl[tt][h] = b;
+          rsp_split1(sc[tt][h], a, b);
+          ph[h] = a; pl[h] = b;
         }
-      (void)mx;
+        *reinterpret_cast<half8_t*>(piece + (tt * 2 + 0) * 1024 + lane * 16) = ph;
+        *reinterpret_cast<half8_t*>(piece + (tt * 2 + 1) * 1024 + lane * 16) = pl;
+      }
     }
-    // ---- O^T = Vp^T P^T (8 channel blocks x NKS steps x 3 passes), 64 channels at a time: the two accumulators of
-    //      a chunk go through the transposition piece to the row layout x[ch][g] (4 channels 64 ch + c4.. of row
-    //      g * 4 + lr0), where the out_proj bias and the residual are added.  One chunk in flight keeps the register
-    //      count at x (128) + 2 accumulators (32) + the P fragments (40). ----
+    __syncthreads();
+    // ================= phase B: O^T[g] = Vp^T (channel block `wave`) x P[g]^T for the 8 position groups =================
     f32x16_t acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int g = 0; g < 8; ++g) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
 #pragma unroll
       for (int s_ = 0; s_ < NKS; ++s_) {
-        const half8_t ah = *reinterpret_cast<const half8_t*>(sVh + (s_ * 8 + j) * 1024 + a_off);
-        const half8_t al = *reinterpret_cast<const half8_t*>(sVl + (s_ * 8 + j) * 1024 + a_off);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, ph[s_], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, pl[s_], acc[j], 0, 0, 0);
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ph[s_], acc[j], 0, 0, 0);
+        const half8_t bh = *reinterpret_cast<const half8_t*>(smem + g * REG + (s_ * 2 + 0) * 1024 + lane * 16);
+        const half8_t bl = *reinterpret_cast<const half8_t*>(smem + g * REG + (s_ * 2 + 1) * 1024 + lane * 16);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s_], bh, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bl, acc[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bh, acc[g], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_sched_barrier(0);                    // one group's fragments in registers at a time
     }
-    f32x4 x[4][8];
+    // ================= phase C: bias + residual, LayerNorm over the 256 channels (8 waves), planes out =================
+    // residual of group g + 1 requested before group g is processed (straight-line code: no branch, counted waits)
+    f32x4 rf[2][4];
+    half4_t rh[2][4], rl[2][4];
+    auto res_load = [&](int g, int b) {
+      const int pos = min(p_round + g * 32 + l31, N - 1);
+      if constexpr (RES_F32) {
+        const float* rp = p.res + (rb * N + pos) * (int64_t)CO + ch0;            // + 8 a: immediate offsets
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) {
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
+        for (int a = 0; a < 4; ++a) rf[b][a] = *reinterpret_cast<const f32x4*>(rp + 8 * a);
+      } else {
+        const int64_t ro = ((int64_t)wave * p.res_rows + (int64_t)r * N + pos) * 32 + 4 * hh;
 #pragma unroll
-      for (int jj = 0; jj < 2; ++jj)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const f32x4 v = {acc[2 * ch + jj][4 * q], acc[2 * ch + jj][4 * q + 1], acc[2 * ch + jj][4 * q + 2], acc[2 * ch + jj][4 * q + 3]};
-          *reinterpret_cast<f32x4*>(tb_pos + hh * 16 + (jj * 8 + 2 * q) * 16) = v * unscale;
+        for (int a = 0; a < 4; ++a) {
+          rh[b][a] = *reinterpret_cast<const half4_t*>(p.res_hi + ro + 8 * a);
+          rl[b][a] = *reinterpret_cast<const half4_t*>(p.res_lo + ro + 8 * a);
         }
-      const f32x4 bo4 = *reinterpret_cast<const f32x4*>(sBo + 64 * ch + c4);
-#pragma unroll
-      for (int g = 0; g < 8; ++g) {
-        const int lr = g * 4 + lr0;
-        const int pos = min(p_base + lr, N - 1);
-        f32x4 rsd;
-        if (p.res) {
-          rsd = *reinterpret_cast<const f32x4*>(p.res + (rb * N + pos) * (int64_t)CO + 64 * ch + c4);
-        } else {
-          const int col = 64 * ch + c4;
-          const int64_t ro = ((int64_t)(col >> 5) * p.res_rows + (int64_t)r * N + pos) * 32 + (col & 31);
-          const half4_t rh = *reinterpret_cast<const half4_t*>(p.res_hi + ro);
-          const half4_t rl = *reinterpret_cast<const half4_t*>(p.res_lo + ro);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) rsd[e] = ((float)rh[e] + (float)rl[e]) * p.res_inv_scale;
-        }
-        x[ch][g] = *reinterpret_cast<const f32x4*>(tb_row + g * 4 * TBR) + bo4 + rsd;
       }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    // ---- LayerNorm over the 256 channels of a row: 16 values here, the rest in the row's other 15 lanes ----
-    asm volatile("" ::: "memory");
+    };
+    res_load(0, 0);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
+      if (g + 1 < 8) res_load(g + 1, (g + 1) & 1);
       float sm = 0.f;
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch) sm += (x[ch][g][0] + x[ch][g][1]) + (x[ch][g][2] + x[ch][g][3]);
+      for (int a = 0; a < 4; ++a) {
+        const f32x4 bo4 = *reinterpret_cast<const f32x4*>(sBo + ch0 + 8 * a);
+        f32x4 rsd;
+        if constexpr (RES_F32) {
+          rsd = rf[g & 1][a];
+        } else {
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o, 64);
-      const float mean = sm * (1.0f / CO);
+          for (int e = 0; e < 4; ++e) rsd[e] = ((float)rh[g & 1][a][e] + (float)rl[g & 1][a][e]) * p.res_inv_scale;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float y = acc[g][4 * a + e] * unscale + bo4[e] + rsd[e];
+          acc[g][4 * a + e] = y;
+          sm += y;
+        }
+      }
+      sm += __shfl_xor(sm, 32, 64);
+      if (hh == 0) sSum[(g * 8 + wave) * 32 + l31] = sm;
+      __builtin_amdgcn_sched_barrier(0);                    // (the residual loads of all 8 groups at once would spill)
+    }
+    __syncthreads();
+    float mean[8];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += sSum[(g * 8 + w) * 32 + l31];
+      mean[g] = t * (1.0f / CO);
       float sq = 0.f;
 #pragma unroll
-      for (int ch = 0; ch < 4; ++ch)
+      for (int e = 0; e < 16; ++e) { const float dl = acc[g][e] - mean[g]; sq += dl * dl; }
+      sq += __shfl_xor(sq, 32, 64);
+      if (hh == 0) sSq[(g * 8 + wave) * 32 + l31] = sq;
+    }
+    __syncthreads();
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { const float dl = x[ch][g][e] - mean; sq += dl * dl; }
+    for (int g = 0; g < 8; ++g) {
+      float t = 0.f;
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) sq += __shfl_xor(sq, o, 64);
-      const float rstd = 1.0f / sqrtf(sq * (1.0f / CO) + p.eps);
-      const int pos = p_base + g * 4 + lr0;
+      for (int w = 0; w < 8; ++w) t += sSq[(g * 8 + w) * 32 + l31];
+      const float rstd = 1.0f / sqrtf(t * (1.0f / CO) + p.eps);
+      const int pos = p_round + g * 32 + l31;
       if (pos < N) {
         const int64_t orow = (int64_t)r * N + pos;
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
-          const f32x4 g4 = *reinterpret_cast<const f32x4*>(sG + 64 * ch + c4);
-          const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + 64 * ch + c4);
+        for (int a = 0; a < 4; ++a) {
+          const int ch = ch0 + 8 * a;
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(sG + ch);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + ch);
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (x[ch][g][e] - mean) * rstd * g4[e] + b4[e];
-          const int col = 64 * ch + c4;
-          if (p.out) *reinterpret_cast<f32x4*>(p.out + orow * CO + col) = o;
-          if (p.ohi) rsp_store_planes4(p.ohi, p.olo, ((int64_t)(col >> 5) * p.out_rows + orow) * 32 + (col & 31), o * p.pscale, false);
+          for (int e = 0; e < 4; ++e) o[e] = (acc[g][4 * a + e] - mean[g]) * rstd * g4[e] + b4[e];
+          rsp_store_planes4(p.ohi, p.olo, ((int64_t)wave * p.out_rows + orow) * 32 + (ch & 31), o * p.pscale, false);
         }
       }
     }
+    // (the next round's phase A writes the pieces, phase C the statistics: both behind this round's barriers)
   }
 }
 
@@ -649,15 +672,20 @@ extern "C" int rsp_sam_i2t_fused(const RspI2tFusedDesc* d, rsp_stream_t stream) 
   p.pscale = ldexpf(1.0f, RSP_PLANE_EXP(d->out_scale_log2)); p.out_rows = (int64_t)d->R * d->N;
   p.T = d->T; p.N = d->N; p.scale = d->scale;
   hipStream_t s = (hipStream_t)stream;
-  // The matrix-core form is correct (same unit tests) but not yet the faster one: 4.9 / 6.8 ms against 3.8 / 4.2 ms of
-  // the VALU form at R = 800 (profiles/r3_i2t_mfma_vs_valu.txt) -- hipcc spills ~250 registers around its position
-  // loop (800 B of scratch per lane), and with 156 KB of LDS one block per CU hides no latency.  Opt-in until that is
-  // fixed: RSP_I2T_MFMA=1.
-  const bool mfma_form = getenv("RSP_I2T_MFMA") != nullptr;      // read per call: the tests run both forms
+  // The matrix-core form is the product path (2.7 / 2.4 ms against 3.8 / 4.0 ms of the VALU form at R = 800, layer-0 /
+  // layer-1 arguments, profiles/r3_i2t_mfma_vs_valu.txt); it writes planes only, so a request for the fp32 copy of the
+  // result (tests) is served by the VALU form, which RSP_I2T_VALU=1 also selects (A/B runs; read per call).
+  const bool mfma_form = getenv("RSP_I2T_VALU") == nullptr && !d->out;
   if (mfma_form) {
     dim3 grid2((d->N + F2_POS - 1) / F2_POS, d->R);
-    if (d->T <= 8) hipLaunchKernelGGL((sam_i2t_fused_mfma_kernel<4>), grid2, dim3(F2_THREADS), 0, s, p);
-    else hipLaunchKernelGGL((sam_i2t_fused_mfma_kernel<5>), grid2, dim3(F2_THREADS), 0, s, p);
+    const bool f32res = d->res != nullptr;
+    if (d->T <= 8) {
+      if (f32res) hipLaunchKernelGGL((sam_i2t_fused_mfma_kernel<4, true>), grid2, dim3(F2_THREADS), 0, s, p);
+      else hipLaunchKernelGGL((sam_i2t_fused_mfma_kernel<4, false>), grid2, dim3(F2_THREADS), 0, s, p);
+    } else {
+      if (f32res) hipLaunchKernelGGL((sam_i2t_fused_mfma_kernel<5, true>), grid2, dim3(F2_THREADS), 0, s, p);
+      else hipLaunchKernelGGL((sam_i2t_fused_mfma_kernel<5, false>), grid2, dim3(F2_THREADS), 0, s, p);
+    }
     RSP_CHECK_LAUNCH();
     return RSP_OK;
   }

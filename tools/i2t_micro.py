@@ -1,6 +1,6 @@
 """rsp_sam_i2t_fused at the bench shape (R = 800 prompt sets, T = 10 tokens, N = 4096 positions), layer-0 form (per-image
 queries / residual through the RoI map) and layer-1 form (per-RoI plane residual): ms per call, GB/s of its algorithmic
-traffic.  RSP_I2T_MFMA=1 selects the round-3 matrix-core form (A/B).   python tools/i2t_micro.py [R]"""
+traffic.  RSP_I2T_VALU=1 selects the round-2 VALU form (A/B).   python tools/i2t_micro.py [R]"""
 import os
 import sys
 
@@ -37,6 +37,6 @@ pl0 = ops.sam_i2t_fused(q0, k, v, wo, bo, gamma, beta, q_map=roi_img, res=res0, 
 ms0 = timed(lambda: ops.sam_i2t_fused(q0, k, v, wo, bo, gamma, beta, q_map=roi_img, res=res0, res_map=roi_img, **kw))
 q1 = torch.randn(R * N, 128, device=dev)
 ms1 = timed(lambda: ops.sam_i2t_fused(q1, k, v, wo, bo, gamma, beta, res_planes=pl0, **kw))
-tag = 'MFMA (round 3, opt-in)' if os.environ.get('RSP_I2T_MFMA') else 'VALU (round 2, default)'
+tag = 'VALU (round 2, RSP_I2T_VALU=1)' if os.environ.get('RSP_I2T_VALU') else 'MFMA (round 3, default)'
 print(f'{tag}: layer-0 form {ms0:.3f} ms ({R * N * 1024 / ms0 / 1e6:.0f} GB/s written), layer-1 form {ms1:.3f} ms '
       f'({R * N * 2560 / ms1 / 1e6:.0f} GB/s moved); checksum {float(pl0.hi.float().abs().mean()):.6f} {float(pl0.lo.float().abs().mean()):.6f}')
