@@ -1,3 +1,4 @@
+// hipcc-flags: -mllvm -amdgpu-atomic-optimizer-strategy=None
 // fp16x3 GEMM, "two blocks per CU" persistent form (round 3).  Same arithmetic and the same plane operands as
 // gemm_dma.hip (a_lo*b_hi + a_hi*b_lo + a_hi*b_hi per 16 k, fp32 accumulate in v_mfma_f32_32x32x16_f16; results are
 // bit-identical to that kernel), other structure:
@@ -321,8 +322,16 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
     }
     // t = nk - 4: the last stage that still has a DMA to issue (nk - 1)
     step(f0, f1, cur, t, oc, on, T_{}, T_{}, std::integral_constant<int, NDMA>{}, T_{}); adv();
-    step(f1, f0, cur, t + 1, oc, on, T_{}, F_{}, std::integral_constant<int, NDMA>{}, F_{}); adv();
-    step(f0, f1, cur, t + 2, oc, on, T_{}, F_{}, std::integral_constant<int, 0>{}, T_{}); adv();
+    // The NEXT tile's ticket is drawn here, behind the tile's last DMA: the atomic's round trip to the L2 (about a
+    // microsecond, formerly exposed between the K loop and the epilogue) passes under the last three steps.  vmcnt retires
+    // in order, so the youngest operation may stay outstanding if the two remaining waits allow one more; every wave
+    // issues one (waves 1-3 on a scratch word) so that the immediates are the same for all of them.
+    unsigned tk = 0;
+    if (lane == 0)
+      tk = __hip_atomic_fetch_add(wave == 0 ? p.ticket + xcd : p.ticket + 12, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_sched_barrier(0);
+    step(f1, f0, cur, t + 1, oc, on, T_{}, F_{}, std::integral_constant<int, NDMA + 1>{}, F_{}); adv();
+    step(f0, f1, cur, t + 2, oc, on, T_{}, F_{}, std::integral_constant<int, 1>{}, T_{}); adv();
     // last stage: its fragments are in f1; once every wave holds its own the ring is free for the next tile
     __builtin_amdgcn_s_waitcnt(WC_LGKM0);
     __builtin_amdgcn_s_barrier();
@@ -336,7 +345,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
     // when the epilogue wave goes first.
     if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(3);
     const Tile done = cur;
-    id = draw();
+    if (tid == 0) *s_next = id_base + (int)tk;        // (the next write of this word is a whole tile of barriers away)
+    __syncthreads();
+    id = __builtin_amdgcn_readfirstlane(*s_next);
     const bool more = id < id_end;
     auto queue_next = [&]() {                         // the next tile's first three stages fly during the epilogue
       if (more) sfor<0, NS>([&](auto sc) { issue_stage(cur, decltype(sc)::value, decltype(sc)::value * STAGE); });
