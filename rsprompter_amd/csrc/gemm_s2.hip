@@ -72,7 +72,7 @@ __device__ __forceinline__ void sfor(F&& f) {
   }
 }
 
-// VAR (experiment switches; 0 = product): bit 0 = raised wave priority during the epilogue, bit 1 = epilogue without its stores (ablation), bit 2 = no DMA
+// VAR (experiment switches; 0 = product): bit 0 = result stores with the non-temporal hint (was: raised wave priority in the epilogue -- no effect), bit 1 = epilogue without its stores (ablation), bit 2 = no DMA
 // inside the K loop (ablation, garbage results), bit 3 = no epilogue (ablation), bit 4 = every DMA reads the first K block
 // (cache-hot sources: separates memory latency from issue / LDS-write cost; garbage results), bit 5 = time stamps
 template <int VAR, int EPI>
@@ -343,7 +343,6 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
     // the SIMD's arbiter gives the older wave's stream nearly every slot (measured, time stamps: the younger block's
     // epilogue took 145k cycles against 19k alone).  An MFMA stream needs one issue slot in 32 cycles: it loses little
     // when the epilogue wave goes first.
-    if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(3);
     const Tile done = cur;
     if (tid == 0) *s_next = id_base + (int)tk;        // (the next write of this word is a whole tile of barriers away)
     __syncthreads();
@@ -386,6 +385,9 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
       typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
       typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
       constexpr int NG = 8;                                   // read-back groups per 32-row pass: 4 rows x 64 columns
+      // VAR & 1 (experiment): results stored with the non-temporal hint -- they are not read again by this kernel and
+      // should not push operand lines out of the L2 (the K-streams of 64 concurrent tiles per XCD live there)
+      constexpr int ST_AUX = (VAR & 1) ? 2 : 0;
       const float alpha = d.alpha;
       const float cs = (EPI & E_PL) ? ldexpf(1.0f, RSP_PLANE_EXP(d.c_scale_log2)) : 1.0f;
       const int cols0 = done.n0 + wn * 64;                    // scalar: first column of this wave
@@ -484,7 +486,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
           const int cr = crow_of(ic, g);
           if constexpr ((EPI & E_C) && !(VAR & 2)) {
             const unsigned co = cr < 0 ? OOB : (unsigned)(((cr - (int)c_row0) * d.ldc + cols0 + c4) * 4);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x[g]), rC, co, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, x[g]), rC, co, 0, ST_AUX);
           }
           if constexpr (EPI & E_PL) {
             half4_t h4, l4;
@@ -499,15 +501,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
               asm volatile("" ::"v"(h4), "v"(l4));
             } else {
               const unsigned po = cr < 0 ? OOB : (unsigned)(cr * 64 + pl_lane);
-              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h4), rH, po, 0, 0);
-              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l4), rL, po, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h4), rH, po, 0, ST_AUX);
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l4), rL, po, 0, ST_AUX);
             }
           }
           if constexpr ((EPI & E_C) && (VAR & 2)) asm volatile("" ::"v"(x[g]));
         }
       });
     }
-    if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
     if constexpr (VAR & 32) {
       if (p.trace && tid == 0 && trace_n < 16) {
         unsigned long long* t = p.trace + ((size_t)blockIdx.x * 16 + trace_n) * 4;
@@ -603,13 +604,13 @@ int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s) {
   S2_CASE(0, E_PL | E_GELU);       // lin1
   S2_CASE(0, E_C | E_GELU);
   S2_CASE(0, E_GENERIC);
-  S2_CASE(1, E_C | E_RES); S2_CASE(1, E_PL | E_GELU);          // epilogue priority
+  S2_CASE(1, E_C | E_RES); S2_CASE(1, E_PL | E_GELU);          // non-temporal result stores
   S2_CASE(2, E_C | E_RES); S2_CASE(2, E_PL | E_GELU); S2_CASE(2, E_PL); S2_CASE(8, E_PL);   // no stores
   S2_CASE(4, E_C | E_RES); S2_CASE(4, E_PL | E_GELU);          // no DMA in the loop
   S2_CASE(8, E_C | E_RES); S2_CASE(8, E_PL | E_GELU);          // no epilogue
   S2_CASE(16, E_C | E_RES); S2_CASE(16, E_PL | E_GELU);        // cache-hot DMA sources
   S2_CASE(32, E_C | E_RES); S2_CASE(32, E_PL | E_GELU);        // time stamps
-  S2_CASE(33, E_C | E_RES); S2_CASE(33, E_PL | E_GELU);        // time stamps + epilogue priority
+  S2_CASE(33, E_C | E_RES); S2_CASE(33, E_PL | E_GELU);        // time stamps + non-temporal stores
   S2_CASE(1, E_C); S2_CASE(1, E_C | E_PL);
 #undef S2_CASE
   if (var != 0) return RSP_EINVAL;

@@ -36,6 +36,7 @@ def main():
     ap.add_argument('--batch', type=int, default=8)
     ap.add_argument('--iters', type=int, default=3)
     ap.add_argument('--what', default='gemm,attn,ln')
+    ap.add_argument('--only', default='', help='comma list of GEMM group names (default: all)')
     args = ap.parse_args()
     a = SAM_ARCH[args.arch]
     D, nh, mlp = a['hidden'], a['heads'], a['mlp']
@@ -52,21 +53,33 @@ def main():
         res = torch.randn(Mg, D, device=dev)
         mk = lambda n, k: ops.PackedWeight(torch.randn(n, k) / k ** 0.5, torch.randn(n) * 0.05, device=dev)
         w_qkv, w_proj, w_lin1, w_lin2 = mk(3 * D, D), mk(D, D), mk(mlp, D), mk(D, mlp)
-        o_qkvw = torch.empty(Mw, 3 * D, device=dev)
-        o_qkvg = torch.empty(Mg, 3 * D, device=dev)
         o_x = torch.empty(Mg, D, device=dev)
+        # the encoder's forms since round 3 (sam_encoder.py): the windowed qkv scatters its token rows to window order
+        # (the padded rows are a bias fill), the windowed proj gathers them back; q leaves as fp32, K | V as planes
+        g_, w_ = 64, 14
+        nw = (g_ + w_ - 1) // w_
+        idx = torch.arange(B * nw * nw * w_ * w_)
+        yy, xx = ((idx // (w_ * w_ * nw)) % nw) * w_ + (idx // w_) % w_, ((idx // (w_ * w_)) % nw) * w_ + idx % w_
+        real = (yy < g_) & (xx < g_)
+        t2w = torch.empty(Mg, dtype=torch.int64)
+        t2w[((idx // (w_ * w_ * nw * nw)) * g_ * g_ + yy * g_ + xx)[real]] = idx[real]
+        t2w = t2w.to(torch.int32).to(dev)
         cases = [
-            ('qkv_window', Mw, 3 * D, D, lambda: ops.gemm(xw, w_qkv, out=o_qkvw)),
-            ('qkv_global', Mg, 3 * D, D, lambda: ops.gemm(xg, w_qkv, out=o_qkvg)),
+            ('qkv_window_scatter', Mg, 3 * D, D,
+             lambda: ops.gemm(xg, w_qkv, c_rowmap=t2w, out_rows=Mw, out_planes=True, c_ncols=D, pl_col0=D)),
+            ('qkv_global', Mg, 3 * D, D, lambda: ops.gemm(xg, w_qkv, out_planes=True, c_ncols=D, pl_col0=D)),
+            ('proj_window_gather', Mg, D, D, lambda: ops.gemm(xw, w_proj, out=o_x, res=res, a_rowmap=t2w, M=Mg)),
             ('proj_global', Mg, D, D, lambda: ops.gemm(xg, w_proj, out=o_x, res=res)),
             ('lin1_gelu_planes', Mg, mlp, D, lambda: ops.gemm(xg, w_lin1, act=ops.ACT_GELU, out_planes=True, out_f32=False)),
             ('lin2_res', Mg, D, mlp, lambda: ops.gemm(xm, w_lin2, out=o_x, res=res)),
         ]
+        only = [s_ for s_ in args.only.split(',') if s_]
         for name, m, n, k, fn in cases:
+            if only and name not in only:
+                continue
             ms = timed(fn, args.iters)
-            print(json.dumps(dict(group=name, kernel='gemm_f16x3_dma_kernel', tile=ops._dma_tile_name(m, n, 0, False, k),
-                                  M=m, N=n, K=k, ms=round(ms, 4), tflops=round(2.0 * m * n * k / ms / 1e9, 1),
-                                  launches=args.iters + 1)), flush=True)
+            print(json.dumps(dict(group=name, kernel='gemm_f16x3_s2_kernel', tile='256x128', M=m, N=n, K=k, ms=round(ms, 4),
+                                  tflops=round(2.0 * m * n * k / ms / 1e9, 1), launches=args.iters + 1)), flush=True)
     if 'attn' in what:
         for name, Bp, S in (('attn_global', B, 64), ('attn_window', B * 25, 14)):
             Tt = S * S
