@@ -56,8 +56,9 @@ def _up_to_date(dig):
 def build(force=False, verbose=True):
     """Compile + link under an exclusive file lock: N ranks of `bench.py --gpus N` / torchrun that all find a stale
     library at import time must not run hipcc into the same object files or replace the .so while another rank is
-    dlopen()ing it.  The first rank builds (objects in a private directory, library and stamp moved into place with
-    os.replace, stamp last); the others block on the lock and then find the library up to date."""
+    dlopen()ing it.  The first rank builds (objects in `build/` -- only the lock holder writes there --, the library
+    linked to a temporary name and moved into place with os.replace, the stamp written last); the others block on the lock
+    and then find the library up to date."""
     import fcntl
     dig = _digest()
     if not force and _up_to_date(dig):
