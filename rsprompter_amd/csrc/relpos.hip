@@ -3,6 +3,7 @@
 //   rel[bh, t, 0:S] = q . Rh[qh - kh + S-1],  rel[bh, t, S:2S] = q . Rw[qw - kw + S-1]     (UNSCALED q)
 // Own translation unit because it wants the SLP vectorizer off: packing the FMAs of two table rows into
 // v_pk_fma_f32 makes the compiler keep {q, q} pairs of the whole query (hundreds of registers, spills).
+#include <stdlib.h>
 #include "rsp_common.h"
 
 namespace {
@@ -203,6 +204,113 @@ __global__ __launch_bounds__(256) void vit_relpos_win_kernel(const float* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Global layers (S = 32 | 64, tables of 2S-1 rows), round 3: the same matrix-core form.  The FMA kernel above spends
+// 2S x dh FMAs per query and head (10 GFLOP per ViT-H layer on the VALU: 0.65 ms, 6x the traffic floor of the q rows it
+// reads and the rel rows it writes).  A wave's 32 consecutive queries lie in ONE image row (32 | S), so
+//   rel_h[q, j] = Rh[qy + S-1 - j] . q   needs exactly the S table rows qy .. qy + S-1, wave-uniform: with the A rows taken
+//                                        in reverse order the accumulator IS rel_h^T (no Toeplitz gather),
+//   rel_w[q, j] = Rw[qx + S-1 - j] . q   needs rows qx0 .. qx0 + S + 30 for the wave (3 blocks of 32 at S = 64): G_w^T for
+//                                        those rows, then the per-query band through the wave's LDS piece.
+// Both results leave through the piece in row layout (S/4 lanes x 16 B per rel row and table: whole 256-byte runs).
+template <int DH>
+__global__ __launch_bounds__(256) void vit_relpos_glob_kernel(const float* __restrict__ qkv, const float* __restrict__ rph,
+                                                              const float* __restrict__ rpw, float* __restrict__ rel, int T,
+                                                              int S, int nh, int64_t tok_stride) {
+  constexpr int DSTEPS = DH / 16;
+  constexpr int LDT = DH + 8;                                  // halves per table row (conflict-free b128 reads)
+  constexpr int GS = 97;                                       // floats per query row of the piece (odd: conflict free)
+  __shared__ __attribute__((aligned(16))) half_t sTh[2][68 * LDT];    // Rh rows qyb .. qyb + S + 2 (hi, lo)
+  __shared__ __attribute__((aligned(16))) half_t sTw[2][128 * LDT];   // Rw, all 2S-1 rows (hi, lo), row 127 = 0
+  __shared__ float sG[4][32 * GS];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int hh = lane >> 5, l31 = lane & 31;
+  const int h = blockIdx.y;
+  const int nrow = 2 * S - 1;
+  const int64_t g0 = (int64_t)blockIdx.x * 128;                // first query row of the block (T % 128 == 0)
+  const int bp = (int)(g0 / T);
+  const int qb = (int)(g0 - (int64_t)bp * T);
+  const int qyb = qb / S;                                      // first image row of the block
+  const int nh_rows = S + 128 / S - 1;                         // Rh rows the block's waves need
+  const float ts = ldexpf(1.0f, RT);
+  for (int idx = tid; idx < (nh_rows + 128) * (DH / 4); idx += 256) {
+    const int r = idx / (DH / 4), c = idx - r * (DH / 4);
+    const bool is_w = r >= nh_rows;
+    const int tr = is_w ? r - nh_rows : qyb + r;               // table row
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (tr < nrow) v = *reinterpret_cast<const f32x4*>((is_w ? rpw : rph) + (int64_t)tr * DH + 4 * c);
+    half4_t hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { half_t a, b; rsp_split1(v[e] * ts, a, b); hi[e] = a; lo[e] = b; }
+    half_t* d0 = is_w ? &sTw[0][(r - nh_rows) * LDT + 4 * c] : &sTh[0][r * LDT + 4 * c];
+    half_t* d1 = is_w ? &sTw[1][(r - nh_rows) * LDT + 4 * c] : &sTh[1][r * LDT + 4 * c];
+    *reinterpret_cast<half4_t*>(d0) = hi;
+    *reinterpret_cast<half4_t*>(d1) = lo;
+  }
+  const int q0 = qb + wave * 32;                               // the wave's queries q0 .. q0 + 31: one image row
+  const int qy = q0 / S, qx0 = q0 - qy * S;
+  const int64_t row = g0 + wave * 32 + l31;
+  half8_t qh[DSTEPS], ql[DSTEPS];
+  {
+    const float qs = ldexpf(1.0f, RQ);
+    const float* src = qkv + row * tok_stride + (int64_t)h * DH;
+#pragma unroll
+    for (int st = 0; st < DSTEPS; ++st) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(src + st * 16 + hh * 8);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(src + st * 16 + hh * 8 + 4);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        half_t x, y;
+        rsp_split1(a[e] * qs, x, y); qh[st][e] = x; ql[st][e] = y;
+        rsp_split1(b[e] * qs, x, y); qh[st][4 + e] = x; ql[st][4 + e] = y;
+      }
+    }
+  }
+  __syncthreads();
+  const float unscale = ldexpf(1.0f, -(RQ + RT));
+  float* const piece = sG[wave];
+  float* const dst0 = rel + (((int64_t)bp * nh + h) * T + q0) * (2 * S);    // rel row of query q0 (row pitch 2S floats)
+  const int lpr = S >> 2;                                      // lanes per rel row and table (16 B each)
+  const int rpi = 64 / lpr;                                    // rows per store instruction
+  const int lr = lane / lpr, c4 = (lane - lr * lpr) * 4;
+  auto product = [&](const half_t* th, const half_t* tl, int row_of_l31, int nblk, int col0) {
+    // piece[q][col0 + 32 blk + m] = T[row(m)] . q for the nblk blocks of 32 table rows (row(m) given per lane by the caller)
+    for (int blk = 0; blk < nblk; ++blk) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int trow = row_of_l31 + (col0 < 0 ? -32 * blk : 32 * blk);
+#pragma unroll
+      for (int st = 0; st < DSTEPS; ++st) {
+        const int off = trow * LDT + st * 16 + hh * 8;
+        const half8_t a_h = *reinterpret_cast<const half8_t*>(th + off);
+        const half8_t a_l = *reinterpret_cast<const half8_t*>(tl + off);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l, qh[st], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, ql[st], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h, qh[st], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) piece[l31 * GS + 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hh] = acc[r] * unscale;
+    }
+  };
+  // ---- rel_h: A row m of block blk = Rh[qy + S-1 - (32 blk + m)] -> piece[q][j] = rel_h[q, j] ----
+  product(sTh[0], sTh[1], (qy - qyb) + S - 1 - l31, S / 32, -1);
+  for (int g = 0; g < 32; g += rpi) {
+    const int r_ = g + lr;
+    const float* pr = piece + r_ * GS + c4;
+    const f32x4 o = {pr[0], pr[1], pr[2], pr[3]};
+    *reinterpret_cast<f32x4*>(dst0 + (int64_t)r_ * (2 * S) + c4) = o;
+  }
+  // ---- rel_w: G_w^T for table rows qx0 .. qx0 + 32 nbw - 1, then rel_w[q, j] = piece[q][(q - q0) + S-1 - j] ----
+  product(sTw[0], sTw[1], qx0 + l31, (S + 62) / 32, 0);
+  for (int g = 0; g < 32; g += rpi) {
+    const int r_ = g + lr;
+    const float* pr = piece + r_ * GS + r_ + S - 1 - c4;
+    const f32x4 o = {pr[0], pr[-1], pr[-2], pr[-3]};
+    *reinterpret_cast<f32x4*>(dst0 + (int64_t)r_ * (2 * S) + S + c4) = o;
+  }
+}
+
 }  // namespace
 
 extern "C" int rsp_vit_relpos_q(const float* qkv, int64_t q_ld, const float* rel_pos_h, const float* rel_pos_w,
@@ -222,9 +330,19 @@ extern "C" int rsp_vit_relpos_q(const float* qkv, int64_t q_ld, const float* rel
     RSP_CHECK_LAUNCH();
     return RSP_OK;
   }
+  hipStream_t s = (hipStream_t)stream;
+  // global layers: matrix-core form (round 3); RSP_RELPOS_FMA=1 keeps the fp32 FMA kernel (A/B runs; read per call)
+  if ((S == 32 || S == 64) && (dh == 64 || dh == 80) && getenv("RSP_RELPOS_FMA") == nullptr) {
+    dim3 g3((unsigned)(rows_total / 128), nh, 1);              // T = S^2 is a multiple of 128
+    if (dh == 64)
+      hipLaunchKernelGGL((vit_relpos_glob_kernel<64>), g3, dim3(256), 0, s, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, tok_stride);
+    else
+      hipLaunchKernelGGL((vit_relpos_glob_kernel<80>), g3, dim3(256), 0, s, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, tok_stride);
+    RSP_CHECK_LAUNCH();
+    return RSP_OK;
+  }
   dim3 grid((unsigned)((rows_total + 63) / 64), nh, 1);
   const size_t smem = (size_t)(2 * (2 * S - 1)) * (dh + 4) * sizeof(float);
-  hipStream_t s = (hipStream_t)stream;
   if (dh == 64) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_relpos_kernel<64>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
