@@ -198,6 +198,15 @@ int rsp_vit_attention_planes(const float* q, int64_t q_ld, const uint16_t* kv_hi
                              int64_t kv_rows, int32_t kv_scale_log2, const float* rel, float* out, uint16_t* out_hi,
                              uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t S, int32_t nh, int32_t dh,
                              float scale, rsp_stream_t stream);
+/* ... with the window grid of window_partition (HF:900-922) known: the Bp windows are (image, wy, wx) over a            */
+/* win_per_side x win_per_side grid whose last row / column holds only win_real_last real rows / columns (64-grid, 14:    */
+/* 5 and 8).  Outputs of the padded tokens are NOT written (window_unpartition crops them); their keys / values take     */
+/* part as usual.  win_per_side = 0: every query is computed (= rsp_vit_attention_planes).                                */
+int rsp_vit_attention_planes_ex(const float* q, int64_t q_ld, const uint16_t* kv_hi, const uint16_t* kv_lo,
+                                int64_t kv_rows, int32_t kv_scale_log2, const float* rel, float* out,
+                                uint16_t* out_hi, uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t S,
+                                int32_t nh, int32_t dh, float scale, int32_t win_per_side, int32_t win_real_last,
+                                rsp_stream_t stream);
 /* rsp_vit_relpos with an explicit token stride of q (q rows of [Bp*T, q_ld], head h at column h*dh)                   */
 int rsp_vit_relpos_q(const float* q, int64_t q_ld, const float* rel_pos_h, const float* rel_pos_w, float* rel,
                      int32_t Bp, int32_t S, int32_t nh, int32_t dh, rsp_stream_t stream);

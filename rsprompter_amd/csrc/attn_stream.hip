@@ -95,6 +95,7 @@ struct AttnSP {
   bool out_f8;                                  // output planes in the cat8 format (plane format word)
   int T, S, nh, D;
   float scale;
+  int win_n, win_real;                          // windows per image side / real rows (columns) of the last one; 0: unknown
 };
 
 template <int DH, int NW, int KT, int NBUF, bool WINDOW>
@@ -125,8 +126,24 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   const int bp = (int)(lb / (unsigned)(nqb * nh));
   const int h = (int)(lb / (unsigned)nqb) - bp * nh;
   const int q0 = (int)(lb % (unsigned)nqb) * QB;
-  const int q = q0 + wave * 32 + l31;
-  const bool qv = q < T;
+  // Windows cut from a padded grid (HF:900-922): the windows of the last row / column hold only win_real real rows /
+  // columns; their padded tokens are keys like any other (k = v = bias) but nobody reads their outputs (window_unpartition
+  // crops them), so the real queries are packed into the first waves and the remaining waves only keep the block's
+  // barriers and DMA slots going.  win_n == 0 (grid unknown): every query is computed.
+  int q = q0 + wave * 32 + l31;
+  bool qv = q < T;
+  bool dead = false;
+  if constexpr (WINDOW) {
+    if (p.win_n > 0) {
+      const int wi = bp % (p.win_n * p.win_n);
+      const int wy = wi / p.win_n, wx = wi - wy * p.win_n;
+      const int rh = wy == p.win_n - 1 ? p.win_real : WS, cw = wx == p.win_n - 1 ? p.win_real : WS;
+      const int c = wave * 32 + l31, cy = c / cw;
+      qv = c < rh * cw;
+      q = cy * WS + (c - cy * cw);
+      dead = wave * 32 >= rh * cw;                   // wave-uniform
+    }
+  }
   const float* rel_b = p.rel + ((int64_t)bp * nh + h) * T * (2 * S);
   const int64_t row0 = (int64_t)bp * T;               // first row of this image / window in q, planes, out
 
@@ -257,6 +274,7 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
       if (nb >= NBUF) nb -= NBUF;
       issue_tile(kt + NBUF - 1, nb);
     }
+    if (dead) return;                                    // no real query in this wave (see above)
     const unsigned char* sb = &smem[buf][0];
     const half_t* sK0 = reinterpret_cast<const half_t*>(sb);
     const half_t* sK1 = reinterpret_cast<const half_t*>(sb + K_UNITS * 16);
@@ -438,10 +456,11 @@ int launch_stream(const AttnSP& p, int Bp, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int rsp_vit_attention_planes(const float* q, int64_t q_ld, const uint16_t* kv_hi, const uint16_t* kv_lo,
-                                        int64_t kv_rows, int32_t kv_scale_log2, const float* rel, float* out,
-                                        uint16_t* out_hi, uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp,
-                                        int32_t S, int32_t nh, int32_t dh, float scale, rsp_stream_t stream) {
+extern "C" int rsp_vit_attention_planes_ex(const float* q, int64_t q_ld, const uint16_t* kv_hi, const uint16_t* kv_lo,
+                                           int64_t kv_rows, int32_t kv_scale_log2, const float* rel, float* out,
+                                           uint16_t* out_hi, uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp,
+                                           int32_t S, int32_t nh, int32_t dh, float scale, int32_t win_per_side,
+                                           int32_t win_real_last, rsp_stream_t stream) {
   if (!q || !kv_hi || !kv_lo || !rel || Bp <= 0 || nh <= 0) return RSP_EINVAL;
   if (!out && !(out_hi && out_lo)) return RSP_EINVAL;
   if ((out_hi == nullptr) != (out_lo == nullptr)) return RSP_EINVAL;
@@ -456,8 +475,21 @@ extern "C" int rsp_vit_attention_planes(const float* q, int64_t q_ld, const uint
   p.out_pscale = ldexpf(1.0f, RSP_PLANE_EXP(out_scale_log2)); p.out_f8 = out_hi && RSP_PLANE_IS_F8(out_scale_log2);
   p.out_rows = (int64_t)Bp * S * S;
   p.T = S * S; p.S = S; p.nh = nh; p.D = D; p.scale = scale;
+  p.win_n = 0; p.win_real = 0;
+  if (S == 14 && win_per_side > 0) {
+    if (win_real_last < 1 || win_real_last > 14 || Bp % (win_per_side * win_per_side)) return RSP_EINVAL;
+    p.win_n = win_per_side; p.win_real = win_real_last;
+  }
   hipStream_t s = (hipStream_t)stream;
   if (dh == 64) return launch_stream<64>(p, Bp, s);
   if (dh == 80) return launch_stream<80>(p, Bp, s);
   return RSP_EINVAL;
+}
+
+extern "C" int rsp_vit_attention_planes(const float* q, int64_t q_ld, const uint16_t* kv_hi, const uint16_t* kv_lo,
+                                        int64_t kv_rows, int32_t kv_scale_log2, const float* rel, float* out,
+                                        uint16_t* out_hi, uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp,
+                                        int32_t S, int32_t nh, int32_t dh, float scale, rsp_stream_t stream) {
+  return rsp_vit_attention_planes_ex(q, q_ld, kv_hi, kv_lo, kv_rows, kv_scale_log2, rel, out, out_hi, out_lo, out_scale_log2,
+                                     Bp, S, nh, dh, scale, 0, 0, stream);
 }

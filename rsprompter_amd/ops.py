@@ -409,9 +409,11 @@ def vit_relpos(qkv, rel_pos_h, rel_pos_w, Bp, S, nh, dh, q_ld=None):
     return rel
 
 
-def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False, f8=False):
+def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False, f8=False, win_grid=None):
     """SAM ViT attention with q as fp32 rows [Bp*T, nh*dh] and K | V as the fp16 Planes [Bp*T, 2*nh*dh] the qkv GEMM
-    wrote (gemm(..., out_planes=True, c_ncols=D, pl_col0=D)).  planes=True: the output only as Planes."""
+    wrote (gemm(..., out_planes=True, c_ncols=D, pl_col0=D)).  planes=True: the output only as Planes.
+    win_grid=(windows per image side, real rows / columns of the last window): the outputs of the padded tokens of
+    window_partition are not computed (their rows of the result are left unwritten)."""
     lib = _lib.load()
     T, D = S * S, nh * dh
     if not isinstance(kv, Planes) or kv.shape[-1] != 2 * D or kv.rows < Bp * T:
@@ -423,11 +425,12 @@ def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False, f8=Fals
     if kv.f8:
         raise ValueError('K | V planes are consumed as fp16 hi / lo planes (qkv GEMM: out_f8=False)')
     kind = 'global' if T >= 1024 else 'window'
+    wn, wr = (int(win_grid[0]), int(win_grid[1])) if (win_grid is not None and S == 14) else (0, 0)
     _timed(f'attn_stream_kernel<vit,{kind}>', 4.0 * Bp * nh * T * T * dh, 0,
-           lambda: _lib.check(lib.rsp_vit_attention_planes(q.data_ptr(), q.stride(0), kv.hi.data_ptr(), kv.lo.data_ptr(),
-                                                           kv.rows, kv.scale_log2, rel.data_ptr(), _ptr(out), hi, lo, e,
-                                                           Bp, S, nh, dh, scale, _stream()),
-                              "rsp_vit_attention_planes"))
+           lambda: _lib.check(lib.rsp_vit_attention_planes_ex(q.data_ptr(), q.stride(0), kv.hi.data_ptr(), kv.lo.data_ptr(),
+                                                              kv.rows, kv.scale_log2, rel.data_ptr(), _ptr(out), hi, lo, e,
+                                                              Bp, S, nh, dh, scale, wn, wr, _stream()),
+                              "rsp_vit_attention_planes_ex"))
     return pl if planes else out
 
 

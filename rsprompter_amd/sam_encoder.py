@@ -216,7 +216,10 @@ class SamVisionEncoderHIP(HIPModule):
                 ops.fill_bias_rows(L['qkv'].bias, pad_rows, 3 * D, out=q, planes=kv, c_ncols=D, pl_col0=D)
                 rowmap = tok2win
             rel = ops.vit_relpos(q, L['rph'], L['rpw'], Bp, S, nh, dh, q_ld=D)
-            att = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=True, f8=f8)
+            # windows of the last grid row / column hold padding: only their real tokens are queries (the proj GEMM
+            # below gathers nothing else)
+            wg = None if S == g else (nw, g - (nw - 1) * S)
+            att = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=True, f8=f8, win_grid=wg)
             qkv = (q, kv)
             # proj + window_unpartition + crop + residual (HF:830, 924-952, 969): a row GATHER of the real tokens from
             # window order (the padded rows are never multiplied)

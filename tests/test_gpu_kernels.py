@@ -176,6 +176,39 @@ def test_vit_attention_planes(dev, S, nh, dh, Bp):
     assert float((_planes_to_f32(pl).view(Bp, T, D) - ref).abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize('nw,real,nh,dh,B', [(5, 8, 2, 80, 1), (3, 4, 3, 64, 2), (2, 14, 2, 80, 1)])
+def test_vit_attention_planes_skips_padded_queries(dev, nw, real, nh, dh, B):
+    """rsp_vit_attention_planes_ex with the window grid known (HF:900-922: 64-grid -> 5 x 5 windows, 8 real rows / columns
+    in the last ones; 32-grid -> 3 x 3, 4): the real tokens' outputs equal the plain kernel's / the fp64 restatement's,
+    padded tokens still act as keys, their own outputs are left unwritten."""
+    from rsprompter_amd import ops
+    S = 14
+    g = torch.Generator().manual_seed(700 + nw + dh)
+    Bp, T, D = B * nw * nw, S * S, nh * dh
+    qkv = torch.randn(Bp, T, 3, nh, dh, generator=g)
+    qkv[:, :, 0] *= 2.0
+    rph = torch.randn(2 * S - 1, dh, generator=g) * 0.2
+    rpw = torch.randn(2 * S - 1, dh, generator=g) * 0.2
+    scale = dh ** -0.5
+    ref, _ = _ref_vit_attention(qkv, rph, rpw, S, nh, dh, scale)
+    q = qkv[:, :, 0].reshape(Bp * T, D).contiguous().to(dev)
+    kv = ops.to_planes(qkv[:, :, 1:].reshape(Bp * T, 2 * D).contiguous().to(dev))
+    rel = ops.vit_relpos(q, rph.to(dev), rpw.to(dev), Bp, S, nh, dh, q_ld=D)
+    full = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale).view(Bp, S, S, D).cpu()
+    got = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, win_grid=(nw, real))
+    got = torch.nan_to_num(got, nan=7.0).view(Bp, S, S, D).cpu()          # unwritten rows hold whatever the allocator had
+    wi = torch.arange(Bp) % (nw * nw)
+    rh = torch.where(wi // nw == nw - 1, real, S)
+    cw = torch.where(wi % nw == nw - 1, real, S)
+    yy, xx = torch.arange(S)[None, :, None], torch.arange(S)[None, None, :]
+    is_real = (yy < rh[:, None, None]) & (xx < cw[:, None, None])           # [Bp, S, S]
+    assert int(is_real.sum()) == B * (S * (nw - 1) + real) ** 2
+    assert torch.equal(got[is_real], full[is_real])                         # same arithmetic, only the query -> lane map differs
+    assert float((got[is_real].double() - ref.view(Bp, S, S, D)[is_real]).abs().max()) < 2e-5
+    pl = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=True, win_grid=(nw, real))
+    assert float((_planes_to_f32(pl).view(Bp, S, S, D)[is_real] - ref.view(Bp, S, S, D)[is_real]).abs().max()) < 2e-5
+
+
 def test_gemm_column_range_outputs(dev):
     """rsp_gemm c_ncols / pl_col0 (the qkv projection's split hand-off): fp32 for the first D columns only, planes for
     the rest, with a row-gather map and padded rows like the windowed layers."""

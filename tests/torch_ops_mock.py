@@ -98,7 +98,7 @@ def vit_attention(qkv, rel, Bp, S, nh, dh, scale, planes=False):
     return (attn @ v).view(Bp, nh, T, dh).permute(0, 2, 1, 3).reshape(Bp * T, nh * dh)
 
 
-def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False, f8=False):
+def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False, f8=False, win_grid=None):
     T = S * S
     qkv = torch.cat([q.view(Bp * T, 1, nh * dh), kv.view(Bp * T, 2, nh * dh)], 1)
     return vit_attention(qkv.reshape(Bp * T, 3 * nh * dh), rel, Bp, S, nh, dh, scale)
