@@ -210,6 +210,12 @@ int rsp_vit_attention_planes_ex(const float* q, int64_t q_ld, const uint16_t* kv
 /* rsp_vit_relpos with an explicit token stride of q (q rows of [Bp*T, q_ld], head h at column h*dh)                   */
 int rsp_vit_relpos_q(const float* q, int64_t q_ld, const float* rel_pos_h, const float* rel_pos_w, float* rel,
                      int32_t Bp, int32_t S, int32_t nh, int32_t dh, rsp_stream_t stream);
+/* ... for a list of rows only (windowed layers): rows_map[n_rows] = the q / rel rows to compute, e.g. the real tokens  */
+/* of padded windows -- the rel rows of padded queries are never read once the attention skips them                     */
+/* (rsp_vit_attention_planes_ex).  rows_map = NULL: all Bp*S*S rows.                                                     */
+int rsp_vit_relpos_rows(const float* q, int64_t q_ld, const float* rel_pos_h, const float* rel_pos_w, float* rel,
+                        int32_t Bp, int32_t S, int32_t nh, int32_t dh, const int32_t* rows_map, int64_t n_rows,
+                        rsp_stream_t stream);
 /* (K as [key][dh], V transposed) inside `workspace` (rsp_vit_attention_global_ws_bytes) and the attention kernel   */
 /* streams them HBM -> LDS with the DMA engine.  Same semantics and outputs as rsp_vit_attention_ex.                */
 int64_t rsp_vit_attention_global_ws_bytes(int32_t Bp, int32_t S, int32_t nh, int32_t dh);

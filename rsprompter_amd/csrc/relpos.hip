@@ -117,13 +117,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 8))) voi
 // followed by the Toeplitz gather rel_h[q, j] = G_h[qy - j + S-1, q], rel_w[q, j] = G_w[qx - j + S-1, q] through a
 // per-wave LDS transpose.  28 of the 32 ViT-H layers are windowed; the FMA kernel above is LDS-read bound there.
 constexpr int RQ = 6, RT = 6;          // power-of-two operand scales (fp16 range), as in the attention kernels
+constexpr int WIN_ITERS = 4;           // groups of 128 queries per block of the window kernel
 
 template <int DH>
 __global__ __launch_bounds__(256) void vit_relpos_win_kernel(const float* __restrict__ qkv,
                                                              const float* __restrict__ rph,
                                                              const float* __restrict__ rpw,
                                                              float* __restrict__ rel, int T, int S, int nh,
-                                                             int64_t rows_total, int64_t tok_stride) {
+                                                             int64_t rows_total, int64_t tok_stride,
+                                                             const int32_t* __restrict__ rows_map) {
+  // rows_map (optional): the rows to process, e.g. the real tokens of padded windows (the rel rows of padded queries
+  // are never read once the attention skips them); rows_total then counts the map's entries.
+  // A block stages the two tables once and walks WIN_ITERS groups of 128 queries (the staging was 40 % of its work).
   constexpr int DSTEPS = DH / 16;
   constexpr int LDT = DH + 8;                                  // halves per table row (conflict-free b128 reads)
   __shared__ __attribute__((aligned(16))) half_t sT[2][2][32 * LDT];   // [table][hi/lo][idx][d]
@@ -144,9 +149,12 @@ __global__ __launch_bounds__(256) void vit_relpos_win_kernel(const float* __rest
     *reinterpret_cast<half4_t*>(&sT[tb][0][r * LDT + 4 * c]) = hi;
     *reinterpret_cast<half4_t*>(&sT[tb][1][r * LDT + 4 * c]) = lo;
   }
-  const int64_t g = ((int64_t)blockIdx.x * 4 + wave) * 32 + l31;
+  __syncthreads();
+  for (int it = 0; it < WIN_ITERS; ++it) {
+  const int64_t g = (((int64_t)blockIdx.x * WIN_ITERS + it) * 4 + wave) * 32 + l31;
+  if (((int64_t)blockIdx.x * WIN_ITERS + it) * 128 >= rows_total) break;          // block-uniform
   const bool ok = g < rows_total;
-  const int64_t gg = ok ? g : 0;
+  const int64_t gg = ok ? (rows_map ? (int64_t)rows_map[g] : g) : 0;
   const int q = (int)(gg % T);
   const int qy = q / S, qx = q - qy * S;
   // Q fragments (B operand): lane = query column, k slots 8hh..8hh+7 of every 16
@@ -166,7 +174,6 @@ __global__ __launch_bounds__(256) void vit_relpos_win_kernel(const float* __rest
       }
     }
   }
-  __syncthreads();
   const float unscale = ldexpf(1.0f, -(RQ + RT));
   const int64_t bpw = gg / T;                                  // window index: rel is [Bp*nh, T, 2S]
   float* dst = rel + ((bpw * nh + h) * T + q) * (2 * S);
@@ -202,6 +209,7 @@ __global__ __launch_bounds__(256) void vit_relpos_win_kernel(const float* __rest
     }
     __syncthreads();
   }
+  }   // it
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -313,23 +321,27 @@ __global__ __launch_bounds__(256) void vit_relpos_glob_kernel(const float* __res
 
 }  // namespace
 
-extern "C" int rsp_vit_relpos_q(const float* qkv, int64_t q_ld, const float* rel_pos_h, const float* rel_pos_w,
-                                float* rel, int32_t Bp, int32_t S, int32_t nh, int32_t dh, rsp_stream_t stream) {
+extern "C" int rsp_vit_relpos_rows(const float* qkv, int64_t q_ld, const float* rel_pos_h, const float* rel_pos_w,
+                                   float* rel, int32_t Bp, int32_t S, int32_t nh, int32_t dh, const int32_t* rows_map,
+                                   int64_t n_rows, rsp_stream_t stream) {
   const int64_t tok_stride = q_ld;
+  if (rows_map && (n_rows < 0 || n_rows > (int64_t)Bp * S * S || S > 16)) return RSP_EINVAL;   // row lists: windowed layers
   if ((q_ld & 3) || q_ld < (int64_t)nh * dh) return RSP_EINVAL;
   if (!qkv || !rel_pos_h || !rel_pos_w || !rel || Bp <= 0 || S <= 0 || S > 64 || nh <= 0)
     return RSP_EINVAL;
   const int T = S * S;
-  const int64_t rows_total = (int64_t)Bp * T;
+  const int64_t rows_total = rows_map ? n_rows : (int64_t)Bp * T;
+  if (rows_total == 0) return RSP_OK;
   if (S <= 16 && (dh == 64 || dh == 80)) {   // windowed layers: MFMA form
-    dim3 g2((unsigned)((rows_total + 127) / 128), nh, 1);
+    dim3 g2((unsigned)((rows_total + 128 * WIN_ITERS - 1) / (128 * WIN_ITERS)), nh, 1);
     if (dh == 64)
-      hipLaunchKernelGGL((vit_relpos_win_kernel<64>), g2, dim3(256), 0, (hipStream_t)stream, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total, tok_stride);
+      hipLaunchKernelGGL((vit_relpos_win_kernel<64>), g2, dim3(256), 0, (hipStream_t)stream, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total, tok_stride, rows_map);
     else
-      hipLaunchKernelGGL((vit_relpos_win_kernel<80>), g2, dim3(256), 0, (hipStream_t)stream, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total, tok_stride);
+      hipLaunchKernelGGL((vit_relpos_win_kernel<80>), g2, dim3(256), 0, (hipStream_t)stream, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, rows_total, tok_stride, rows_map);
     RSP_CHECK_LAUNCH();
     return RSP_OK;
   }
+  if (rows_map) return RSP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   // global layers: matrix-core form (round 3); RSP_RELPOS_FMA=1 keeps the fp32 FMA kernel (A/B runs; read per call)
   if ((S == 32 || S == 64) && (dh == 64 || dh == 80) && getenv("RSP_RELPOS_FMA") == nullptr) {
@@ -358,6 +370,11 @@ extern "C" int rsp_vit_relpos_q(const float* qkv, int64_t q_ld, const float* rel
   return RSP_OK;
 }
 
+
+extern "C" int rsp_vit_relpos_q(const float* qkv, int64_t q_ld, const float* rel_pos_h, const float* rel_pos_w,
+                                float* rel, int32_t Bp, int32_t S, int32_t nh, int32_t dh, rsp_stream_t stream) {
+  return rsp_vit_relpos_rows(qkv, q_ld, rel_pos_h, rel_pos_w, rel, Bp, S, nh, dh, nullptr, 0, stream);
+}
 
 extern "C" int rsp_vit_relpos(const float* qkv, const float* rel_pos_h, const float* rel_pos_w,
                               float* rel, int32_t Bp, int32_t S, int32_t nh, int32_t dh,

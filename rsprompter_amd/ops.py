@@ -329,7 +329,9 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
         d.Chi, d.Clo, d.c_scale_log2, d.c_rows = pl.hi.data_ptr(), pl.lo.data_ptr(), pl.word, rows
     d.c_ncols, d.pl_col0 = c_ncols, pl_col0
     if out is None and out_f32:
-        out = torch.empty((rows, c_ncols or n), dtype=torch.float32, device=a.device)
+        # (a scattered output leaves the rows nobody maps to unwritten: zeroed under the finite check, else never read)
+        alloc = torch.zeros if (DEBUG_FINITE and c_rowmap is not None) else torch.empty
+        out = alloc((rows, c_ncols or n), dtype=torch.float32, device=a.device)
     if out is not None:
         _chk_f32(out, "out")
     if bias == "auto":
@@ -398,14 +400,18 @@ def layernorm(x, gamma, beta, eps=1e-6, act=ACT_NONE, out=None, planes=False, f3
     return out
 
 
-def vit_relpos(qkv, rel_pos_h, rel_pos_w, Bp, S, nh, dh, q_ld=None):
-    """q_ld: row stride of the tensor holding q in its first nh*dh columns (default: the [.., 3, nh, dh] qkv matrix)."""
+def vit_relpos(qkv, rel_pos_h, rel_pos_w, Bp, S, nh, dh, q_ld=None, rows=None):
+    """q_ld: row stride of the tensor holding q in its first nh*dh columns (default: the [.., 3, nh, dh] qkv matrix).
+    rows (int32, windowed layers): only these q rows are evaluated (the real tokens of padded windows); the other rows of
+    the result stay unwritten."""
     lib = _lib.load()
     rel = torch.empty((Bp * nh, S * S, 2 * S), dtype=torch.float32, device=qkv.device)
     q_ld = 3 * nh * dh if q_ld is None else q_ld
+    n_rows = 0 if rows is None else int(rows.shape[0])
     _timed('vit_relpos_kernel', 2.0 * Bp * nh * S * S * 2 * S * dh, 0,
-           lambda: _lib.check(lib.rsp_vit_relpos_q(qkv.data_ptr(), q_ld, rel_pos_h.data_ptr(), rel_pos_w.data_ptr(),
-                                                   rel.data_ptr(), Bp, S, nh, dh, _stream()), "rsp_vit_relpos_q"))
+           lambda: _lib.check(lib.rsp_vit_relpos_rows(qkv.data_ptr(), q_ld, rel_pos_h.data_ptr(), rel_pos_w.data_ptr(),
+                                                      rel.data_ptr(), Bp, S, nh, dh, _ptr(rows), n_rows, _stream()),
+                              "rsp_vit_relpos_rows"))
     return rel
 
 

@@ -213,9 +213,11 @@ class SamVisionEncoderHIP(HIPModule):
                 Bp = B * nw * nw
                 q, kv = ops.gemm(xn, L['qkv'], c_rowmap=tok2win, out_rows=Bp * S * S, out_planes=True, c_ncols=D,
                                  pl_col0=D)
-                ops.fill_bias_rows(L['qkv'].bias, pad_rows, 3 * D, out=q, planes=kv, c_ncols=D, pl_col0=D)
+                # (only K | V: the q rows of padded tokens are never read -- rel-pos and attention below work on the real
+                # tokens only)
+                ops.fill_bias_rows(L['qkv'].bias, pad_rows, 3 * D, out=None, planes=kv, c_ncols=D, pl_col0=D)
                 rowmap = tok2win
-            rel = ops.vit_relpos(q, L['rph'], L['rpw'], Bp, S, nh, dh, q_ld=D)
+            rel = ops.vit_relpos(q, L['rph'], L['rpw'], Bp, S, nh, dh, q_ld=D, rows=rowmap)   # windowed: real tokens only
             # windows of the last grid row / column hold padding: only their real tokens are queries (the proj GEMM
             # below gathers nothing else)
             wg = None if S == g else (nw, g - (nw - 1) * S)

@@ -207,6 +207,14 @@ def test_vit_attention_planes_skips_padded_queries(dev, nw, real, nh, dh, B):
     assert float((got[is_real].double() - ref.view(Bp, S, S, D)[is_real]).abs().max()) < 2e-5
     pl = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=True, win_grid=(nw, real))
     assert float((_planes_to_f32(pl).view(Bp, S, S, D)[is_real] - ref.view(Bp, S, S, D)[is_real]).abs().max()) < 2e-5
+    # rel-pos terms for a row list (the real tokens, in any order): those rows equal the full evaluation bit for bit
+    rows = is_real.reshape(-1).nonzero()[:, 0]
+    rows = rows[torch.randperm(rows.numel(), generator=g)].to(torch.int32).to(dev)
+    rel_rows = ops.vit_relpos(q, rph.to(dev), rpw.to(dev), Bp, S, nh, dh, q_ld=D, rows=rows)
+    sel = is_real.reshape(Bp, T)[:, None, :].expand(Bp, nh, T).reshape(Bp * nh, T)
+    assert torch.equal(torch.nan_to_num(rel_rows.cpu(), nan=3.0)[sel], rel.cpu()[sel])
+    out2 = ops.vit_attention_planes(q, kv, rel_rows, Bp, S, nh, dh, scale, win_grid=(nw, real)).view(Bp, S, S, D).cpu()
+    assert torch.equal(out2[is_real], full[is_real])
 
 
 def test_gemm_column_range_outputs(dev):

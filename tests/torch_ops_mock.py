@@ -77,7 +77,7 @@ def layernorm(x, gamma, beta, eps=1e-6, act=0, out=None, planes=False, f32=True,
     return (y, y) if (planes and f32) else y
 
 
-def vit_relpos(qkv, rph, rpw, Bp, S, nh, dh, q_ld=None):
+def vit_relpos(qkv, rph, rpw, Bp, S, nh, dh, q_ld=None, rows=None):
     T = S * S
     if q_ld is not None and q_ld == nh * dh:
         q = qkv.view(Bp, T, nh, dh).permute(0, 2, 1, 3).reshape(Bp * nh, S, S, dh)
