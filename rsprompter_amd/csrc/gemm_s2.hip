@@ -535,7 +535,11 @@ int launch_s2(const RspGemmDesc& d, hipStream_t s) {
   p.ntiles = (int)nt;
   p.per_xcd = (p.ntiles + 7) / 8;
   p.group_m = (d.tile_hint >> 8) & 0xff;
-  if (p.group_m == 0) p.group_m = 8;
+  // tile order: groups of group_m M-tiles x all N-tiles, M fastest (the ~64 tiles an XCD runs at once then share
+  // group_m A panels and 64 / group_m W panels).  tools/gemm_s2_group_sweep.py on the ViT-H shapes: 8 is best for the
+  // K = 1280, N <= 3840 shapes, the wide lin1 (N = 5120) prefers 4 (+2.7 %), the long-K lin2 (K = 5120: an A panel is
+  // 5 MB) prefers 2 (+2.4 %)
+  if (p.group_m == 0) p.group_m = d.K >= 4096 ? 2 : (d.N >= 4096 ? 4 : 8);
   p.trace = g_s2_trace;
   p.ticket = tickets + (size_t)(slot++ % TICKET_SLOTS) * TICKET_WORDS;
   int nblk = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;     // a multiple of 8: every XCD gets nblk / 8 walkers
