@@ -25,6 +25,18 @@ if [ "$1" != "nopmc" ]; then
     find $P/$shape -name "*agent_info.csv" -delete
   done
 fi
+if [ "$1" != "nopmc" ]; then
+  # the two ViT attention kernels (+ rel-pos), same counters
+  P=$O/pmc; mkdir -p $P
+  timeout 300 python tools/pmc_suite.py --what attn > $P/manifest_attn.jsonl 2> $P/manifest_attn.err
+  for n in sq1 sq3; do
+    if [ $n = sq1 ]; then C="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU"; else C="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_WAVES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU"; fi
+    timeout 300 rocprofv3 --pmc $C --output-format csv -d $P/attn/$n -o r -- python tools/pmc_suite.py --what attn --iters 2 > $P/attn_$n.log 2>&1
+    echo "pass attn $n rc=$?"
+  done
+  python tools/pmc_report.py $P/attn --json $P/report_attn.json > $P/report_attn.txt 2>&1
+  find $P/attn -name "*agent_info.csv" -delete
+fi
 python - <<'PY'
 import json
 d=json.loads(open('gpurun_out/r3_final/bench_default.json').read().strip().splitlines()[-1])
