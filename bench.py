@@ -198,6 +198,8 @@ def main():
                     help="prompter variant; the headline line is 'anchor' (BASELINE.json configs[3])")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shapes', action='store_true', help='break the kernel table down by GEMM/attention shape')
+    ap.add_argument('--host-inputs', action='store_true',
+                    help='NOT the headline: the tiles start in pinned host memory every step (PCIe-inclusive rate for DESIGN.md)')
     ap.add_argument('--f8corr', action='store_true',
                     help='opt-in fast mode: encoder GEMMs as fp16 hi.hi + one fp8 correction MFMA (DESIGN.md section 3); '
                          'NOT the headline configuration -- parity margins are 8x smaller')
@@ -237,7 +239,8 @@ def main():
     num_classes = 10 if args.model == 'anchor' else 1
     model = build_model(args.arch, num_classes, dev, args.model)
     B = args.batch
-    imgs = [im.to(dev) for im in synth_images(B, seed=1234 + 1000 * rank)]
+    host_imgs = [im.pin_memory() for im in synth_images(B, seed=1234 + 1000 * rank)]
+    imgs = [im.to(dev) for im in host_imgs]
     metas = synth_metas(B)
 
     # N > 1: the result exchange of step i (records + COCO RLE strings of every instance, produced by device kernels and
@@ -250,7 +253,8 @@ def main():
 
     def step():
         samples = [DetDataSample(metainfo=dict(m)) for m in metas]
-        out = model.test_step(dict(inputs=imgs, data_samples=samples))
+        step_imgs = [im.to(dev, non_blocking=True) for im in host_imgs] if args.host_inputs else imgs
+        out = model.test_step(dict(inputs=step_imgs, data_samples=samples))
         res = [o.pred_instances for o in out]
         if world > 1:
             if pending[0] is not None:
@@ -323,7 +327,7 @@ def main():
             'vs_baseline': None,
             'dtype': 'f32 (fp32 in/out; GEMMs and attention as fp16x3 split-precision MFMA with fp32 accumulate'
                      + ('; --f8corr: encoder GEMMs as fp16 hi.hi + one fp8 (e4m3, MX block scales) correction MFMA)' if args.f8corr else ')'),
-            'data': 'synthetic',
+            'data': 'synthetic' + (' (tiles copied from pinned host memory every step: not the headline)' if args.host_inputs else ''),
             'config': {'workload': f'rsprompter_{args.model} SAM-ViT-{args.arch}, batch {B}x1024x1024 per GPU, '
                                    f'{num_classes} classes, seeded synthetic weights' + _config_tag(args, B, world),
                        'images_per_gpu_per_step': B, 'detections_per_step_rank0': n_dets,
