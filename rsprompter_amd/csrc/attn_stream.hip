@@ -28,6 +28,7 @@
 //     register-pipelined LDS fragment reads (kept), a software-pipelined tile loop with QK^T of tile t + 1 interleaved
 //     into the softmax of tile t by sched_group_barrier (ISA showed the interleave; 3.26 vs 3.13 ms, removed), and
 //     de-phasing the two waves of a SIMD (no change).  The remaining lever is fewer VALU instructions per score.
+#include <stdlib.h>
 #include <type_traits>
 #include "rsp_common.h"
 
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   const int hh = lane >> 5, l31 = lane & 31;
   const int T = p.T, S = p.S, nh = p.nh;
   const int QB = NW * 32;
-  const int nqb = WINDOW ? 1 : T / QB;
+  const int nqb = WINDOW ? (7 + NW - 1) / NW : T / QB;      // windows: 7 query groups of 32 (196 -> 224) over 7 / NW blocks
   const unsigned lb = WINDOW ? blockIdx.x : xcd_contig_s(blockIdx.x, gridDim.x);
   const int bp = (int)(lb / (unsigned)(nqb * nh));
   const int h = (int)(lb / (unsigned)nqb) - bp * nh;
@@ -138,10 +139,14 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
       const int wi = bp % (p.win_n * p.win_n);
       const int wy = wi / p.win_n, wx = wi - wy * p.win_n;
       const int rh = wy == p.win_n - 1 ? p.win_real : WS, cw = wx == p.win_n - 1 ? p.win_real : WS;
-      const int c = wave * 32 + l31, cy = c / cw;
+      const int c = q0 + wave * 32 + l31, cy = c / cw;
       qv = c < rh * cw;
       q = cy * WS + (c - cy * cw);
-      dead = wave * 32 >= rh * cw;                   // wave-uniform
+      dead = q0 + wave * 32 >= rh * cw;              // wave-uniform
+      if (q0 >= rh * cw) return;                     // block-uniform: a whole query block of padding (NW < 7)
+    } else {
+      dead = q0 + wave * 32 >= T;
+      if (q0 >= T) return;
     }
   }
   const float* rel_b = p.rel + ((int64_t)bp * nh + h) * T * (2 * S);
@@ -443,7 +448,12 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
 template <int DH>
 int launch_stream(const AttnSP& p, int Bp, hipStream_t s) {
   if (p.S == 14) {
-    hipLaunchKernelGGL((attn_stream_kernel<DH, 7, 32, 3, true>), dim3((unsigned)(Bp * p.nh)), dim3(448), 0, s, p);
+    // RSP_ATTN_WIN4=1 (experiment): two 4-wave blocks per (window, head) instead of one 7-wave block -- at dh = 80 the
+    // kernel needs 177 VGPRs, so only ONE 7-wave block fits a CU; two 4-wave blocks do, each with its own barriers
+    if (getenv("RSP_ATTN_WIN4") != nullptr)
+      hipLaunchKernelGGL((attn_stream_kernel<DH, 4, 32, 3, true>), dim3((unsigned)(Bp * p.nh * 2)), dim3(256), 0, s, p);
+    else
+      hipLaunchKernelGGL((attn_stream_kernel<DH, 7, 32, 3, true>), dim3((unsigned)(Bp * p.nh)), dim3(448), 0, s, p);
   } else {
     constexpr int NW = 8;
     if (p.T % (NW * 32) || p.T % 64) return RSP_EINVAL;
