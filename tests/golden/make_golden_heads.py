@@ -112,6 +112,28 @@ def main():
         bb.append(dict(roi=roi, cls_score=cls_score, bbox_pred=bbox_pred, img_shape=(1024, 1024), num_classes=nc,
                        score_thr=0.05, iou_thr=0.5, max_per_img=100, bboxes=r.bboxes, scores=r.scores, labels=r.labels))
     out['bbox_head_predict_single'] = bb
+    # ... with rescale=True (a RoI head without mask branch, e.g. SAMDet's Faster R-CNN detector: bbox_head.py:549-552
+    # multiplies the decoded, clipped boxes by fp32(1 / scale_factor) through the REAL scale_boxes BEFORE the NMS)
+    import sys as _sys
+    _sys.modules['mmdet.structures.bbox'].BaseBoxes = type('BaseBoxes', (), {})
+    tr = mg._load('mmdet/structures/bbox/transforms.py', '_ref_bbox_transforms')
+    bh.scale_boxes = tr.scale_boxes
+    bbr = []
+    for seed, (n, nc, sf) in enumerate(((300, 10, (2.56, 2.56)), (200, 1, (1.7, 2.3)), (500, 10, (0.8, 0.8)))):
+        g = torch.Generator().manual_seed(140 + seed)
+        fake_b = types.SimpleNamespace(bbox_coder=coder2, custom_cls_channels=False, reg_class_agnostic=False,
+                                       num_classes=nc, predict_box_type='hbox')
+        xy = torch.rand(n, 2, generator=g) * 800
+        roi = torch.cat([torch.zeros(n, 1), xy, xy + torch.rand(n, 2, generator=g) * 200 + 2], 1)
+        cls_score = torch.randn(n, nc + 1, generator=g) * 3
+        bbox_pred = torch.randn(n, nc * 4, generator=g)
+        cfg = Cfg(score_thr=0.05, nms=Cfg(type='nms', iou_threshold=0.5), max_per_img=100)
+        r = bh.BBoxHead._predict_by_feat_single(fake_b, roi, cls_score, bbox_pred,
+                                                dict(img_shape=(1024, 1024), scale_factor=sf), rescale=True, rcnn_test_cfg=cfg)
+        bbr.append(dict(roi=roi, cls_score=cls_score, bbox_pred=bbox_pred, img_shape=(1024, 1024), num_classes=nc,
+                        score_thr=0.05, iou_thr=0.5, max_per_img=100, scale_factor=sf, bboxes=r.bboxes, scores=r.scores,
+                        labels=r.labels))
+    out['bbox_head_predict_single_rescale'] = bbr
 
     # ------------------------------------------------------------------ RoI level mapping
     ext = mg._load('mmdet/models/roi_heads/roi_extractors/single_level_roi_extractor.py', '_ref_roi_ext')

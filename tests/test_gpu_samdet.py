@@ -110,6 +110,35 @@ def test_box_prompt_mask_post_and_scale_boxes(dev):
     assert torch.equal(ops.scale_boxes(b.to(dev), f).cpu(), b * torch.tensor(f, dtype=torch.float32))
 
 
+def test_bbox_post_matches_real_bbox_head_with_and_without_rescale(dev):
+    """rsp_bbox_post (+ rsp_scale_boxes, rsp_batched_nms) on the golden vectors of the REAL BBoxHead._predict_by_feat_single
+    (bbox_head.py:476-571; tests/golden/make_golden_heads.py): rescale=True multiplies by fp32(1 / scale_factor) before the
+    NMS -- labels and the kept set are exact, boxes and scores to fp32 rounding of the decode."""
+    import math
+    from rsprompter_amd import ops
+    g = torch.load(os.path.join(HERE, 'golden', 'reference_vectors_heads.pt'), weights_only=False)
+    for key in ('bbox_head_predict_single', 'bbox_head_predict_single_rescale'):
+        for c in g[key]:
+            n, nc = c['roi'].shape[0], c['num_classes']
+            LD = (5 * nc + 1 + 3) // 4 * 4
+            head = torch.zeros((n, LD))
+            head[:, :nc + 1] = c['cls_score']
+            head[:, nc + 1:5 * nc + 1] = c['bbox_pred']
+            sf = c.get('scale_factor')
+            out = ops.bbox_post(head.to(dev), LD, c['roi'].to(dev), torch.tensor([0, n]), torch.tensor([c['img_shape']],
+                                dtype=torch.float32, device=dev), nc, c['score_thr'], (0.1, 0.1, 0.2, 0.2),
+                                abs(math.log(16 / 1000)), c['iou_thr'], c['max_per_img'],
+                                scale_factors=None if sf is None else [sf])
+            k = int(out['count'][0])
+            assert k == c['labels'].shape[0], (key, sf)
+            pairs = match_detections(out['boxes'][0, :k].cpu(), out['scores'][0, :k].cpu(), out['ids'][0, :k].cpu().long(),
+                                     c['bboxes'], c['scores'], c['labels'])
+            assert len(pairs) == k
+            ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
+            assert _err(out['boxes'][0, :k].cpu()[ii], c['bboxes'][jj]) < 2e-3 and _err(out['scores'][0, :k].cpu()[ii], c['scores'][jj]) < 1e-6
+            assert int((ii != jj).sum()) <= 4                      # rank swaps only at score ties
+
+
 def test_resnet50_fpn_modules_match_real_classes(dev):
     """the HIP ResNet-50 + FPN modules on the inputs / weights of the golden run of the REAL mmdet classes."""
     from rsprompter_amd.samdet import FPN, ResNet

@@ -249,6 +249,14 @@ def test_detection_glue_restatements_match_reference_vectors():
                                                         c['num_classes'], c['score_thr'], c['iou_thr'], c['max_per_img'])
         assert torch.equal(dets[:, :4], c['bboxes']) and torch.equal(dets[:, 4], c['scores'])
         assert torch.equal(labels, c['labels'])
+    # rescale=True (mask-less RoI heads: SAMDet's detector): bbox_head.py:549-552 through the REAL scale_boxes -- bit-exact,
+    # which a division by the scale factor instead of the product with fp32(1 / s) would not be
+    for c in d['bbox_head_predict_single_rescale']:
+        dets, labels, _ = glue.bbox_head_predict_single(c['roi'], c['cls_score'], c['bbox_pred'], c['img_shape'],
+                                                        c['num_classes'], c['score_thr'], c['iou_thr'], c['max_per_img'],
+                                                        scale_factor=c['scale_factor'])
+        assert torch.equal(dets[:, :4], c['bboxes']) and torch.equal(dets[:, 4], c['scores'])
+        assert torch.equal(labels, c['labels'])
     m = d['map_roi_levels']
     assert torch.equal(glue.map_roi_levels(m['rois'], m['num_levels'], m['finest_scale']), m['out'])
 
