@@ -367,3 +367,9 @@ def test_samdet_end_to_end_host_logic(mocked):
     pi = out[0].pred_instances
     assert torch.equal(pi.labels, torch.tensor([3, 5])) and torch.equal(pi.scores, torch.ones(2))
     assert float((pi.masks != ref[0]['masks']).float().mean()) < 1e-3
+    # no detection at all (models.py:1163-1169): empty masks of the original size, no segmentor call
+    model.test_cfg = None
+    model.detector.roi_head.test_cfg = dict(model.detector.roi_head.test_cfg, score_thr=1.5)
+    out = model.test_step(dict(inputs=imgs, data_samples=[DetDataSample(metainfo=dict(metas[0]))]))
+    pi = out[0].pred_instances
+    assert pi.bboxes.shape == (0, 4) and pi.masks.dtype == torch.bool and tuple(pi.masks.shape) == (0, 512, 512)
