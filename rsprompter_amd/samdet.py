@@ -52,9 +52,9 @@ class ResNet(HIPModule):
         norm_type = (norm_cfg or dict(type='BN'))['type']
         if (in_channels != 3 or (stem_channels or base_channels) != 64 or base_channels != 64 or deep_stem or avg_down
                 or dcn is not None or plugins is not None or conv_cfg is not None or norm_type not in ('BN', 'SyncBN')
-                or any(d != 1 for d in dilations) or style not in ('pytorch', 'caffe')):
+                or any(d != 1 for d in dilations) or style != 'pytorch'):
             raise NotImplementedError('ResNet: only the configuration of configs/rsprompter/_base_/samdet.py:58-68 '
-                                      '(7x7 stem, 64 base channels, BN, no dilation / DCN / plugins) is implemented')
+                                      '(7x7 stem, 64 base channels, BN, style="pytorch", no dilation / DCN / plugins) is implemented')
         assert 1 <= num_stages <= 4 and max(out_indices) < num_stages
         self.depth, self.style, self.num_stages = depth, style, num_stages
         self.out_indices, self.strides = tuple(out_indices), tuple(strides[:num_stages])
@@ -108,7 +108,7 @@ class ResNet(HIPModule):
 
     def _block(self, x, pk, planes, stride):
         """resnet.py:268-300: relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1 x))))))) + identity)."""
-        s1, s2 = (1, stride) if self.style == 'pytorch' else (stride, 1)
+        s1, s2 = 1, stride                  # style='pytorch': the stride sits on the 3x3 conv (resnet.py:135-140)
         o, (B, H1, W1) = self._conv1x1(x, pk['c1'], s1, act=ops.ACT_RELU)
         H2, W2 = (H1 - 1) // s2 + 1, (W1 - 1) // s2 + 1
         o = ops.gemm(o.view(B, H1, W1, planes), pk['c2'], act=ops.ACT_RELU, conv=(3, s2, 1))
