@@ -153,6 +153,10 @@ int rsp_gemm(const RspGemmDesc* desc, rsp_stream_t stream);
 /* 1 when rsp_gemm serves this descriptor with the two-blocks-per-CU persistent kernel (csrc/gemm_s2.hip), 0 when with   */
 /* one of the csrc/gemm_dma.hip / gemm.hip tiles (profiler labels; no device work)                                       */
 int rsp_gemm_uses_s2(const RspGemmDesc* desc);
+/* -1 when rsp_gemm_uses_s2(desc) == 0, else the epilogue form that kernel runs for the descriptor: bit flags 1 = fp32     */
+/* residual, 2 = GELU, 4 = fp32 output, 8 = plane output, 16 = output row map; 64 = the run-time form that serves every    */
+/* other mode (tests assert which compile-time specialisation they exercise; no device work)                               */
+int rsp_gemm_s2_epilogue(const RspGemmDesc* desc);
 
 /* ------------------------------------------------------------------------ */
 /* LayerNorm over the last dim of a [rows, C] matrix (C % 4 == 0, C <= 2048). */

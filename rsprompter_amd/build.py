@@ -19,6 +19,10 @@ FLAGS = [
     "-ffp-contract=off",           # bit-stable box/IoU arithmetic (NMS parity with the CPU reference)
     "-Wno-unused-result",
 ]
+# development build (tools/gemm_s2_exp.py time|trace): also instantiates the GEMM's ablation variants, which compute
+# wrong results on purpose.  Part of the digest, so a product process never loads a development library.
+if os.environ.get("RSP_DEV_BUILD") == "1":
+    FLAGS.append("-DRSP_S2_ABLATIONS")
 
 
 def file_flags(src):

@@ -578,13 +578,10 @@ template <int DH>
 static int launch_attn_window(const AttnP& p, int B, hipStream_t s) {
   constexpr int KP = 224;
   const size_t smem = (size_t)2 * (KP * (DH + 8) + DH * (KP + 8)) * sizeof(half_t);
-  static bool configured = false;
-  if (!configured) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_window_kernel<DH>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return RSP_ELAUNCH;
-    configured = true;
-  }
+  // (a per-device attribute: set on every call, no cached "done" flag that would be wrong for a second device)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_window_kernel<DH>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+    return RSP_ELAUNCH;
   hipLaunchKernelGGL((attn_window_kernel<DH>), dim3(1, p.nh, B), dim3(448), smem, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;

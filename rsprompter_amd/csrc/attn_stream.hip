@@ -448,12 +448,9 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
 template <int DH>
 int launch_stream(const AttnSP& p, int Bp, hipStream_t s) {
   if (p.S == 14) {
-    // RSP_ATTN_WIN4=1 (experiment): two 4-wave blocks per (window, head) instead of one 7-wave block -- at dh = 80 the
-    // kernel needs 177 VGPRs, so only ONE 7-wave block fits a CU; two 4-wave blocks do, each with its own barriers
-    if (getenv("RSP_ATTN_WIN4") != nullptr)
-      hipLaunchKernelGGL((attn_stream_kernel<DH, 4, 32, 3, true>), dim3((unsigned)(Bp * p.nh * 2)), dim3(256), 0, s, p);
-    else
-      hipLaunchKernelGGL((attn_stream_kernel<DH, 7, 32, 3, true>), dim3((unsigned)(Bp * p.nh)), dim3(448), 0, s, p);
+    // (two 4-wave blocks per (window, head) were measured in round 3 and lost once the padded queries were skipped:
+    // profiles/r3_attn_window_7wave_vs_2x4wave.txt)
+    hipLaunchKernelGGL((attn_stream_kernel<DH, 7, 32, 3, true>), dim3((unsigned)(Bp * p.nh)), dim3(448), 0, s, p);
   } else {
     constexpr int NW = 8;
     if (p.T % (NW * 32) || p.T % 64) return RSP_EINVAL;

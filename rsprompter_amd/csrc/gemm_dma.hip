@@ -778,6 +778,14 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
 
 // which kernel rsp_gemm runs for a descriptor of the plane path (profiler labels, tools): 1 = gemm_s2 (two blocks per
 // CU, 256 x 128), 0 = one of this file's tiles
+int rsp_gemm_s2_epilogue_of(const RspGemmDesc& d);                     // gemm_s2.hip
+extern "C" int rsp_gemm_s2_epilogue(const RspGemmDesc* d) {
+  if (!d || !rsp_gemm_uses_s2(d)) return -1;
+  const int h = d->tile_hint & 0xff;
+  if (h >= 40 + 64) return 64;                                         // hint 104: the run-time epilogue, forced
+  return rsp_gemm_s2_epilogue_of(*d);
+}
+
 extern "C" int rsp_gemm_uses_s2(const RspGemmDesc* d) {
   if (!d || !(d->Ahi && d->Alo)) return 0;
   const int h = d->tile_hint & 0xff;

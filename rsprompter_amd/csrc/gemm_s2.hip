@@ -26,6 +26,7 @@
 // Scope: plain GEMMs of the plane path (row gather / scatter, bias, activation, fp32 or plane residual, fp32 and / or
 // plane outputs incl. column ranges).  Convolutions, ConvTranspose / fused-LayerNorm / hyper-network epilogues and the
 // fp8-corrected product stay with gemm_dma.hip.
+#include <atomic>
 #include <type_traits>
 #include "rsp_common.h"
 
@@ -56,9 +57,27 @@ unsigned long long* g_s2_trace = nullptr;
 // Tile tickets: the blocks of an XCD draw their tiles from that XCD's counter (one returning device-scope atomic per
 // tile, ~1 us against a ~100 us tile) instead of a static stride -- co-resident blocks do not run at the same speed (the
 // older wave of a SIMD wins the matrix pipe, the younger fills its gaps), a static split leaves the fast half idle at
-// the end.  Every launch takes the next of 64 slots; the last block to finish zeroes the slot again.
-constexpr int TICKET_SLOTS = 64, TICKET_WORDS = 16;
+// the end.  Every launch takes the next of TICKET_SLOTS slots (one 64-byte line each) of the CURRENT device's copy of
+// g_s2_tickets; the last block to finish zeroes the slot again.  Host side (launch_s2): ONE process-wide atomic slot
+// counter shared by all instantiations and host threads, the array's address looked up per device -- concurrent launches
+// (streams, host threads, several devices in one process) never share ticket words unless more than TICKET_SLOTS GEMMs
+// are in flight on one device at once.
+constexpr int TICKET_SLOTS = 1024, TICKET_WORDS = 16;
 __device__ unsigned g_s2_tickets[TICKET_SLOTS * TICKET_WORDS];
+std::atomic<unsigned> g_s2_slot{0};
+constexpr int S2_MAX_DEVICES = 64;
+std::atomic<unsigned*> g_s2_ticket_base[S2_MAX_DEVICES];
+
+unsigned* s2_ticket_base() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= S2_MAX_DEVICES) return nullptr;
+  unsigned* b = g_s2_ticket_base[dev].load(std::memory_order_acquire);
+  if (!b) {                       // (a race here looks the same address up twice)
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&b), HIP_SYMBOL(g_s2_tickets)) != hipSuccess) return nullptr;
+    g_s2_ticket_base[dev].store(b, std::memory_order_release);
+  }
+  return b;
+}
 
 // epilogue specialisations (EPI template argument): bit flags of what the tile's outputs need; E_GENERIC = everything at
 // run time (all modes of the descriptor, slow: branches per 4 outputs)
@@ -72,7 +91,8 @@ __device__ __forceinline__ void sfor(F&& f) {
   }
 }
 
-// VAR (experiment switches; 0 = product): bit 0 = result stores with the non-temporal hint (was: raised wave priority in the epilogue -- no effect), bit 1 = epilogue without its stores (ablation), bit 2 = no DMA
+// VAR (experiment switches; 0 = product, the only value instantiated unless the library is built with
+// -DRSP_S2_ABLATIONS -- the ablations compute WRONG results on purpose and do not belong into a shipped library): bit 0 = result stores with the non-temporal hint (was: raised wave priority in the epilogue -- no effect), bit 1 = epilogue without its stores (ablation), bit 2 = no DMA
 // inside the K loop (ablation, garbage results), bit 3 = no epilogue (ablation), bit 4 = every DMA reads the first K block
 // (cache-hot sources: separates memory latency from issue / LDS-write cost; garbage results), bit 5 = time stamps
 template <int VAR, int EPI>
@@ -524,9 +544,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
 
 template <int VAR, int EPI>
 int launch_s2(const RspGemmDesc& d, hipStream_t s) {
-  static unsigned slot = 0;
-  static unsigned* tickets = nullptr;
-  if (!tickets && hipGetSymbolAddress(reinterpret_cast<void**>(&tickets), HIP_SYMBOL(g_s2_tickets)) != hipSuccess) return RSP_ELAUNCH;
+  unsigned* const tickets = s2_ticket_base();
+  if (!tickets) return RSP_ELAUNCH;
   S2P p; p.d = d;
   p.fd_resmod = make_fastdiv(d.res_mod); p.fd_resb = make_fastdiv(d.res_brows);
   p.nbm = (d.M + BM - 1) / BM; p.nbn = (d.N + BN - 1) / BN;
@@ -541,7 +560,7 @@ int launch_s2(const RspGemmDesc& d, hipStream_t s) {
   // 5 MB) prefers 2 (+2.4 %)
   if (p.group_m == 0) p.group_m = d.K >= 4096 ? 2 : (d.N >= 4096 ? 4 : 8);
   p.trace = g_s2_trace;
-  p.ticket = tickets + (size_t)(slot++ % TICKET_SLOTS) * TICKET_WORDS;
+  p.ticket = tickets + (size_t)(g_s2_slot.fetch_add(1u, std::memory_order_relaxed) % TICKET_SLOTS) * TICKET_WORDS;
   int nblk = p.ntiles < 512 ? (p.ntiles + 7) / 8 * 8 : 512;     // a multiple of 8: every XCD gets nblk / 8 walkers
   hipLaunchKernelGGL((gemm_f16x3_s2_kernel<VAR, EPI>), dim3((unsigned)nblk), dim3(NTHR), 0, s, p);
   RSP_CHECK_LAUNCH();
@@ -585,13 +604,22 @@ static int s2_epilogue_of(const RspGemmDesc& d) {
 
 // 1: this kernel is the product choice for the descriptor (eligible, a specialised epilogue exists, enough tiles to fill
 // the 512 block slots once); 0: stay with gemm_dma.hip
+int rsp_gemm_s2_epilogue_of(const RspGemmDesc& d);
 int rsp_gemm_s2_auto(const RspGemmDesc& d) {
-  if (!rsp_gemm_s2_eligible(d)) return 0;
+  const int e = rsp_gemm_s2_epilogue_of(d);
+  const bool have = e >= 0 && e != E_GENERIC;
+  const long long nt = (long long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+  return have && nt >= 256 && d.K >= 128;
+}
+
+// tests / profiler labels: the epilogue form rsp_gemm_s2_dispatch(d, 0) runs (bit flags E_RES = 1, E_GELU = 2, E_C = 4,
+// E_PL = 8, E_RMAP = 16; 64 = the run-time form), -1 for a descriptor this kernel does not implement
+int rsp_gemm_s2_epilogue_of(const RspGemmDesc& d) {
+  if (!rsp_gemm_s2_eligible(d)) return -1;
   const int e = s2_epilogue_of(d);
   const bool have = e == E_C || e == (E_C | E_RES) || e == (E_C | E_RES | E_RMAP) || e == (E_C | E_PL) || e == (E_C | E_PL | E_RMAP) || e == E_PL ||
                     e == (E_PL | E_GELU) || e == (E_C | E_GELU);
-  const long long nt = (long long)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
-  return have && nt >= 256 && d.K >= 128;
+  return have ? e : E_GENERIC;
 }
 
 // var: experiment switches of the kernel (0 = product); the epilogue specialisation follows from the descriptor
@@ -608,6 +636,7 @@ int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s) {
   S2_CASE(0, E_PL | E_GELU);       // lin1
   S2_CASE(0, E_C | E_GELU);
   S2_CASE(0, E_GENERIC);
+#ifdef RSP_S2_ABLATIONS          /* tools/gemm_s2_exp.py time: RSP_DEV_BUILD=1 python -m rsprompter_amd.build */
   S2_CASE(1, E_C | E_RES); S2_CASE(1, E_PL | E_GELU);          // non-temporal result stores
   S2_CASE(2, E_C | E_RES); S2_CASE(2, E_PL | E_GELU); S2_CASE(2, E_PL); S2_CASE(8, E_PL);   // no stores
   S2_CASE(4, E_C | E_RES); S2_CASE(4, E_PL | E_GELU);          // no DMA in the loop
@@ -616,11 +645,13 @@ int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s) {
   S2_CASE(32, E_C | E_RES); S2_CASE(32, E_PL | E_GELU);        // time stamps
   S2_CASE(33, E_C | E_RES); S2_CASE(33, E_PL | E_GELU);        // time stamps + non-temporal stores
   S2_CASE(1, E_C); S2_CASE(1, E_C | E_PL);
+#endif
 #undef S2_CASE
   if (var != 0) return RSP_EINVAL;
-  if (epi & E_RMAP) return launch_s2<0, E_GENERIC>(d, s);
   return launch_s2<0, E_GENERIC>(d, s);       // any other combination of outputs
 }
 
+#ifdef RSP_S2_ABLATIONS
 // tools only (not part of include/rsp_hip.h): device buffer [512][16][4] u64 for the time-stamp variant
 extern "C" void rsp_debug_s2_trace(void* p) { g_s2_trace = reinterpret_cast<unsigned long long*>(p); }
+#endif

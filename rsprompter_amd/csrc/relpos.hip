@@ -343,8 +343,8 @@ extern "C" int rsp_vit_relpos_rows(const float* qkv, int64_t q_ld, const float* 
   }
   if (rows_map) return RSP_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  // global layers: matrix-core form (round 3); RSP_RELPOS_FMA=1 keeps the fp32 FMA kernel (A/B runs; read per call)
-  if ((S == 32 || S == 64) && (dh == 64 || dh == 80) && getenv("RSP_RELPOS_FMA") == nullptr) {
+  // global layers: matrix-core form (round 3); other grid sizes: the fp32 FMA kernel below
+  if ((S == 32 || S == 64) && (dh == 64 || dh == 80)) {
     dim3 g3((unsigned)(rows_total / 128), nh, 1);              // T = S^2 is a multiple of 128
     if (dh == 64)
       hipLaunchKernelGGL((vit_relpos_glob_kernel<64>), g3, dim3(256), 0, s, qkv, rel_pos_h, rel_pos_w, rel, T, S, nh, tok_stride);

@@ -157,13 +157,10 @@ extern "C" int rsp_resnet_stem(const float* x, const float* w, const float* bias
   if (B == 0) return RSP_OK;
   const int Ho = (H + 6 - 7) / 2 + 1, Wo = (W + 6 - 7) / 2 + 1;
   const size_t smem = (size_t)(ST_K * 64 + 3 * ST_PH * ST_PWP) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)smem) != hipSuccess)
-      return RSP_ELAUNCH;
-    attr_set = true;
-  }
+  // (a per-device attribute: set on every call, no cached "done" flag that would be wrong for a second device)
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_conv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)smem) != hipSuccess)
+    return RSP_ELAUNCH;
   dim3 grid((Wo + ST_TX - 1) / ST_TX, (Ho + ST_TY - 1) / ST_TY, B);
   if (grid.y > 65535u || grid.z > 65535u) return RSP_EINVAL;
   hipLaunchKernelGGL(stem_conv_kernel, grid, dim3(256), smem, (hipStream_t)stream, x, w, bias, y, H, W, Ho, Wo);

@@ -674,8 +674,8 @@ extern "C" int rsp_sam_i2t_fused(const RspI2tFusedDesc* d, rsp_stream_t stream) 
   hipStream_t s = (hipStream_t)stream;
   // The matrix-core form is the product path (2.7 / 2.4 ms against 3.8 / 4.0 ms of the VALU form at R = 800, layer-0 /
   // layer-1 arguments, profiles/r3_i2t_mfma_vs_valu.txt); it writes planes only, so a request for the fp32 copy of the
-  // result (tests) is served by the VALU form, which RSP_I2T_VALU=1 also selects (A/B runs; read per call).
-  const bool mfma_form = getenv("RSP_I2T_VALU") == nullptr && !d->out;
+  // result (tests, tools/i2t_micro.py) is served by the VALU form.
+  const bool mfma_form = !d->out;
   if (mfma_form) {
     dim3 grid2((d->N + F2_POS - 1) / F2_POS, d->R);
     const bool f32res = d->res != nullptr;

@@ -153,9 +153,6 @@ class PackedWeight:
         self.bias = None if bias is None else bias.detach().to(torch.float32).contiguous().to(device)
 
 
-# RSP_GEMM_RULE=r2: every GEMM by the round-2 tile rule (csrc/gemm_dma.hip) instead of the two-blocks-per-CU kernel
-# (csrc/gemm_s2.hip) -- A/B switch for tools and bench.py --gemm-r2; results are bit-identical either way
-GEMM_ROUND2_RULE = os.environ.get('RSP_GEMM_RULE', '') == 'r2'
 PLANE_F8 = 0x100        # include/rsp_hip.h "Plane format word"
 # Opt-in fast mode (RSP_F8CORR=1, or set ops.F8_CORR before the model is built / first run): the four big GEMMs of every
 # encoder block run fp16 hi.hi + ONE fp8 MFMA carrying both correction terms (2 units of matrix time instead of 3).
@@ -277,8 +274,11 @@ def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30, f8=False):
 def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, c_rowmap=None,
          M=None, out_rows=None, res_mod=0, a_scale_log2=DEFAULT_A_SCALE_LOG2, conv=None,
          res_bmap=None, res_brows=0, out_planes=False, out_f32=True, dma="auto", tile_hint=0, c_ncols=0, pl_col0=0,
-         out_f8=False):
+         out_f8=False, plan_only=False):
     """C = act(A @ W^T + bias) + res   (see RspGemmDesc in include/rsp_hip.h).
+
+    plan_only=True launches nothing and returns rsp_gemm_s2_epilogue(desc): -1 = a gemm_dma.hip / gemm.hip tile serves
+    the call, otherwise the epilogue form of gemm_f16x3_s2_kernel (tests assert which specialisation they exercise).
 
     a: [rows, K] fp32 (row stride = a.stride(0)) or, with conv=(k, stride, pad),
        an NHWC tensor [B, H, W, C].
@@ -356,12 +356,14 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.res_mod = res_mod
     d.res_bmap, d.res_brows = _ptr(res_bmap), res_brows
     d.b_rows = getattr(w, 'b_rows', 0)
-    d.tile_hint = tile_hint if (tile_hint or not GEMM_ROUND2_RULE) else 1
+    d.tile_hint = tile_hint
     if d.c_rows == 0:
         d.c_rows = rows          # also bounds C when rows are scattered (c_rowmap)
     d.act = act
     d.a_scale_log2 = plane_word(a_scale_log2, w_f8)
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
+    if plan_only:
+        return int(_lib_real.load().rsp_gemm_s2_epilogue(d)) if is_planes else -1
     tile = _dma_tile_name(m, n, tile_hint, conv is not None, w.K, w_f8) if is_planes else ('128x128' if n > 64 else ('128x64' if n > 32 else '128x32'))
     kname = ('gemm_f16f8_dma_kernel' if w_f8 else 'gemm_f16x3_dma_kernel') if is_planes else 'gemm_f16x3_kernel'
     if is_planes and _prof is not None and _lib_real.load().rsp_gemm_uses_s2(d):

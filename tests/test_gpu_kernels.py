@@ -723,15 +723,12 @@ def test_gemm_fp8_chain_with_rowmap_and_f8_output(dev):
 
 @pytest.mark.parametrize('form', ['valu', 'mfma'])
 @pytest.mark.parametrize('T,N,planes_res', [(10, 600, False), (10, 1024, True), (7, 520, True), (3, 64, False)])
-def test_sam_i2t_fused_matches_composition(dev, T, N, planes_res, form, monkeypatch):
+def test_sam_i2t_fused_matches_composition(dev, T, N, planes_res, form):
     """rsp_sam_i2t_fused = LayerNorm(residual + out_proj(image -> token attention)) (HF:340-348) against the fp64
     composition of the plain pieces: per-image queries / residual through RoI maps (layer 0) and per-RoI plane
     residual (layer 1); N not a multiple of the block's 512 positions; T on both kernel instantiations."""
     from rsprompter_amd import ops
-    if form == 'valu':        # the round-2 VALU form of the kernel (csrc/samattn.hip): same contract, kept for A/B runs
-        monkeypatch.setenv('RSP_I2T_VALU', '1')
-    else:
-        monkeypatch.delenv('RSP_I2T_VALU', raising=False)
+    # form 'valu': the request for an fp32 copy of the result is served by the VALU form of the kernel (csrc/samattn.hip)
     g = torch.Generator().manual_seed(100 + T)
     R, B = 5, 2
     roi_img = torch.tensor([0, 0, 1, 1, 1], dtype=torch.int32)
