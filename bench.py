@@ -30,28 +30,44 @@ PEAK_F16_MFMA_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, /opt/skills/guides/
 ATTN_GEMM_GFLOP_PER_IMAGE = {'base': 229.8, 'large': 353.6, 'huge': 481.3}   # SURVEY.md §8d / BASELINE.md §3
 
 
-def build_model(arch, num_classes, device, kind='anchor'):
+def bench_metas(n, kind, lora):
+    """configs[4] is quoted on WHU-shape tiles (512-px images resized x2: the mask logits go through the second resize
+    of RSMaskFormerFusionHead.predict); every other line uses plain 1024-px metas.  tests/golden/make_golden_bench.py
+    builds the canary goldens on the same metas."""
+    from rsprompter_amd.synth import synth_metas
+    if kind == 'query' and lora:
+        return synth_metas(n, ori_shape=(512, 512), scale_factor=(2.0, 2.0))
+    return synth_metas(n)
+
+
+def build_model(arch, num_classes, device, kind='anchor', lora=False):
     import rsprompter_amd as ra
-    from rsprompter_amd.default_configs import rsprompter_anchor, rsprompter_query
+    from rsprompter_amd.default_configs import rsprompter_anchor, rsprompter_query, rsprompter_query_lora
     from rsprompter_amd.synth import synth_state_dict
+    if lora and kind != 'query':
+        raise SystemExit('bench.py: --lora is the BASELINE.json configs[4] tree (rsprompter_query + LoRA): use --model query')
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        cfg = rsprompter_anchor(arch, num_classes) if kind == 'anchor' else rsprompter_query(arch, num_classes)
+        cfg = rsprompter_anchor(arch, num_classes) if kind == 'anchor' else (
+            rsprompter_query_lora(arch, num_classes) if lora else rsprompter_query(arch, num_classes))
         model = ra.build_model(cfg)
     model.load_state_dict(synth_state_dict(model, seed=0), strict=True)
     return model.to(device)
 
 
-def cpu_baseline(arch, num_classes, passes=3):
+def cpu_baseline(arch, num_classes, passes=3, kind='anchor', lora=False):
     """The reference path restated on the CPU (oracle/), timed on this box's host cores: SAME architecture as the
     GPU line, 1 warm-up + `passes` timed runs per stage (mmdet/utils/benchmark.py:208-244), one tile.
     Bounded sample: the ViT encoder is timed as patch-embed + ONE windowed layer + ONE global layer + neck and
     extrapolated by the layer counts (all windowed / all global layers have identical shapes); every other stage
-    (feature aggregator, FPN, RPN, RoI heads, SAM mask decoder, mask post-process) runs in full."""
+    (feature aggregator, FPN, then RPN, RoI heads, SAM mask decoder, mask post-process on the anchor path / the
+    Mask2Former prompter with its SAM decoder call and the fusion head on the query path) runs in full."""
     from oracle import glue
     from oracle.anchor import AnchorOracle
     from oracle import hf_sam
     from rsprompter_amd.synth import synth_images, synth_metas, synth_state_dict
+    if kind == 'query':
+        return _cpu_baseline_query(arch, num_classes, passes, lora)
 
     def timeit(fn):
         out = fn()                                   # warm-up
@@ -88,8 +104,14 @@ def cpu_baseline(arch, num_classes, passes=3):
         t_box, (dets, _) = timeit(lambda: o.bbox_predict(x_pe, [p['bboxes'] for p in props], metas))
         t_mask, _ = timeit(lambda: o.mask_predict(x_pe, dets, metas, emb, ipe))
         n_det = int(sum(d['bboxes'].shape[0] for d in dets))
+        # and ONE untimed-by-stage pass of the whole predict call (every layer really executed): the check on the
+        # extrapolated encoder figure
+        t = time.perf_counter()
+        o.predict(x, metas)
+        t_e2e = time.perf_counter() - t
     total = t_enc + t_agg + t_rpn + t_box + t_mask
     return dict(value=round(n / total, 5), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                end_to_end_s=round(t_e2e, 3), end_to_end_images_per_s=round(n / t_e2e, 5),
                 stages_s=dict(encoder=round(t_enc, 3), encoder_patch=round(t_patch, 3), encoder_window_layer=round(t_win, 3),
                               encoder_global_layer=round(t_glob, 3), encoder_neck=round(t_neck, 3),
                               neck=round(t_agg, 3), rpn=round(t_rpn, 3), bbox_head=round(t_box, 3), mask_head=round(t_mask, 3)),
@@ -99,7 +121,95 @@ def cpu_baseline(arch, num_classes, passes=3):
                        f'({n_det} prompt sets through the SAM decoder)')
 
 
-def parity_canary(model, imgs, metas, arch, kind):
+def _cpu_baseline_query(arch, num_classes, passes, lora):
+    from oracle import glue
+    from oracle import hf_sam
+    from oracle.query import QueryOracle, fusion_predict
+    from rsprompter_amd.synth import synth_images, synth_state_dict
+    import torch.nn.functional as F
+
+    def timeit(fn):
+        out = fn()
+        ts = []
+        for _ in range(passes):
+            t = time.perf_counter()
+            out = fn()
+            ts.append(time.perf_counter() - t)
+        return sum(ts) / len(ts), out
+
+    with torch.no_grad():
+        o = QueryOracle(arch, num_classes, 100, max_per_image=100, lora=dict(r=16, alpha=32) if lora else None)
+        o.load_state_dict(synth_state_dict(o, seed=0))
+        enc = o.backbone.vision_encoder
+        if lora:
+            enc = enc.base_model.model                    # peft's wrapping (oracle/vitsam.py PeftWrapped)
+        cfg = hf_sam.ARCH[arch]
+        depth, glob = cfg['num_hidden_layers'], list(cfg['global_attn_indexes'])
+        win = [i for i in range(depth) if i not in glob]
+        metas = bench_metas(1, 'query', lora)
+        x = glue.data_preprocess(synth_images(1), [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], True, 32)
+        first = lambda r: r[0] if isinstance(r, (tuple, list)) else r
+        t_patch, h0 = timeit(lambda: enc.patch_embed(x) + enc.pos_embed)
+        t_win, h1 = timeit(lambda: first(enc.layers[win[0]](h0)))
+        t_glob, h2 = timeit(lambda: first(enc.layers[glob[0]](h1)))
+        t_neck, emb = timeit(lambda: enc.neck(h2))
+        t_enc = t_patch + len(win) * t_win + len(glob) * t_glob + t_neck
+        hidden = tuple([h0] + [(h1, h2)[i % 2] for i in range(depth)])
+        G = o.shared_image_embedding.shared_image_embedding.positional_embedding
+        ipe = glue.image_wide_positional_embeddings(G, emb.shape[-1]).repeat(emb.shape[0], 1, 1, 1)
+        t_agg, feats = timeit(lambda: o.neck.feature_spliter(o.neck.feature_aggregator(hidden)))
+        t_head, (cls, mask, _) = timeit(lambda: o.panoptic_head(feats, emb, ipe))
+
+        def fuse():
+            up = F.interpolate(mask, size=tuple(metas[0]['batch_input_shape'][:2]), mode='bilinear', align_corners=False)
+            return fusion_predict(cls, up, metas, num_classes, 100, True)
+        t_fuse, _ = timeit(fuse)
+        t = time.perf_counter()
+        o.predict(x, metas)                                   # one pass of the whole predict call, every layer executed
+        t_e2e = time.perf_counter() - t
+    total = t_enc + t_agg + t_head + t_fuse
+    return dict(value=round(1 / total, 5), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                end_to_end_s=round(t_e2e, 3), end_to_end_images_per_s=round(1 / t_e2e, 5),
+                stages_s=dict(encoder=round(t_enc, 3), encoder_patch=round(t_patch, 3), encoder_window_layer=round(t_win, 3),
+                              encoder_global_layer=round(t_glob, 3), encoder_neck=round(t_neck, 3),
+                              neck=round(t_agg, 3), query_head=round(t_head, 3), fusion_head=round(t_fuse, 3)),
+                sample=f'1 x 1024x1024 tile, CPU oracle (fp32 PyTorch, HF SAM eager attention), SAM-ViT-{arch}'
+                       + (' + LoRA(qkv, r16) unmerged' if lora else '') +
+                       f'; 1 warm-up + {passes} timed passes per stage; encoder = patch + {len(win)} x windowed layer + '
+                       f'{len(glob)} x global layer + neck from one timed layer of each kind; pixel decoder, masked decoder, '
+                       f'SAM mask decoder (100 prompt sets) and fusion head in full')
+
+
+def canary_name(kind, arch, lora):
+    return f'bench_canary_{kind}_{arch}' + ('_lora' if lora else '') + '.pt'
+
+
+def _parity_canary_query(model, res, out, path):
+    """query path: class logits and SAM mask logits of ALL Nq queries of tile 0 (no selection involved).  A query whose
+    thresholded attention mask differs from the fp32 oracle's in one bit moves by more than 1e-3 -- for the reference's
+    own fp32 forward as well -- so `ok` holds every query to 1e-2 and all but 4 to 1e-3."""
+    g = torch.load(path, map_location='cpu', weights_only=True)
+    out['golden'] = os.path.relpath(path, ROOT)
+    emb = model._last_embeddings
+    out['image_embedding_max_abs_err'] = float((emb[0, :, ::8, ::8].float().cpu() - g['embedding_sample']).abs().max())
+    cls, lazy = model._last_head_out
+    low = lazy.low_res.detach().float().cpu()                 # [B, Nq, 256, 256]
+    per_q = (low[0, :, ::16, ::16] - g['low_res_sample']).abs().flatten(1).amax(1)
+    out['class_logit_max_abs_err'] = float((cls[0].detach().float().cpu() - g['cls_pred']).abs().max())
+    out['mask_logit_max_abs_err'] = float(per_q.max())
+    out['mask_logit_err_5th_largest'] = float(per_q.sort(descending=True).values[min(4, per_q.numel() - 1)])
+    out['queries_within_1e-3'] = f'{int((per_q < 1e-3).sum())}/{per_q.numel()}'
+    same = res[0].pred_instances.query_indices.cpu().long() == g['query_indices']
+    out['query_indices_equal'] = f'{int(same.sum())}/{same.numel()}'
+    out['mask_logit_range'] = g['low_res_absmax']
+    out['tolerance'] = 1e-3
+    out['ok'] = bool(out['finite'] and out['image_embedding_max_abs_err'] < 1e-3 and out['class_logit_max_abs_err'] < 1e-3
+                     and int((per_q < 1e-3).sum()) >= per_q.numel() - 4 and float(per_q.max()) < 1e-2
+                     and int(same.sum()) >= same.numel() - 4)
+    return out
+
+
+def parity_canary(model, imgs, metas, arch, kind, lora=False):
     """One extra step OUTSIDE the timed region on the bench's own inputs, tile 0 compared with the CPU oracle's answer
     for exactly this fixture (tests/golden/bench_canary_anchor_<arch>.pt, written by tests/golden/make_golden_bench.py;
     nothing under oracle/ is imported here).  Reports whether every output of the step is finite, the max-abs error
@@ -126,7 +236,9 @@ def parity_canary(model, imgs, metas, arch, kind):
             if low is not None:
                 fin &= bool(torch.isfinite(low).all())
         out['finite'] = bool(fin)
-        path = os.path.join(ROOT, 'tests', 'golden', f'bench_canary_{kind}_{arch}.pt')
+        path = os.path.join(ROOT, 'tests', 'golden', canary_name(kind, arch, lora))
+        if kind == 'query' and os.path.exists(path):
+            return _parity_canary_query(model, res, out, path)
         if kind != 'anchor' or not os.path.exists(path) or low is None:
             return out
         g = torch.load(path, map_location='cpu', weights_only=True)
@@ -163,7 +275,7 @@ def _pmc_traffic(arch):
     process, so the number is the one measured with tools/pmc_round2.sh on the kernel's most expensive shape of this
     architecture; None when no pass exists for it."""
     root = os.path.dirname(os.path.abspath(__file__))
-    for rel in (f'profiles/r3_pmc/gemm_traffic_{arch}.json', f'profiles/r2_pmc/gemm_traffic_{arch}.json', 'profiles/r1_pmc/gemm_lin1_traffic.json'):
+    for rel in (f'profiles/r4_pmc/gemm_traffic_{arch}.json', f'profiles/r3_pmc/gemm_traffic_{arch}.json', f'profiles/r2_pmc/gemm_traffic_{arch}.json', 'profiles/r1_pmc/gemm_lin1_traffic.json'):
         try:
             with open(os.path.join(root, rel)) as fh:
                 t = json.load(fh)
@@ -184,6 +296,9 @@ def _config_tag(args, B, world):
         return ' (BASELINE.json configs[1])'
     if args.model == 'query' and args.arch == 'large' and B == 16 and world == 1:
         return ' (BASELINE.json configs[2])'
+    if args.model == 'query' and args.arch == 'huge' and B == 4 and args.lora:
+        return (' (BASELINE.json configs[4]: batch 32 over 8 GPUs, WHU-shape metas)' if world == 8 else
+                f' (the per-GPU slice of BASELINE.json configs[4] on {world} GPU' + ('s' if world > 1 else '') + ', WHU-shape metas)')
     return ''
 
 
@@ -196,6 +311,9 @@ def main():
     ap.add_argument('--batch', type=int, default=8, help='images per GPU per step')
     ap.add_argument('--model', default='anchor', choices=['anchor', 'query'],
                     help="prompter variant; the headline line is 'anchor' (BASELINE.json configs[3])")
+    ap.add_argument('--lora', action='store_true',
+                    help='--model query only: LoRA(qkv, r16, alpha32) adapters on the encoder and WHU-shape metas '
+                         '(BASELINE.json configs[4]: --model query --arch huge --batch 4 --lora)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--shapes', action='store_true', help='break the kernel table down by GEMM/attention shape')
     ap.add_argument('--host-inputs', action='store_true',
@@ -237,11 +355,11 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device('cuda', local)
     num_classes = 10 if args.model == 'anchor' else 1
-    model = build_model(args.arch, num_classes, dev, args.model)
+    model = build_model(args.arch, num_classes, dev, args.model, args.lora)
     B = args.batch
     host_imgs = [im.pin_memory() for im in synth_images(B, seed=1234 + 1000 * rank)]
     imgs = [im.to(dev) for im in host_imgs]
-    metas = synth_metas(B)
+    metas = bench_metas(B, args.model, args.lora)
 
     # N > 1: the result exchange of step i (records + COCO RLE strings of every instance, produced by device kernels and
     # gathered to rank 0 like mmengine collect_results: rsprompter_amd/dist.py::gather_results) is queued completely --
@@ -284,7 +402,7 @@ def main():
         elapsed = float(t.item())
     n_dets = sum(len(r.bboxes) for r in step())
     sync()
-    canary = parity_canary(model, imgs, metas, args.arch, args.model) if rank == 0 and not args.f8corr else None
+    canary = parity_canary(model, imgs, metas, args.arch, args.model, args.lora) if rank == 0 and not args.f8corr else None
 
     result = None
     # ---- roofline leg: one extra instrumented step, per-kernel HIP events on the launch stream.  Every rank runs
@@ -321,14 +439,15 @@ def main():
         attn_tf_rel = sum(v['flops'] for v in attn) / (attn_ms + relpos_ms) / 1e9 if attn_ms else None
         value = world * B * args.steps / elapsed
         result = {
-            'metric': 'images/sec (1024x1024 synthetic tiles, rsprompter_%s SAM-ViT-%s, full predict path)' % (args.model, args.arch[0].upper()),
+            'metric': 'images/sec (1024x1024 synthetic tiles, rsprompter_%s SAM-ViT-%s%s, full predict path)' % (
+                args.model, args.arch[0].upper(), ' + LoRA' if args.lora else ''),
             'value': round(value, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None,
             'dtype': 'f32 (fp32 in/out; GEMMs and attention as fp16x3 split-precision MFMA with fp32 accumulate'
                      + ('; --f8corr: encoder GEMMs as fp16 hi.hi + one fp8 (e4m3, MX block scales) correction MFMA)' if args.f8corr else ')'),
             'data': 'synthetic' + (' (tiles copied from pinned host memory every step: not the headline)' if args.host_inputs else ''),
-            'config': {'workload': f'rsprompter_{args.model} SAM-ViT-{args.arch}, batch {B}x1024x1024 per GPU, '
+            'config': {'workload': f'rsprompter_{args.model} SAM-ViT-{args.arch}' + (' + LoRA(qkv r16)' if args.lora else '') + f', batch {B}x1024x1024 per GPU, '
                                    f'{num_classes} classes, seeded synthetic weights' + _config_tag(args, B, world),
                        'images_per_gpu_per_step': B, 'detections_per_step_rank0': n_dets,
                        'parallelism': f'dp{world} (images sharded by batch, result gather to rank 0 over RCCL)' if world > 1 else 'single GPU'},
@@ -351,9 +470,9 @@ def main():
             'parity_canary': canary,
             'kernels': kernels,
         }
-        if world == 1 and not args.no_cpu_baseline and args.model == 'anchor':
+        if world == 1 and not args.no_cpu_baseline:
             try:
-                result['cpu_baseline'] = cpu_baseline(args.arch, num_classes)
+                result['cpu_baseline'] = cpu_baseline(args.arch, num_classes, kind=args.model, lora=args.lora)
             except Exception as e:  # the baseline is context, never a reason to lose the measurement
                 result['cpu_baseline'] = {'value': None, 'unit': 'images/s', 'cores': torch.get_num_threads(),
                                           'kind': 'port', 'sample': f'failed: {e!r}'}

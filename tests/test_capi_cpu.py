@@ -54,3 +54,22 @@ def test_ctypes_struct_matches_header_field_order():
         for n in names.split(','):
             fields.append(n.strip().lstrip('*').strip())
     assert fields == [f[0] for f in _lib.RspGemmDesc._fields_]
+
+
+def test_shipped_library_has_no_ablation_kernels():
+    """The persistent GEMM (csrc/gemm_s2.hip) is instantiated once per product epilogue form and for nothing else: the
+    ablation variants (VAR != 0: no DMA, no epilogue, cache-hot sources -- wrong results on purpose) exist only in a
+    development build (RSP_DEV_BUILD=1), and no tools-only entry point is exported."""
+    import subprocess
+    from rsprompter_amd import _lib
+    nm = '/opt/rocm/lib/llvm/bin/llvm-nm'
+    out = subprocess.run([nm if os.path.exists(nm) else 'nm', '-C', _lib.LIB_PATH], capture_output=True, text=True).stdout
+    inst = set(re.findall(r'gemm_f16x3_s2_kernel<(\d+), (\d+)>', out))
+    assert inst, 'gemm_f16x3_s2_kernel not found in the library'
+    assert {v for v, _ in inst} == {'0'}, sorted(inst)
+    want = {4, 5, 21, 12, 28, 8, 10, 6, 64}       # E_C, +RES, +RES+RMAP, C+PL, C+PL+RMAP, PL, PL+GELU, C+GELU, run-time
+    assert {int(e) for _, e in inst} == want, sorted(inst)
+    assert 'rsp_debug_s2_trace' not in out
+    lib = _lib.load()
+    d = _lib.RspGemmDesc()
+    assert lib.rsp_gemm_s2_epilogue(None) == -1 and lib.rsp_gemm_s2_epilogue(ctypes.byref(d)) == -1
