@@ -211,6 +211,19 @@ int rsp_vit_attention_planes_ex(const float* q, int64_t q_ld, const uint16_t* kv
                                 uint16_t* out_hi, uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t S,
                                 int32_t nh, int32_t dh, float scale, int32_t win_per_side, int32_t win_real_last,
                                 rsp_stream_t stream);
+/* Windowed layers, rel-pos terms computed INSIDE the attention kernel (csrc/attn_win.hip; replaces the pair             */
+/* rsp_vit_relpos_rows + rsp_vit_attention_planes_ex of a windowed SamVisionAttention.forward, HF:803-831 + 761-801):     */
+/* rel_tab = the layer's two tables packed once by rsp_pack_relpos_tables; q / K | V planes / outputs / window grid as    */
+/* above with S = 14.  variant: 0 = product; bit 0 = two 4-wave blocks per (window, head) (measurement only).             */
+int rsp_vit_window_attention(const float* q, int64_t q_ld, const uint16_t* kv_hi, const uint16_t* kv_lo,
+                             int64_t kv_rows, int32_t kv_scale_log2, const uint16_t* rel_tab, float* out,
+                             uint16_t* out_hi, uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t nh,
+                             int32_t dh, float scale, int32_t win_per_side, int32_t win_real_last, int32_t variant,
+                             rsp_stream_t stream);
+/* rel_pos_h / rel_pos_w [2S-1, dh] fp32 (2S-1 <= 32, dh % 8 == 0) -> out [2][2][32][dh + 8] fp16: per table the hi and   */
+/* lo planes of table * 2^6, rows >= 2S-1 and the 8 pad columns zero (16-byte aligned, 2*2*32*(dh+8) halves)               */
+int rsp_pack_relpos_tables(const float* rel_pos_h, const float* rel_pos_w, uint16_t* out, int32_t S, int32_t dh,
+                           rsp_stream_t stream);
 /* rsp_vit_relpos with an explicit token stride of q (q rows of [Bp*T, q_ld], head h at column h*dh)                   */
 int rsp_vit_relpos_q(const float* q, int64_t q_ld, const float* rel_pos_h, const float* rel_pos_w, float* rel,
                      int32_t Bp, int32_t S, int32_t nh, int32_t dh, rsp_stream_t stream);

@@ -105,6 +105,10 @@ PROTOTYPES = {
     "rsp_vit_attention_planes_ex": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
                                             c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_int,
                                             c_void_p]),
+    "rsp_vit_window_attention": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p,
+                                         c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int, c_int,
+                                         c_void_p]),
+    "rsp_pack_relpos_tables": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rsp_vit_relpos_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
                                     c_int64, c_void_p]),
     "rsp_vit_relpos_q": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -1,4 +1,5 @@
-// SAM ViT attention, "plane-fed" form (round 2): K and V are consumed as the fp16 hi / lo PLANES the qkv GEMM's epilogue
+// SAM ViT GLOBAL-layer attention, "plane-fed" form (round 2; the 14 x 14 windows moved to attn_win.hip in round 4 -- the
+// WINDOW notes below describe what both kernels share): K and V are consumed as the fp16 hi / lo PLANES the qkv GEMM's epilogue
 // already wrote (KB32 layout [col/32][row][32], rsp_gemm Chi/Clo with pl_col0 = D) -- no fp32 K/V tensor, no split pass,
 // no transposed copy of V.  Reference semantics: SamVisionAttention.forward HF:803-831 + get_decomposed_rel_pos
 // HF:761-801 (vit_sam.py:117-157, 202-221); windows of 14x14 (HF:900-952) and the global layers (S = 64 / 32).
@@ -447,21 +448,21 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
 
 template <int DH>
 int launch_stream(const AttnSP& p, int Bp, hipStream_t s) {
-  if (p.S == 14) {
-    // (two 4-wave blocks per (window, head) were measured in round 3 and lost once the padded queries were skipped:
-    // profiles/r3_attn_window_7wave_vs_2x4wave.txt)
-    hipLaunchKernelGGL((attn_stream_kernel<DH, 7, 32, 3, true>), dim3((unsigned)(Bp * p.nh)), dim3(448), 0, s, p);
-  } else {
-    constexpr int NW = 8;
-    if (p.T % (NW * 32) || p.T % 64) return RSP_EINVAL;
-    hipLaunchKernelGGL((attn_stream_kernel<DH, NW, 64, 2, false>), dim3((unsigned)(p.T / (NW * 32)) * p.nh * Bp),
-                       dim3(NW * 64), 0, s, p);
-  }
+  constexpr int NW = 8;
+  if (p.T % (NW * 32) || p.T % 64) return RSP_EINVAL;
+  hipLaunchKernelGGL((attn_stream_kernel<DH, NW, 64, 2, false>), dim3((unsigned)(p.T / (NW * 32)) * p.nh * Bp),
+                     dim3(NW * 64), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
 
 }  // namespace
+
+// attn_win.hip: the 14 x 14 windows (rel-pos terms given as a tensor, or computed in the kernel from packed tables)
+int rsp_attn_win_dispatch(const float* q, int64_t q_ld, const uint16_t* kv_hi, const uint16_t* kv_lo, int64_t kv_rows,
+                          int32_t kv_scale_log2, const float* rel, const uint16_t* rel_tab, float* out, uint16_t* out_hi,
+                          uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t nh, int32_t dh, float scale,
+                          int32_t win_per_side, int32_t win_real_last, int32_t variant, hipStream_t s);
 
 extern "C" int rsp_vit_attention_planes_ex(const float* q, int64_t q_ld, const uint16_t* kv_hi, const uint16_t* kv_lo,
                                            int64_t kv_rows, int32_t kv_scale_log2, const float* rel, float* out,
@@ -472,6 +473,9 @@ extern "C" int rsp_vit_attention_planes_ex(const float* q, int64_t q_ld, const u
   if (!out && !(out_hi && out_lo)) return RSP_EINVAL;
   if ((out_hi == nullptr) != (out_lo == nullptr)) return RSP_EINVAL;
   if (!(S == 14 || S == 32 || S == 64)) return RSP_EINVAL;
+  if (S == 14)
+    return rsp_attn_win_dispatch(q, q_ld, kv_hi, kv_lo, kv_rows, kv_scale_log2, rel, nullptr, out, out_hi, out_lo,
+                                 out_scale_log2, Bp, nh, dh, scale, win_per_side, win_real_last, 0, (hipStream_t)stream);
   const int D = nh * dh;
   if ((D & 31) || (q_ld & 3) || kv_rows < (int64_t)Bp * S * S) return RSP_EINVAL;
   if (RSP_PLANE_IS_F8(kv_scale_log2)) return RSP_EINVAL;   // K | V are consumed as fp16 hi / lo planes
@@ -483,10 +487,6 @@ extern "C" int rsp_vit_attention_planes_ex(const float* q, int64_t q_ld, const u
   p.out_rows = (int64_t)Bp * S * S;
   p.T = S * S; p.S = S; p.nh = nh; p.D = D; p.scale = scale;
   p.win_n = 0; p.win_real = 0;
-  if (S == 14 && win_per_side > 0) {
-    if (win_real_last < 1 || win_real_last > 14 || Bp % (win_per_side * win_per_side)) return RSP_EINVAL;
-    p.win_n = win_per_side; p.win_real = win_real_last;
-  }
   hipStream_t s = (hipStream_t)stream;
   if (dh == 64) return launch_stream<64>(p, Bp, s);
   if (dh == 80) return launch_stream<80>(p, Bp, s);

@@ -434,11 +434,51 @@ def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False, f8=Fals
         raise ValueError('K | V planes are consumed as fp16 hi / lo planes (qkv GEMM: out_f8=False)')
     kind = 'global' if T >= 1024 else 'window'
     wn, wr = (int(win_grid[0]), int(win_grid[1])) if (win_grid is not None and S == 14) else (0, 0)
-    _timed(f'attn_stream_kernel<vit,{kind}>', 4.0 * Bp * nh * T * T * dh, 0,
+    _timed('attn_stream_kernel<vit,global>' if S != 14 else 'attn_win_kernel<vit,window,rel given>',
+           4.0 * Bp * nh * T * T * dh, 0,
            lambda: _lib.check(lib.rsp_vit_attention_planes_ex(q.data_ptr(), q.stride(0), kv.hi.data_ptr(), kv.lo.data_ptr(),
                                                               kv.rows, kv.scale_log2, rel.data_ptr(), _ptr(out), hi, lo, e,
                                                               Bp, S, nh, dh, scale, wn, wr, _stream()),
                               "rsp_vit_attention_planes_ex"))
+    return pl if planes else out
+
+
+def pack_relpos_tables(rel_pos_h, rel_pos_w, S, dh):
+    """the two rel-pos tables of a windowed layer ([2S-1, dh] fp32 each) as the fp16 hi / lo planes rsp_vit_window_attention
+    DMAs into LDS: uint16 [2, 2, 32, dh + 8] (rsp_pack_relpos_tables; once per layer at pack time)."""
+    lib = _lib.load()
+    _chk_f32(rel_pos_h, 'rel_pos_h')
+    _chk_f32(rel_pos_w, 'rel_pos_w')
+    if tuple(rel_pos_h.shape) != (2 * S - 1, dh) or tuple(rel_pos_w.shape) != (2 * S - 1, dh):
+        raise ValueError(f'rel-pos tables must be [{2 * S - 1}, {dh}]')
+    out = torch.empty((2, 2, 32, dh + 8), dtype=torch.float16, device=rel_pos_h.device)
+    _lib.check(lib.rsp_pack_relpos_tables(rel_pos_h.contiguous().data_ptr(), rel_pos_w.contiguous().data_ptr(), out.data_ptr(),
+                                          S, dh, _stream()), 'rsp_pack_relpos_tables')
+    return out
+
+
+def vit_window_attention(q, kv, rel_tab, Bp, nh, dh, scale, planes=False, f8=False, win_grid=None, variant=0):
+    """Windowed SamVisionAttention (HF:803-831 with get_decomposed_rel_pos HF:761-801) in ONE kernel: q fp32 rows
+    [Bp*196, nh*dh], K | V as the qkv GEMM's fp16 Planes, rel_tab = pack_relpos_tables(...) of the layer; the rel-pos terms
+    are computed inside (csrc/attn_win.hip).  win_grid as in vit_attention_planes."""
+    lib = _lib.load()
+    T, D = 196, nh * dh
+    if not isinstance(kv, Planes) or kv.shape[-1] != 2 * D or kv.rows < Bp * T or kv.f8:
+        raise ValueError('kv must be the fp16 K | V planes of the qkv GEMM')
+    if tuple(rel_tab.shape) != (2, 2, 32, dh + 8) or rel_tab.dtype != torch.float16 or not rel_tab.is_contiguous():
+        raise ValueError('rel_tab must come from pack_relpos_tables')
+    _chk_f32(q, 'q')
+    out = None if planes else torch.empty((Bp * T, D), dtype=torch.float32, device=q.device)
+    pl = empty_planes((Bp * T, D), q.device, f8=f8) if planes else None
+    hi, lo, e = (pl.hi.data_ptr(), pl.lo.data_ptr(), pl.word) if planes else (0, 0, 0)
+    wn, wr = (int(win_grid[0]), int(win_grid[1])) if win_grid is not None else (0, 0)
+    # flops: the padded-window figure of SURVEY section 8(d) (bench.py also quotes the evaluated-query figure); the 30 + 28
+    # rel-pos / bias MFMAs per wave are not counted
+    _timed('attn_win_kernel<vit,window>', 4.0 * Bp * nh * T * T * dh, 0,
+           lambda: _lib.check(lib.rsp_vit_window_attention(q.data_ptr(), q.stride(0), kv.hi.data_ptr(), kv.lo.data_ptr(),
+                                                           kv.rows, kv.scale_log2, rel_tab.data_ptr(), _ptr(out), hi, lo, e,
+                                                           Bp, nh, dh, scale, wn, wr, variant, _stream()),
+                              'rsp_vit_window_attention'))
     return pl if planes else out
 
 

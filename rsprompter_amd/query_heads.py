@@ -555,6 +555,7 @@ class RSPrompterQuery(BaseDetectorHIP):
     def predict(self, batch_inputs, batch_data_samples, rescale=True):
         """models.py:249-272."""
         x, emb, pe = self.extract_feat(batch_inputs)
+        self._last_embeddings = debug.keep(emb)            # parity tests / bench canary only (rsprompter_amd/debug.py)
         cls, masks = self.panoptic_head.predict(x, batch_data_samples, image_embeddings=emb,
                                                 image_positional_embeddings=pe)
         self._last_head_out = debug.keep((cls, masks))     # parity tests only (rsprompter_amd/debug.py)

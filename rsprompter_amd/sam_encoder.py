@@ -129,16 +129,20 @@ class SamVisionEncoderHIP(HIPModule):
             if self.lora is not None and i in self.lora:
                 A, Bm, sc = self.lora[i]
                 wq = wq + sc * (Bm.to(wq) @ A.to(wq))   # load-time merge W += (alpha/r) B A (models.py:785-797)
+            rph = resize_rel_pos(L.attn.rel_pos_h.detach(), s).contiguous()
+            rpw = resize_rel_pos(L.attn.rel_pos_w.detach(), s).contiguous()
+            # windowed layers: the rel-pos terms are computed inside the attention kernel from tables split once here
+            reltab = (ops.pack_relpos_tables(rph.float(), rpw.float(), s, self.dh)
+                      if (s == 14 and self.dh in (64, 80)) else None)
             P['layers'].append(dict(
-                S=s,
+                S=s, reltab=reltab,
                 ln1=(ln1.weight.detach(), ln1.bias.detach()),
                 ln2=(ln2.weight.detach(), ln2.bias.detach()),
                 qkv=ops.PackedWeight(wq, L.attn.qkv.bias, f8=f8),
                 proj=ops.PackedWeight(L.attn.proj.weight, L.attn.proj.bias, f8=f8),
                 lin1=ops.PackedWeight(lin1.weight, lin1.bias, f8=f8),
                 lin2=ops.PackedWeight(lin2.weight, lin2.bias, f8=f8),
-                rph=resize_rel_pos(L.attn.rel_pos_h.detach(), s).contiguous(),
-                rpw=resize_rel_pos(L.attn.rel_pos_w.detach(), s).contiguous(),
+                rph=rph, rpw=rpw,
             ))
         nm = self.nm
         c1, c2, n1, n2 = (_get(self, nm[k]) for k in ('conv1', 'conv2', 'nln1', 'nln2'))
@@ -217,11 +221,16 @@ class SamVisionEncoderHIP(HIPModule):
                 # tokens only)
                 ops.fill_bias_rows(L['qkv'].bias, pad_rows, 3 * D, out=None, planes=kv, c_ncols=D, pl_col0=D)
                 rowmap = tok2win
-            rel = ops.vit_relpos(q, L['rph'], L['rpw'], Bp, S, nh, dh, q_ld=D, rows=rowmap)   # windowed: real tokens only
             # windows of the last grid row / column hold padding: only their real tokens are queries (the proj GEMM
             # below gathers nothing else)
             wg = None if S == g else (nw, g - (nw - 1) * S)
-            att = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=True, f8=f8, win_grid=wg)
+            if S != g and L['reltab'] is not None:
+                # windowed layer: rel-pos terms (HF:761-801), bias, softmax and PV in ONE kernel (csrc/attn_win.hip)
+                rel = None
+                att = ops.vit_window_attention(q, kv, L['reltab'], Bp, nh, dh, scale, planes=True, f8=f8, win_grid=wg)
+            else:
+                rel = ops.vit_relpos(q, L['rph'], L['rpw'], Bp, S, nh, dh, q_ld=D, rows=rowmap)
+                att = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=True, f8=f8, win_grid=wg)
             qkv = (q, kv)
             # proj + window_unpartition + crop + residual (HF:830, 924-952, 969): a row GATHER of the real tokens from
             # window order (the padded rows are never multiplied)

@@ -217,6 +217,56 @@ def test_vit_attention_planes_skips_padded_queries(dev, nw, real, nh, dh, B):
     assert torch.equal(out2[is_real], full[is_real])
 
 
+@pytest.mark.parametrize('variant', [0, 1])
+@pytest.mark.parametrize('nw,real,nh,dh,B', [(5, 8, 2, 80, 1), (3, 4, 3, 64, 2), (2, 14, 16, 80, 1), (0, 0, 3, 64, 3)])
+def test_vit_window_attention_fused_relpos(dev, nw, real, nh, dh, B, variant):
+    """rsp_vit_window_attention (csrc/attn_win.hip): windowed SamVisionAttention with the decomposed rel-pos terms
+    (HF:761-801) computed INSIDE the kernel from the packed tables, the bias added through the matrix cores, lazy online
+    softmax -- against the fp64 restatement of HF:803-831; with the window grid known only the real tokens are queries.
+    variant 1 = two 4-wave blocks per (window, head).  nw = 0: grid unknown, every query computed."""
+    from rsprompter_amd import ops
+    S = 14
+    g = torch.Generator().manual_seed(900 + nw + dh)
+    Bp, T, D = B * max(nw, 1) ** 2, S * S, nh * dh
+    qkv = torch.randn(Bp, T, 3, nh, dh, generator=g)
+    qkv[:, :, 0] *= 2.0                       # sharper softmax
+    qkv[0, :, 1] *= 3.0                       # one window with a wide score range: the lazy maximum has to move there
+    qkv[0, 150:, 1] *= 2.0
+    rph = torch.randn(2 * S - 1, dh, generator=g) * 0.2
+    rpw = torch.randn(2 * S - 1, dh, generator=g) * 0.2
+    scale = dh ** -0.5
+    ref, ref_rel = _ref_vit_attention(qkv, rph, rpw, S, nh, dh, scale)
+    ref = ref.view(Bp, S, S, D)
+    q = qkv[:, :, 0].reshape(Bp * T, D).contiguous().to(dev)
+    kv = ops.to_planes(qkv[:, :, 1:].reshape(Bp * T, 2 * D).contiguous().to(dev))
+    tab = ops.pack_relpos_tables(rph.to(dev), rpw.to(dev), S, dh)
+    # the packed tables are the fp16 hi / lo split of table * 2^6, zero beyond the 27 rows / dh columns
+    tb = tab.float().cpu()
+    assert float((tb[0, 0] + tb[0, 1])[:27, :dh].sub(rph * 64).abs().max()) < 64 * 2.0 ** -20
+    assert float((tb[1, 0] + tb[1, 1])[:27, :dh].sub(rpw * 64).abs().max()) < 64 * 2.0 ** -20
+    assert float(tb[:, :, 27:].abs().max()) == 0.0 and float(tb[:, :, :, dh:].abs().max()) == 0.0
+    wg = (nw, real) if nw else None
+    got = ops.vit_window_attention(q, kv, tab, Bp, nh, dh, scale, win_grid=wg, variant=variant)
+    got = torch.nan_to_num(got, nan=7.0).view(Bp, S, S, D).cpu()
+    if nw:
+        wi = torch.arange(Bp) % (nw * nw)
+        rh = torch.where(wi // nw == nw - 1, real, S)
+        cw = torch.where(wi % nw == nw - 1, real, S)
+        yy, xx = torch.arange(S)[None, :, None], torch.arange(S)[None, None, :]
+        is_real = (yy < rh[:, None, None]) & (xx < cw[:, None, None])
+    else:
+        is_real = torch.ones(Bp, S, S, dtype=torch.bool)
+    err = float((got[is_real].double() - ref[is_real]).abs().max())
+    print(f'vit_window_attention nw={nw} real={real} nh={nh} dh={dh} variant={variant}: max abs err {err:.2e}')
+    assert err < 2e-5
+    pl = ops.vit_window_attention(q, kv, tab, Bp, nh, dh, scale, planes=True, win_grid=wg, variant=variant)
+    assert float((_planes_to_f32(pl).view(Bp, S, S, D)[is_real] - ref[is_real]).abs().max()) < 2e-5
+    # same arithmetic as the rel-tensor form of the kernel up to the rounding of the rel-pos terms themselves
+    rel = ops.vit_relpos(q, rph.to(dev), rpw.to(dev), Bp, S, nh, dh, q_ld=D)
+    other = ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, win_grid=wg).view(Bp, S, S, D).cpu()
+    assert float((other[is_real] - got[is_real]).abs().max()) < 1e-5
+
+
 def test_gemm_column_range_outputs(dev):
     """rsp_gemm c_ncols / pl_col0 (the qkv projection's split hand-off): fp32 for the first D columns only, planes for
     the rest, with a row-gather map and padded rows like the windowed layers."""
