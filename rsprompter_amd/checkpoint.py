@@ -31,19 +31,54 @@ def _trusted_default():
     return os.environ.get('RSP_TRUSTED_CHECKPOINTS', '0') == '1'
 
 
+def _harmless_globals():
+    """Reconstructors that reference-trained mmengine `.pth` files carry in their `meta` / `message_hub` blocks and that
+    build plain data only (numpy scalars / arrays / dtypes, OrderedDict, mmengine's HistoryBuffer when mmengine is
+    installed): allow-listed for the restricted unpickler, so the upstream checkpoint format loads without the full
+    unpickler.  Anything else in a file still needs the explicit opt-in."""
+    import collections
+    allow = [collections.OrderedDict, collections.defaultdict]
+    try:
+        import numpy as np
+        allow += [np.dtype, np.ndarray, np.float64, np.float32, np.int64, np.int32, np.bool_]
+        for modname in ('numpy.core.multiarray', 'numpy._core.multiarray'):
+            try:
+                mod = __import__(modname, fromlist=['scalar'])
+                allow += [mod.scalar, mod._reconstruct]
+                break
+            except Exception:
+                continue
+        allow += [type(np.dtype('float32')), type(np.dtype('float64')), type(np.dtype('int64')), type(np.dtype('int32'))]
+    except Exception:
+        pass
+    try:
+        from mmengine.logging.history_buffer import HistoryBuffer
+        allow.append(HistoryBuffer)
+    except Exception:
+        pass
+    return allow
+
+
 def _read_file(path, trusted=None):
     """One weight file -> the object stored in it.  Pickle files are read with torch's restricted unpickler
-    (`weights_only=True`: tensors, containers, numbers, strings).  Checkpoints whose meta block pickles arbitrary classes
-    (some mmengine `.pth`: ConfigDict, numpy scalars, ...) are exactly what the restricted loader refuses; the full
-    unpickler -- which executes code chosen by whoever wrote the file -- is used only on an explicit opt-in
-    (`trusted=True` or RSP_TRUSTED_CHECKPOINTS=1).  I/O and corruption errors are never retried."""
+    (`weights_only=True`: tensors, containers, numbers, strings), retried once with an allow-list of harmless numpy /
+    collections / mmengine reconstructors (`_harmless_globals`) -- the objects reference-trained mmengine `.pth` files keep
+    next to their state_dict.  A file that pickles anything else is refused; the full unpickler -- which executes code
+    chosen by whoever wrote the file -- is used only on an explicit opt-in (`trusted=True` or RSP_TRUSTED_CHECKPOINTS=1).
+    I/O and corruption errors are never retried."""
     import pickle
     if path.endswith('.safetensors'):
         from safetensors.torch import load_file
         return load_file(path, device='cpu')
     try:
         return torch.load(path, map_location='cpu', weights_only=True)
-    except pickle.UnpicklingError as e:
+    except pickle.UnpicklingError as e0:
+        try:
+            with torch.serialization.safe_globals(_harmless_globals()):
+                return torch.load(path, map_location='cpu', weights_only=True)
+        except pickle.UnpicklingError:
+            pass
+        e = e0
         if trusted is None:
             trusted = _trusted_default()
         if not trusted:

@@ -1,5 +1,5 @@
-// SAM ViT GLOBAL-layer attention, "plane-fed" form (round 2; the 14 x 14 windows moved to attn_win.hip in round 4 -- the
-// WINDOW notes below describe what both kernels share): K and V are consumed as the fp16 hi / lo PLANES the qkv GEMM's epilogue
+// SAM ViT GLOBAL-layer attention, "plane-fed" form (round 2; the 14 x 14 windows moved to attn_win.hip in round 4, which
+// shares the operand layouts described here): K and V are consumed as the fp16 hi / lo PLANES the qkv GEMM's epilogue
 // already wrote (KB32 layout [col/32][row][32], rsp_gemm Chi/Clo with pl_col0 = D) -- no fp32 K/V tensor, no split pass,
 // no transposed copy of V.  Reference semantics: SamVisionAttention.forward HF:803-831 + get_decomposed_rel_pos
 // HF:761-801 (vit_sam.py:117-157, 202-221); windows of 14x14 (HF:900-952) and the global layers (S = 64 / 32).
@@ -18,10 +18,7 @@
 //     real ones): the four rows of a read start 48 banks apart -> conflict-free, and d >= dh reads zeros.
 //   * P never leaves registers: accumulator registers [8 (s & 1), +8) of score block s >> 1 are the B operand of k-step s
 //     (keys 16 s + 4 hh + {0..3} and 16 s + 8 + 4 hh + {0..3}), matched by two transposing reads per plane.
-//   * WINDOW (S = 14, T = 196, KT = 32): the 7 key tiles are unrolled so that key -> (kh, kw) of the bias and the
-//     validity of the padded keys 196..223 are compile-time; invalid K / V rows are DMA'd from a zero page.
-//     LDS: 3 x 23.5 KB -> two blocks per CU, so one block's prologue (q fragments, first tile) hides under the other's
-//     matrix work.  The old kernel staged the whole window (153 KB, one block per CU) through registers with a split pass.
+//   * the 14 x 14 windows: attn_win.hip (round 4).
 //   * global layers (KT = 64, 8 waves): same structure as attn_global.hip minus the split pass and its HBM round trip.
 //   * What bounds it (round 2, measured): VALU ISSUE.  The loop carries 6.3 (global) / 10.9 (windows) VALU instructions
 //     per MFMA -- bias fma, max, exponent shift, exp2, row sum, the 3-instruction P split, accumulator rescale -- and a
@@ -97,10 +94,9 @@ struct AttnSP {
   bool out_f8;                                  // output planes in the cat8 format (plane format word)
   int T, S, nh, D;
   float scale;
-  int win_n, win_real;                          // windows per image side / real rows (columns) of the last one; 0: unknown
 };
 
-template <int DH, int NW, int KT, int NBUF, bool WINDOW>
+template <int DH, int NW, int KT, int NBUF>
 __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   constexpr int NT = NW * 64;
   constexpr int DSTEPS = DH / 16;
@@ -114,7 +110,6 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   constexpr int TILE_UNITS = 2 * K_UNITS + 2 * V_UNITS;
   constexpr int NDMA = (TILE_UNITS + NT - 1) / NT;
   constexpr int BUF_BYTES = (TILE_UNITS * 16 + 1023) / 1024 * 1024;   // lanes past the image are masked off the DMA
-  constexpr int WT = 196, WS = 14;                    // window tokens / side
   constexpr bool LSUM_MFMA = (DH % 32) != 0;          // spare V^T rows exist: row sums through the MFMA (see g_ones16s)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF][BUF_BYTES];
 
@@ -123,33 +118,13 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   const int hh = lane >> 5, l31 = lane & 31;
   const int T = p.T, S = p.S, nh = p.nh;
   const int QB = NW * 32;
-  const int nqb = WINDOW ? (7 + NW - 1) / NW : T / QB;      // windows: 7 query groups of 32 (196 -> 224) over 7 / NW blocks
-  const unsigned lb = WINDOW ? blockIdx.x : xcd_contig_s(blockIdx.x, gridDim.x);
+  const int nqb = T / QB;
+  const unsigned lb = xcd_contig_s(blockIdx.x, gridDim.x);
   const int bp = (int)(lb / (unsigned)(nqb * nh));
   const int h = (int)(lb / (unsigned)nqb) - bp * nh;
   const int q0 = (int)(lb % (unsigned)nqb) * QB;
-  // Windows cut from a padded grid (HF:900-922): the windows of the last row / column hold only win_real real rows /
-  // columns; their padded tokens are keys like any other (k = v = bias) but nobody reads their outputs (window_unpartition
-  // crops them), so the real queries are packed into the first waves and the remaining waves only keep the block's
-  // barriers and DMA slots going.  win_n == 0 (grid unknown): every query is computed.
-  int q = q0 + wave * 32 + l31;
-  bool qv = q < T;
-  bool dead = false;
-  if constexpr (WINDOW) {
-    if (p.win_n > 0) {
-      const int wi = bp % (p.win_n * p.win_n);
-      const int wy = wi / p.win_n, wx = wi - wy * p.win_n;
-      const int rh = wy == p.win_n - 1 ? p.win_real : WS, cw = wx == p.win_n - 1 ? p.win_real : WS;
-      const int c = q0 + wave * 32 + l31, cy = c / cw;
-      qv = c < rh * cw;
-      q = cy * WS + (c - cy * cw);
-      dead = q0 + wave * 32 >= rh * cw;              // wave-uniform
-      if (q0 >= rh * cw) return;                     // block-uniform: a whole query block of padding (NW < 7)
-    } else {
-      dead = q0 + wave * 32 >= T;
-      if (q0 >= T) return;
-    }
-  }
+  const int q = q0 + wave * 32 + l31;
+  const bool qv = q < T;
   const float* rel_b = p.rel + ((int64_t)bp * nh + h) * T * (2 * S);
   const int64_t row0 = (int64_t)bp * T;               // first row of this image / window in q, planes, out
 
@@ -196,14 +171,14 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
     unsigned char* lbase = &smem[buf][0];
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
-      const bool ok = drow[i] >= 0 && (!WINDOW || kt * KT + drow[i] < WT);
+      const bool ok = drow[i] >= 0;
       const unsigned char* src = ok ? dsrc[i] + (int64_t)kt * (KT * 64) : (drow[i] == -2 ? dsrc[i] : zero);
       if ((i + 1) * NT <= TILE_UNITS || i * NT + tid < TILE_UNITS)     // the last instruction may be partly masked
         __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (i * NT + wave * 64) * 16), 16, 0, 0);
     }
   };
 
-  const int nt = WINDOW ? (WT + KT - 1) / KT : T / KT;
+  const int nt = T / KT;
 #pragma unroll
   for (int t = 0; t < NBUF - 1; ++t)
     if (t < nt) issue_tile(t, t);
@@ -224,33 +199,23 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
     }
   }
   // ---- rel-pos bias in the log2 domain ----
-  // window: 14 + 14 scalars per query; global: rel_w of this lane's key columns (tile invariant) + one rel_h per key row
-  float bHw[WINDOW ? WS : 1], bWw[WINDOW ? WS : 1];
+  // rel_w of this lane's key columns (tile invariant) + one rel_h per key row
   float bw[2][16];                                    // rel_w of key columns 0..31 and 32..63 (mod S) for this lane
   const float* rq = rel_b + (int64_t)(qv ? q : 0) * (2 * S);
-  if constexpr (WINDOW) {
 #pragma unroll
-    for (int j = 0; j < WS; j += 2) {                 // rows are 28 floats = 112 B: 8-byte aligned
-      const float2 a = *reinterpret_cast<const float2*>(rq + j);
-      const float2 b = *reinterpret_cast<const float2*>(rq + WS + j);
-      bHw[j] = a.x * LOG2E_C; bHw[j + 1] = a.y * LOG2E_C; bWw[j] = b.x * LOG2E_C; bWw[j + 1] = b.y * LOG2E_C;
+  for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int kl = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      bw[blk][r] = qv ? rq[S + (kl % S)] * LOG2E_C : 0.f;
     }
-  } else {
-#pragma unroll
-    for (int blk = 0; blk < 2; ++blk)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int kl = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        bw[blk][r] = qv ? rq[S + (kl % S)] * LOG2E_C : 0.f;
-      }
-  }
   auto load_bh = [&](int kt, float& b0, float& b1) {    // global: key row(s) of the tile's two 32-key blocks
     const int kh0 = (kt * KT) / S, kh1 = (kt * KT + 32) / S;
     b0 = qv ? rq[kh0] * LOG2E_C : 0.f;
     b1 = (KT / S > 1 && qv) ? rq[kh1] * LOG2E_C : b0;   // S = 32: two key rows per tile
   };
   float bhn0 = 0.f, bhn1 = 0.f;
-  if constexpr (!WINDOW) load_bh(0, bhn0, bhn1);
+  load_bh(0, bhn0, bhn1);
 
   f32x16 acc_o[DBLK];
 #pragma unroll
@@ -264,8 +229,7 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   const int li = lane & 15, g16 = (lane >> 4) & 1;
   const int v_lane_off = (4 * hh + (li >> 2)) * (VCPR * 16) + (16 * g16 + 4 * (li & 3)) * 2;
 
-  auto tile_body = [&](auto tc_or_rt, int kt, int buf) {
-    // kt: tile index (compile-time usable through tc_or_rt when WINDOW)
+  auto tile_body = [&](int kt, int buf) {
     // this wave's part of tile kt must have landed; the (up to NBUF - 2) younger tiles may stay in flight.  vmcnt retires
     // in order, so the count also covers the few register loads (rel_h) issued since: conservative, never too weak.
     {
@@ -280,7 +244,6 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
       if (nb >= NBUF) nb -= NBUF;
       issue_tile(kt + NBUF - 1, nb);
     }
-    if (dead) return;                                    // no real query in this wave (see above)
     const unsigned char* sb = &smem[buf][0];
     const half_t* sK0 = reinterpret_cast<const half_t*>(sb);
     const half_t* sK1 = reinterpret_cast<const half_t*>(sb + K_UNITS * 16);
@@ -318,22 +281,7 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
     // ---- bias + online softmax in the log2 domain (per-lane query column) ----
     float tmax = -INFINITY;
     float k0s[NBLK];
-    if constexpr (WINDOW) {
-      constexpr int tile = decltype(tc_or_rt)::value;
-#pragma unroll
-      for (int blk = 0; blk < NBLK; ++blk)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key0 = tile * KT + blk * 32 + (r & 3) + 8 * (r >> 2), key1 = key0 + 4;   // hh = 0 / 1
-          const float b0 = key0 < WT ? bHw[key0 < WT ? key0 / WS : 0] + bWw[key0 < WT ? key0 % WS : 0] : -INFINITY;
-          const float b1 = key1 < WT ? bHw[key1 < WT ? key1 / WS : 0] + bWw[key1 < WT ? key1 % WS : 0] : -INFINITY;
-          const float v = fmaf(sc[blk][r], s_unscale2, hh ? b1 : b0);
-          sc[blk][r] = v;
-          tmax = fmaxf(tmax, v);
-        }
-#pragma unroll
-      for (int blk = 0; blk < NBLK; ++blk) k0s[blk] = 0.f;
-    } else {
+    {
       const float bh0 = bhn0, bh1 = bhn1;
       if (kt + 1 < nt) load_bh(kt + 1, bhn0, bhn1);     // a whole tile ahead of its use
 #pragma unroll
@@ -407,15 +355,10 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
     }
   };
 
-  if constexpr (WINDOW) {
-    static_for_s<0, (WT + KT - 1) / KT>([&](auto tc) {
-      constexpr int kt = decltype(tc)::value;
-      tile_body(tc, kt, kt % NBUF);
-    });
-  } else {
+  {
     int buf = 0;
     for (int kt = 0; kt < nt; ++kt) {
-      tile_body(std::integral_constant<int, 0>{}, kt, buf);
+      tile_body(kt, buf);
       if (++buf == NBUF) buf = 0;
     }
   }
@@ -450,7 +393,7 @@ template <int DH>
 int launch_stream(const AttnSP& p, int Bp, hipStream_t s) {
   constexpr int NW = 8;
   if (p.T % (NW * 32) || p.T % 64) return RSP_EINVAL;
-  hipLaunchKernelGGL((attn_stream_kernel<DH, NW, 64, 2, false>), dim3((unsigned)(p.T / (NW * 32)) * p.nh * Bp),
+  hipLaunchKernelGGL((attn_stream_kernel<DH, NW, 64, 2>), dim3((unsigned)(p.T / (NW * 32)) * p.nh * Bp),
                      dim3(NW * 64), 0, s, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
@@ -486,7 +429,6 @@ extern "C" int rsp_vit_attention_planes_ex(const float* q, int64_t q_ld, const u
   p.out_pscale = ldexpf(1.0f, RSP_PLANE_EXP(out_scale_log2)); p.out_f8 = out_hi && RSP_PLANE_IS_F8(out_scale_log2);
   p.out_rows = (int64_t)Bp * S * S;
   p.T = S * S; p.S = S; p.nh = nh; p.D = D; p.scale = scale;
-  p.win_n = 0; p.win_real = 0;
   hipStream_t s = (hipStream_t)stream;
   if (dh == 64) return launch_stream<64>(p, Bp, s);
   if (dh == 80) return launch_stream<80>(p, Bp, s);

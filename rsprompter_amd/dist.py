@@ -117,6 +117,7 @@ class ExchangeState:
         self.img_cap = self.inst_cap = self.byte_cap = 0
         self.run_cap = 4096
         self.host = {}
+        self.in_flight = False       # an exchange queued on a side stream whose collect() has not run: it owns `host`
 
     def fits(self, need):
         return need[0] <= self.img_cap and need[1] <= self.inst_cap and need[2] <= self.byte_cap and need[3] <= 0
@@ -134,7 +135,12 @@ _STATES = {}
 
 
 def _state_of(group):
-    return _STATES.setdefault(id(group) if group is not None else 0, ExchangeState())
+    """one ExchangeState per process group.  The entry keeps a reference to the group object, so its id() cannot be handed
+    to another group while the state exists."""
+    key = id(group) if group is not None else 0
+    if key not in _STATES:
+        _STATES[key] = (group, ExchangeState())
+    return _STATES[key][1]
 
 
 class DeviceCodec:
@@ -215,7 +221,7 @@ def _pad_rows(t, n):
     return out
 
 
-def gather_results(results_list, dataset_size=None, group=None, stream=None, dst=0, codec=None, state=None):
+def gather_results(results_list, dataset_size=None, group=None, stream=None, dst=0, codec=None, state=None, device=None):
     """Bring every rank's per-image results (records + COCO RLE strings) to rank `dst` (None: to every rank).
 
     results_list: this rank's InstanceData list (bboxes, scores, labels, masks bool [k, H_i, W_i]); mask sizes may
@@ -223,14 +229,27 @@ def gather_results(results_list, dataset_size=None, group=None, stream=None, dst
     dataset item i * world + r.  Returns (from `collect()` when a side `stream` is given, directly otherwise) a
     `GatheredResults` on the destination rank(s) and None elsewhere, as mmengine `collect_results` does.
         h = gather_results(out, stream=side, ...)   ->  PendingGather;  ...next test_step...;  res = h.collect()
-    codec: the (records, strings) encoder; the default runs the HIP kernels (tests on CPU inject a numpy one)."""
+    codec: the (records, strings) encoder; the default runs the HIP kernels (tests on CPU inject a numpy one).
+    device: where the exchange buffers live when this rank has NO image this step (default: the current CUDA device under
+    an nccl group, else the CPU) -- the collectives of all ranks must run on the same kind of tensor.
+    One exchange per process group may be in flight: queue the next one after `collect()` of the previous."""
     import numpy as np
     codec = codec or DeviceCodec()
     state = state or _state_of(group)
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n_img = len(results_list)
-    dev = results_list[0].bboxes.device if n_img else torch.device('cpu')
+    if state.in_flight:
+        raise RuntimeError('gather_results: the previous exchange of this process group has not been collected '
+                           '(its pinned host buffers would be overwritten); call collect() first')
+    if n_img:
+        dev = results_list[0].bboxes.device
+    elif device is not None:
+        dev = torch.device(device)
+    elif dist.is_initialized() and torch.cuda.is_available() and 'nccl' in str(dist.get_backend(group)):
+        dev = torch.device('cuda', torch.cuda.current_device())
+    else:
+        dev = torch.device('cpu')
     on_gpu = dev.type == 'cuda'
     use_stream = stream is not None and on_gpu
     to_me = dst is None or rank == dst
@@ -293,8 +312,16 @@ def gather_results(results_list, dataset_size=None, group=None, stream=None, dst
         return headers, got, ev
 
     inflight = queue()
+    state.in_flight = bool(use_stream)
 
     def finish():
+        nonlocal inflight
+        try:
+            return _finish()
+        finally:
+            state.in_flight = False
+
+    def _finish():
         nonlocal inflight
         while True:
             headers, got, ev = inflight

@@ -338,15 +338,19 @@ class SAMDet(BaseDetectorHIP):
         low = None
         if sum(counts):
             sam = self.segmentor.sam_model if hasattr(self.segmentor, 'sam_model') else self.segmentor
-            emb = sam.get_image_embeddings(batch_inputs)
-            # one decoder pass over all images: prompt set r belongs to image roi_img[r]
+            # the reference skips the segmentor for an image without boxes (models.py:1166): only the images that have
+            # prompts go through the ViT; prompt set r belongs to row roi_img[r] of that sub-batch
+            have = [i for i, n in enumerate(counts) if n]
+            sub = batch_inputs if len(have) == len(counts) else batch_inputs[torch.tensor(have, device=dev)]
+            emb = sam.get_image_embeddings(sub)
+            # one decoder pass over all images
             pe = sam.prompt_encoder
             allb = torch.cat(boxes_in, 0)
             sparse = ops.sam_embed_boxes(allb, pe.shared_embedding.positional_embedding,
                                          getattr(pe.point_embed, '2').weight, getattr(pe.point_embed, '3').weight,
                                          (sam.image_size, sam.image_size))
-            roi_img = torch.repeat_interleave(torch.arange(len(counts), dtype=torch.int32),
-                                              torch.tensor(counts)).to(dev)
+            roi_img = torch.repeat_interleave(torch.arange(len(have), dtype=torch.int32),
+                                              torch.tensor([counts[i] for i in have])).to(dev)
             low, _ = sam.mask_decoder.decode(emb, sam.get_image_wide_positional_embeddings(), sparse,
                                              pe.no_mask_embed.weight.reshape(-1), roi_img, want_iou=False)
             low = low[:, 0]                                                                 # [R, 256, 256]

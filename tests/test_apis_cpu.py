@@ -164,3 +164,32 @@ def test_init_detector_and_inference_detector_host_logic(monkeypatch, tmp_path):
     assert float(r.pred_instances.bboxes.max()) <= 128.0 + 1e-3         # boxes rescaled to the original image
     rs = apis.inference_detector(model, [img])
     assert isinstance(rs, list) and len(rs) == 1
+
+
+class _Evil:
+    """a class the restricted loader must keep refusing"""
+
+    def __reduce__(self):
+        return (print, ('code ran while unpickling',))
+
+
+def test_mmengine_style_checkpoint_with_numpy_meta_loads_without_full_unpickling(tmp_path):
+    """Reference-trained mmengine `.pth` files keep numpy scalars / arrays and OrderedDicts next to the state_dict
+    (meta, message_hub: mmengine/runner/checkpoint.py save_checkpoint).  The restricted loader alone refuses those; the
+    allow-list of harmless reconstructors lets the upstream format load out of the box, and a file that pickles anything
+    else is still refused unless the caller opts into the full unpickler."""
+    import collections
+    import numpy as np
+    import pytest
+    from rsprompter_amd import checkpoint as ck
+    sd = collections.OrderedDict(a=torch.randn(3, 4), b=torch.arange(5))
+    good = dict(meta=dict(epoch=12, iter=np.int64(3456), seed=np.array([1, 2, 3]), lr=np.float64(1e-4),
+                          time='2023-10-01', cfg='model = dict(...)'),
+                message_hub=dict(log_scalars=collections.OrderedDict(loss=np.float32(0.25)), runtime_info=dict(iter=7)),
+                state_dict=sd)
+    torch.save(good, str(tmp_path / 'mm.pth'))
+    got = ck.read_state_dict(str(tmp_path / 'mm.pth'))
+    assert set(got) == {'a', 'b'} and torch.equal(got['a'], sd['a'])
+    torch.save(dict(meta=dict(hook=_Evil()), state_dict=sd), str(tmp_path / 'evil.pth'))
+    with pytest.raises(RuntimeError, match='refused'):
+        ck.read_state_dict(str(tmp_path / 'evil.pth'))

@@ -223,7 +223,8 @@ def test_vit_window_attention_fused_relpos(dev, nw, real, nh, dh, B, variant):
     """rsp_vit_window_attention (csrc/attn_win.hip): windowed SamVisionAttention with the decomposed rel-pos terms
     (HF:761-801) computed INSIDE the kernel from the packed tables, the bias added through the matrix cores, lazy online
     softmax -- against the fp64 restatement of HF:803-831; with the window grid known only the real tokens are queries.
-    variant 1 = two 4-wave blocks per (window, head).  nw = 0: grid unknown, every query computed."""
+    variant 1 = 16 persistent blocks, so that every block walks several windows (the K | V tile ring and the q requests
+    cross window boundaries).  nw = 0: grid unknown, every query computed."""
     from rsprompter_amd import ops
     S = 14
     g = torch.Generator().manual_seed(900 + nw + dh)

@@ -104,6 +104,17 @@ def vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale, planes=False, f8=Fals
     return vit_attention(qkv.reshape(Bp * T, 3 * nh * dh), rel, Bp, S, nh, dh, scale)
 
 
+def pack_relpos_tables(rph, rpw, S, dh):
+    """stand-in: the two tables as they are (ops.pack_relpos_tables splits them into fp16 planes for the kernel)"""
+    return (rph.float(), rpw.float(), S)
+
+
+def vit_window_attention(q, kv, rel_tab, Bp, nh, dh, scale, planes=False, f8=False, win_grid=None, variant=0):
+    rph, rpw, S = rel_tab
+    rel = vit_relpos(q, rph, rpw, Bp, S, nh, dh, q_ld=nh * dh)
+    return vit_attention_planes(q, kv, rel, Bp, S, nh, dh, scale)
+
+
 def patchify(img, patch):
     return F.unfold(img, patch, stride=patch).transpose(1, 2).reshape(-1, img.shape[1] * patch * patch)
 

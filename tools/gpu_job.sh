@@ -8,6 +8,9 @@
 #   b:<name>:<bench args>      python bench.py <args>                           -> bench_<name>.json / .err
 #   p:<name>:<bench args>      rocprofv3 --kernel-trace --stats -- bench.py ... -> prof_<name>/ + prof_<name>_kernel_stats.csv
 #   x:<name>:<command>         bash -c <command>                                -> <name>.log      (timeout 900 s)
+#   c:<name>:<command>         rocprofv3 --pmc passes of <command> (SQ groups; counters only, one group per pass)
+#   m:<name>:<command>         ... plus the memory-side passes (FETCH_SIZE, WRITE_SIZE, TCC hit / miss)
+#                              -> pmc_<name>/ + pmc_<name>_report.{txt,json} (tools/pmc_report.py)
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 O=gpurun_out/$1; shift
 mkdir -p "$O"
@@ -39,6 +42,20 @@ PY
        find "$O/prof_$name" -name '*kernel_trace.csv' -delete ;;
     x) timeout 900 bash -c "$args" > "$O/$name.log" 2>&1; rc=$?
        tail -n 4 "$O/$name.log" | cut -c1-300 ;;
+    c|m) P="$O/pmc_$name"; rm -rf "$P"; mkdir -p "$P"; rc=0
+       pmc_pass() { n=$1; shift
+         (cd /tmp && timeout 300 rocprofv3 --pmc "$@" --output-format csv -d "$OLDPWD/$P/$n" -o r -- bash -c "cd $OLDPWD && $args" > "$OLDPWD/$P/$n.log" 2>&1) || rc=$?; }
+       pmc_pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU
+       pmc_pass sq3 SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_VMEM SQ_WAVES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU
+       pmc_pass sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_MISC
+       if [ "$kind" = m ]; then
+         pmc_pass fetch FETCH_SIZE
+         pmc_pass write WRITE_SIZE
+         pmc_pass tcc TCC_HIT_sum TCC_MISS_sum
+       fi
+       python tools/pmc_report.py "$P" --json "$O/pmc_${name}_report.json" > "$O/pmc_${name}_report.txt" 2>&1
+       find "$P" -name "*agent_info.csv" -delete
+       grep -E "^[a-z_A-Z0-9<>, ]+grid=|mfma_busy|pct_of_wave|per_mfma" "$O/pmc_${name}_report.txt" | head -n 40 | cut -c1-150 ;;
     *) echo "unknown step $step"; rc=99 ;;
   esac
   echo "[$kind:$name] rc=$rc $(( $(date +%s) - t0 )) s"

@@ -58,6 +58,8 @@ def derive(row):
                 d[c.lower() + '_pct_of_wave'] = 100.0 * row[c] / w
     if 'SQ_LDS_IDX_ACTIVE' in row and row['SQ_LDS_IDX_ACTIVE']:
         d['lds_conflict_pct'] = 100.0 * row.get('SQ_LDS_BANK_CONFLICT', 0) / row['SQ_LDS_IDX_ACTIVE']
+    if row.get('SQ_INSTS_MFMA'):
+        d['valu_insts_per_mfma'] = row.get('SQ_INSTS_VALU', 0.0) / row['SQ_INSTS_MFMA']
     if 'FETCH_SIZE' in row:
         d['read_bytes'] = row['FETCH_SIZE'] * 1024 * 2
     if 'WRITE_SIZE' in row:
