@@ -119,8 +119,14 @@ def test_bbox_head_and_detection_selection(setup, dev):
     m, tr = setup['model'], setup['trace']
     feats = [_cl(f, dev) for f in tr['fpn']]
     pes = m.roi_head.extra_pe_tables(feats)
-    for t, ref in zip(pes, tr['x_pe']):
-        pass
+    # the extra positional encoding itself (models.py:1566-1574): the oracle adds it to the pyramid (x_pe = fpn + pe), the
+    # HIP path keeps it as per-level tables that RoIAlign samples on the fly -- table == what the oracle added, every image
+    for lvl, (t, xpe, f) in enumerate(zip(pes, tr['x_pe'], tr['fpn'])):
+        added = xpe.double() - f.double()                                   # [B, C, H, W]
+        e_pe = float((t.permute(2, 0, 1).double().cpu()[None] - added).abs().max())
+        bound = 4e-7 * float(xpe.abs().max()) + 1e-6                        # fp32 rounding of the oracle's own sum
+        print(f'extra PE level {lvl}: table vs (x_pe - fpn) {e_pe:.2e} (bound {bound:.2e})')
+        assert e_pe < bound
     rois = tr['rois'].to(dev)
     rf = m.roi_head.bbox_roi_extractor(feats[:4], rois, pes=pes[:4])
     assert _maxerr(rf, tr['roi_feats']) < 2e-4

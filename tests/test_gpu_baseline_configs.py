@@ -73,6 +73,39 @@ def _mask_flips(masks_a, masks_b, n_img):
     return flips, touched
 
 
+TIE = 2.5e-4               # an attention-mask decision may differ from the oracle's only where the oracle's own logit is this
+                           # close to the threshold (the fp32 forward's own distance to fp64 there: 3e-5 ... 1e-4)
+
+
+def _flips_are_ties(our_masks, ref_trace, n_img, pick=None):
+    """Every attention-mask decision (sigmoid(z) < 0.5, models.py:381-392) that differs from the fp32 oracle's must be a TIE:
+    the oracle's own decision logit z (its auxiliary mask logits resized to the level's grid, recomputed here) lies within
+    TIE of 0.  Only a query's FIRST differing layer is held to that: once one key more or fewer is attended, the query's
+    later logits move by an amount unrelated to round-off.  Replaces a count bound (`<= 2 x reference flips + 6`): the
+    number of flips follows from the density of oracle logits near 0, the criterion is where they sit.
+    Returns (flips per layer, touched [n_img, Nq], largest |z| at a first flip)."""
+    import torch.nn.functional as F
+    touched, flips, worst = None, [], 0.0
+    for i, (a, b) in enumerate(zip(our_masks, ref_trace['attn_masks'])):
+        nq = b.shape[-2]
+        ours = a.cpu().bool().view(-1, 8, nq, a.shape[-1])[:, 0]
+        if pick is not None:
+            ours = ours[pick]
+        ref_m = b.cpu().bool().view(n_img, -1, nq, b.shape[-1])[:, 0]
+        size = ref_trace['memory'][i % 3].shape[-2:]
+        z = F.interpolate(ref_trace['mask_pred_plus_all'][i].float(), size, mode='bilinear', align_corners=False).flatten(2)
+        diff = ours != ref_m                                                   # [n_img, Nq, HW]
+        flips.append(int(diff.sum()))
+        row_all = (z < 0).all(-1)                                              # models.py:439-442 clears such rows
+        first = diff & ~row_all[..., None]
+        if touched is not None:
+            first = first & ~touched[..., None]
+        if bool(first.any()):
+            worst = max(worst, float(z.abs()[first].max()))
+        touched = diff.any(-1) if touched is None else (touched | diff.any(-1))
+    return flips, touched, worst
+
+
 def _check_query(model, oracle, imgs, metas, dev, tag, fp64_floor=False):
     """fp64_floor: also run the oracle in fp64 and hold the HIP path to the floor the reference's OWN fp32 forward shows
     against it (tools/parity_fp64_study.py, profiles/r3_parity_fp64_study_config4.json: on the configs[4] fixture the
@@ -93,15 +126,15 @@ def _check_query(model, oracle, imgs, metas, dev, tag, fp64_floor=False):
     print(f'{tag}: free-running SAM mask logits err {e_mask:.2e} (range {rng:.1f}), class logits err {e_cls:.2e} vs the fp32 oracle')
     per_q = (ours - tr['mask_pred']).abs().flatten(2).amax(2)                                       # [B, Nq]
     trace = model.panoptic_head._last_trace
-    flips, flipped_q = _mask_flips(trace['attn_masks'], tr['attn_masks'], n_img)
+    flips, flipped_q, tie_z = _flips_are_ties(trace['attn_masks'], tr, n_img)
     top = per_q.flatten().topk(5).values.tolist()
     print(f'{tag}: attention-mask bits that differ from the fp32 oracle per decoder layer: {flips} '
-          f'({int(flipped_q.sum())} queries touched); 5 largest per-query logit errors: {["%.2e" % v for v in top]}; '
-          f'median {float(per_q.median()):.2e}')
+          f'({int(flipped_q.sum())} queries touched, largest oracle |logit| at a first flip {tie_z:.2e}); 5 largest per-query '
+          f'logit errors: {["%.2e" % v for v in top]}; median {float(per_q.median()):.2e}')
+    # a decision differs only where the oracle's own logit ties with the threshold
+    assert tie_z <= TIE, f'an attention-mask decision differs where the oracle logit is {tie_z:.2e} from the threshold'
     if not fp64_floor:
-        # no decision may differ by more than the handful round-off explains (0-1 observed on these fixtures); queries
-        # with identical masks are held to the 1e-3 budget, a touched one to 1e-2
-        assert int(flipped_q.sum()) <= 4 and sum(flips) <= 6
+        # queries with identical masks are held to the 1e-3 budget, a touched one to 1e-2
         assert float(per_q[~flipped_q].max()) < LOGIT_TOL and e_cls < LOGIT_TOL
         assert float(per_q.max()) < 1e-2
     else:
@@ -122,11 +155,9 @@ def _check_query(model, oracle, imgs, metas, dev, tag, fp64_floor=False):
               f'{float(ref_pq[~ref_touched].max()):.2e}, first auxiliary mask {ref_aux:.2e};  HIP: {sum(our_flips)} decisions '
               f'({int(our_touched.sum())} queries), worst touched {float(our_pq[our_touched].max()) if our_touched.any() else 0.0:.2e}, '
               f'worst untouched {float(our_pq[~our_touched].max()):.2e}, first auxiliary mask {our_aux:.2e}')
-        # the error that decides how many logits sit on the wrong side of 0 is in the reference's own class ...
+        # the error that decides how many logits sit on the wrong side of 0 is in the reference's own class; WHERE the
+        # flips may sit is asserted above (_flips_are_ties), which bounds their number by the oracle logits inside the band
         assert our_aux <= 2.0 * ref_aux + 1e-5, (our_aux, ref_aux)
-        # ... hence so is the count: Poisson with about the reference's own mean (2x + 6 covers the 99.9 % quantile for
-        # means up to 10 and the one-sample estimate of the mean)
-        assert sum(our_flips) <= 2 * sum(ref_flips) + 6 and int(our_touched.sum()) <= 2 * int(ref_touched.sum()) + 6
         # queries whose masks equal the fp64 run's in every layer: the north-star 1e-3, strictly; touched ones move by
         # what one key more or fewer does (1.4e-3 for the reference itself on this fixture): 1e-2
         assert float(our_pq[~our_touched].max()) < LOGIT_TOL and our_cls < LOGIT_TOL
@@ -281,14 +312,88 @@ def test_config2_query_vitl_batch16_r1600(dev):
     assert ours.shape[:2] == (B, 100) and bool(torch.isfinite(ours).all())
     x = glue.data_preprocess([imgs[b] for b in pick], MEAN, STD, True, 32)
     ref, tr = oracle.predict(x, [metas[b] for b in pick])
-    flips, touched = _mask_flips([m.view(B, -1, m.shape[-1])[pick] for m in model.panoptic_head._last_trace['attn_masks']],
-                                 tr['attn_masks'], len(pick))
+    flips, touched, tie_z = _flips_are_ties(model.panoptic_head._last_trace['attn_masks'], tr, len(pick), pick=pick)
+    assert tie_z <= TIE, tie_z
     per_q = (ours[pick] - tr['mask_pred']).abs().flatten(2).amax(2)
     e_cls = _maxerr(cls[pick], tr['cls_pred'])
     print(f'configs[2] at batch 16 (R = 1600), images {pick}: SAM mask logits err {float(per_q.max()):.2e} '
           f'(untouched queries {float(per_q[~touched].max()):.2e}), class logits {e_cls:.2e}, attention-mask decisions that '
           f'differ {flips}')
     assert sum(flips) <= 6 and float(per_q[~touched].max()) < LOGIT_TOL and e_cls < LOGIT_TOL and float(per_q.max()) < 1e-2
+    for n, b in enumerate(pick):
+        pi, r = out[b].pred_instances, ref[n]
+        same = pi.query_indices.cpu().long() == r['query_indices']
+        assert int((~same).sum()) <= 4
+        mism = float((pi.masks.cpu()[same] != r['masks'][same]).float().mean())
+        assert mism < 1e-3
+
+
+def test_config1_anchor_vitb_batch8(dev):
+    """BASELINE.json configs[1] at its own batch (rsprompter_anchor SAM ViT-B, 8 x 1024 x 1024 on one GPU): images 0, 4
+    and 7 of the free-running batch-8 step against the oracle -- detections matched, then the LOW-RES MASK LOGITS of the
+    matched instances (north star: <= 1e-3) and the image embedding."""
+    from oracle import glue
+    from oracle.anchor import AnchorOracle
+    from rsprompter_amd.default_configs import rsprompter_anchor
+    from rsprompter_amd.synth import synth_images, synth_metas
+    B, pick = 8, [0, 4, 7]
+    oracle = AnchorOracle('base', 10)
+    model = _build(rsprompter_anchor('base', 10), oracle, dev)
+    imgs, metas = synth_images(B, seed=1234), synth_metas(B)
+    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
+    low = model.roi_head._last_mask_trace['mask_preds'].cpu()
+    emb = model._last_embeddings.cpu()
+    ks = [int(o.pred_instances.labels.shape[0]) for o in out]
+    assert low.shape[0] == sum(ks) and bool(torch.isfinite(low).all()) and bool(torch.isfinite(emb).all())
+    x = glue.data_preprocess([imgs[b] for b in pick], MEAN, STD, True, 32)
+    ref, tr = oracle.predict(x, [metas[b] for b in pick])
+    ref0 = 0
+    for n, b in enumerate(pick):
+        pi, r = out[b].pred_instances, ref[n]
+        k = r['labels'].shape[0]
+        assert pi.labels.shape[0] == k and tuple(pi.masks.shape[1:]) == (1024, 1024)
+        pairs = match_detections(pi.bboxes, pi.scores, pi.labels, r['bboxes'], r['scores'], r['labels'])
+        ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
+        o0 = sum(ks[:b])
+        e_low = _maxerr(low[o0 + ii], tr['low_res_masks'][ref0 + jj])
+        e_emb = _maxerr(emb[b], tr['image_embeddings'][n])
+        mism = float((pi.masks.cpu()[ii] != r['masks'][jj]).float().mean())
+        print(f'configs[1] anchor ViT-B at batch 8, img {b}: {k} dets, {len(pairs)} matched, low_res_masks err {e_low:.2e} '
+              f'(range {float(tr["low_res_masks"].abs().max()):.1f}), embedding err {e_emb:.2e}, mask pixel mismatch {mism:.2e}')
+        assert e_low < LOGIT_TOL and e_emb < LOGIT_TOL and mism < 1e-3
+        ref0 += k
+
+
+def test_config4_query_vith_lora_batch4(dev):
+    """BASELINE.json configs[4] at its per-GPU batch (32 tiles over 8 GPUs = 4 per GPU; ViT-H + LoRA, Nq = 100, WHU-shape
+    metas): images 0 and 3 of the free-running batch-4 step against the fp32 oracle on those tiles.  Decisions of the
+    masked decoder may differ from the oracle's only at ties (_flips_are_ties); queries whose masks are identical are held
+    to 1e-3, touched ones to 1e-2 (the oracle's own fp32 forward moves by 1.4e-3 on such queries)."""
+    from oracle import glue
+    from oracle.query import QueryOracle
+    from rsprompter_amd.default_configs import rsprompter_query_lora
+    from rsprompter_amd.synth import synth_images, synth_metas
+    B, pick = 4, [0, 3]
+    oracle = QueryOracle('huge', 1, 100, max_per_image=100, lora=dict(r=16, alpha=32))
+    model = _build(rsprompter_query_lora('huge', 1, (100, 5)), oracle, dev, seed=0)
+    imgs = synth_images(B, seed=1234)
+    metas = synth_metas(B, ori_shape=(512, 512), scale_factor=(2.0, 2.0))
+    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
+    cls, lazy = model._last_head_out
+    ours = lazy.low_res.detach().float().cpu()
+    assert ours.shape[:2] == (B, 100) and bool(torch.isfinite(ours).all())
+    x = glue.data_preprocess([imgs[b] for b in pick], MEAN, STD, True, 32)
+    ref, tr = oracle.predict(x, [metas[b] for b in pick])
+    flips, touched, tie_z = _flips_are_ties(model.panoptic_head._last_trace['attn_masks'], tr, len(pick), pick=pick)
+    per_q = (ours[pick] - tr['mask_pred']).abs().flatten(2).amax(2)
+    e_cls = _maxerr(cls[pick], tr['cls_pred'])
+    e_emb = _maxerr(model._last_embeddings[pick], tr['image_embeddings'])
+    print(f'configs[4] at batch 4, images {pick}: SAM mask logits err {float(per_q.max()):.2e} (untouched queries '
+          f'{float(per_q[~touched].max()):.2e}), class logits {e_cls:.2e}, embedding {e_emb:.2e}, attention-mask decisions '
+          f'that differ {flips} ({int(touched.sum())} queries, largest oracle |logit| at a first flip {tie_z:.2e})')
+    assert tie_z <= TIE
+    assert float(per_q[~touched].max()) < LOGIT_TOL and e_cls < LOGIT_TOL and e_emb < LOGIT_TOL
+    assert float(per_q.max()) < 1e-2
     for n, b in enumerate(pick):
         pi, r = out[b].pred_instances, ref[n]
         same = pi.query_indices.cpu().long() == r['query_indices']
