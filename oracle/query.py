@@ -183,9 +183,15 @@ class DecLayer(nn.Module):
 class QueryHead(nn.Module):
     """RSMask2FormerHead (decoder_plus=True): models.py:274-463."""
 
-    def __init__(self, num_classes, num_queries, per_pointset_point=5, feat=128, out=256):
+    def __init__(self, num_classes, num_queries, per_pointset_point=5, feat=128, out=256, decoder_plus=True,
+                 with_sincos=True, input_proj=False):
+        """decoder_plus=False (models.py:303-307, 361-385): no mask-embedding MLP, `no_mask_embed` as the dense prompt, the
+        SAM decoder runs in every stage and its masks drive the attention masks; with_sincos=False (models.py:315-318,
+        346-347): the point MLP emits the prompts directly; input_proj: `enforce_decoder_input_project=True`
+        (mask2former_head.py:93-100: Conv2d 1x1 per level)."""
         super().__init__()
         self.num_classes, self.num_queries, self.npts, self.num_heads = num_classes, num_queries, per_pointset_point, 8
+        self.decoder_plus, self.with_sincos = decoder_plus, with_sincos
         self.pixel_decoder = PixelDecoder(feat, out)
         self.transformer_decoder = nn.Module()
         self.transformer_decoder.layers = nn.ModuleList([DecLayer() for _ in range(6)])
@@ -194,32 +200,47 @@ class QueryHead(nn.Module):
         self.query_feat = nn.Embedding(num_queries, feat)
         self.level_embed = nn.Embedding(3, feat)
         self.cls_embed = nn.Sequential(nn.Linear(feat, feat), nn.ReLU(inplace=True), nn.Linear(feat, num_classes + 1))
-        self.mask_embed = nn.Sequential(nn.Linear(feat, feat), nn.ReLU(inplace=True), nn.Linear(feat, feat),
-                                        nn.ReLU(inplace=True), nn.Linear(feat, out))
+        if decoder_plus:
+            self.mask_embed = nn.Sequential(nn.Linear(feat, feat), nn.ReLU(inplace=True), nn.Linear(feat, feat),
+                                            nn.ReLU(inplace=True), nn.Linear(feat, out))
         self.point_emb = nn.Sequential(nn.Linear(feat, feat // 2), nn.ReLU(inplace=True),
                                        nn.Linear(feat // 2, feat // 2), nn.ReLU(inplace=True),
-                                       nn.Linear(feat // 2, out * 2 * per_pointset_point))
+                                       nn.Linear(feat // 2, out * (2 if with_sincos else 1) * per_pointset_point))
         self.mask_decoder = _Wrap('mask_decoder', hf_sam.build_mask_decoder())
-        self.sam_mask_embed = hf_sam.build_mask_embedding()
+        if decoder_plus:
+            self.sam_mask_embed = hf_sam.build_mask_embedding()
+        else:
+            self.no_mask_embed = nn.Embedding(1, out)
+        if input_proj:
+            self.decoder_input_projs = nn.ModuleList([nn.Conv2d(feat, feat, 1) for _ in range(3)])
+        self.input_proj = input_proj
 
     def _forward_head(self, decoder_out, mask_feature, attn_size, emb, ipe, run_sam):
         bs = emb.shape[0]
         decoder_out = self.transformer_decoder.post_norm(decoder_out)
         cls_pred = self.cls_embed(decoder_out)
-        mask_pred_plus = torch.einsum('bqc,bchw->bqhw', self.mask_embed(decoder_out), mask_feature)
+        mask_pred_plus = torch.einsum('bqc,bchw->bqhw', self.mask_embed(decoder_out), mask_feature) if self.decoder_plus else None
         mask_pred, sparse = None, None
-        if run_sam:     # models.py:644-646 keeps only the last call's SAM output
+        if run_sam or not self.decoder_plus:     # models.py:644-646 keeps only the last call's SAM output
             pe = self.point_emb(decoder_out)
             pe = einops.rearrange(pe, 'b n_set (n_point c) -> b n_set n_point c', n_point=self.npts)
-            pe = torch.sin(pe[..., ::2]) + pe[..., 1::2]
+            if self.with_sincos:
+                pe = torch.sin(pe[..., ::2]) + pe[..., 1::2]
             sparse = einops.rearrange(pe, 'b n_set n_point c -> (b n_set) n_point c').unsqueeze(1)
-            dense = self.sam_mask_embed(einops.repeat(mask_pred_plus, 'b n h w -> (b n) c h w', c=1))
+            if self.decoder_plus:
+                dense = self.sam_mask_embed(einops.repeat(mask_pred_plus, 'b n h w -> (b n) c h w', c=1))
+            else:
+                # models.py:365: expand(img_bs, ...) only broadcasts for one image; the intent -- the same no-mask vector
+                # for every prompt set -- restated for any batch
+                he, we = emb.shape[-2:]
+                dense = self.no_mask_embed.weight.reshape(1, -1, 1, 1).expand(bs * self.num_queries, -1, he, we)
             masks, _ = self.mask_decoder.mask_decoder(
                 image_embeddings=torch.repeat_interleave(emb, self.num_queries, 0),
                 image_positional_embeddings=torch.repeat_interleave(ipe, self.num_queries, 0),
                 sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense, multimask_output=False)
             mask_pred = masks.reshape(bs, -1, *masks.shape[-2:])
-        attn_mask = F.interpolate(mask_pred_plus, attn_size, mode='bilinear', align_corners=False)
+        attn_src = mask_pred_plus if self.decoder_plus else mask_pred          # models.py:380-385
+        attn_mask = F.interpolate(attn_src, attn_size, mode='bilinear', align_corners=False)
         attn_mask = attn_mask.flatten(2).unsqueeze(1).repeat((1, self.num_heads, 1, 1)).flatten(0, 1)
         attn_mask = attn_mask.sigmoid() < 0.5
         return cls_pred, mask_pred, attn_mask, mask_pred_plus, sparse
@@ -230,15 +251,17 @@ class QueryHead(nn.Module):
         mask_features, mem = self.pixel_decoder(x)
         dec_in, dec_pos = [], []
         for i in range(3):
-            d = mem[i].flatten(2).permute(0, 2, 1) + self.level_embed.weight[i].view(1, 1, -1)
+            mi = self.decoder_input_projs[i](mem[i]) if self.input_proj else mem[i]
+            d = mi.flatten(2).permute(0, 2, 1) + self.level_embed.weight[i].view(1, 1, -1)
             pe = glue.sine_positional_encoding(bs, mem[i].shape[-2], mem[i].shape[-1], num_feats=64)
             dec_in.append(d)
             dec_pos.append(pe.flatten(2).permute(0, 2, 1))
         qf = self.query_feat.weight.unsqueeze(0).repeat((bs, 1, 1))
         qe = self.query_embed.weight.unsqueeze(0).repeat((bs, 1, 1))
         trace = dict(mask_features=mask_features, memory=mem, attn_masks=[], query_feats=[qf])
-        cls, _, attn_mask, mpp, _ = self._forward_head(qf, mask_features, mem[0].shape[-2:], emb, ipe, False)
-        trace.update(cls_pred_all=[cls], mask_pred_plus_all=[mpp])
+        src_of = lambda mpp_, mask_: mpp_ if self.decoder_plus else mask_           # what the attention masks are cut from
+        cls, mask0, attn_mask, mpp, _ = self._forward_head(qf, mask_features, mem[0].shape[-2:], emb, ipe, False)
+        trace.update(cls_pred_all=[cls], mask_pred_plus_all=[src_of(mpp, mask0)])
         for i in range(6):
             lvl = i % 3
             attn_mask = attn_mask & (attn_mask.sum(-1) != attn_mask.shape[-1]).unsqueeze(-1)   # models.py:439-442
@@ -248,7 +271,7 @@ class QueryHead(nn.Module):
             cls, mask, attn_mask, mpp, sparse = self._forward_head(
                 qf, mask_features, mem[(i + 1) % 3].shape[-2:], emb, ipe, run_sam=(i == 5))
             trace['cls_pred_all'].append(cls)
-            trace['mask_pred_plus_all'].append(mpp)
+            trace['mask_pred_plus_all'].append(src_of(mpp, mask))
         trace.update(cls_pred=cls, mask_pred=mask, mask_pred_plus=mpp, sparse_embeddings=sparse)
         return cls, mask, trace
 
@@ -304,7 +327,7 @@ class QueryOracle(nn.Module):
     """RSPrompterQuery predict path, configs/rsprompter/_base_/rsprompter_query.py."""
 
     def __init__(self, arch='base', num_classes=1, num_queries=100, select_layers=None, max_per_image=100, lora=None,
-                 peft512=False):
+                 peft512=False, head_kwargs=None):
         """lora=dict(r, alpha): RSSamVisionEncoder(peft_config=...) (models.py:785-797; BASELINE.json configs[4]);
         peft512=True: the rsprompter_query-nwpu-peft-512.py tree (ViTSAM at 512 px + LoRA + PseudoFeatureAggregator)."""
         super().__init__()
@@ -322,7 +345,7 @@ class QueryOracle(nn.Module):
             self.backbone = _Wrap('vision_encoder', hf_sam.build_vision_encoder(arch, lora=lora))
             self.neck.feature_aggregator = FeatureAggregator(arch, 32, 256, select_layers)
         self.neck.feature_spliter = SimpleFPN()
-        self.panoptic_head = QueryHead(num_classes, num_queries)
+        self.panoptic_head = QueryHead(num_classes, num_queries, **(head_kwargs or {}))
         self.eval()
 
     extract_feat = AnchorOracle.extract_feat

@@ -318,8 +318,6 @@ class RSPrompterAnchorMaskHead(HIPModule):
         self.in_channels, self.roi_feat_size = in_channels, roi_feat_size
         self.per_pointset_point, self.with_sincos = per_pointset_point, with_sincos
         self.multimask_output, self.class_agnostic = multimask_output, class_agnostic
-        if multimask_output:
-            raise NotImplementedError('multimask_output=True is not used by any RSPrompter config')
         self.mask_decoder = MODELS.build(mask_decoder)
         # the reference builds a whole RSSamPromptEncoder and keeps its no_mask_embed (models.py:1628-1635)
         add_param(self, 'no_mask_embed.weight', (1, 256))
@@ -371,8 +369,10 @@ class RSPrompterAnchorMaskHead(HIPModule):
         sparse = self.point_embeddings(x)
         roi_img = roi_img_ids.to(torch.int32).contiguous()
         dec = self.mask_decoder.mask_decoder
+        # multimask_output=True (HF:537-542): three masks / iou scores per prompt set instead of one
         low_res, iou = dec.decode(image_embeddings, image_positional_embeddings, sparse,
-                                  self.no_mask_embed.weight.reshape(-1), roi_img)
+                                  self.no_mask_embed.weight.reshape(-1), roi_img,
+                                  multimask_output=bool(self.multimask_output))
         h, w = low_res.shape[-2:]
         return low_res.reshape(roi_bs, -1, h, w), iou.reshape(roi_bs, -1)
 
@@ -400,6 +400,12 @@ class RSPrompterAnchorMaskHead(HIPModule):
         thr = rcnn_test_cfg['mask_thr_binary'] if isinstance(rcnn_test_cfg, dict) else rcnn_test_cfg.mask_thr_binary
         if thr < 0:
             raise NotImplementedError('mask_thr_binary < 0 (visualisation mode)')
+        if mask_preds.shape[1] != 1:
+            # the reference's own post-processing is written for one mask per instance: with the three masks of
+            # multimask_output=True its `.squeeze(1)` is a no-op and the second F.interpolate gets a 5-D tensor
+            # (models.py:1771-1778 raises); forward() / mode='tensor' return the three masks
+            raise ValueError(f'mask post-processing expects one mask per instance, got {mask_preds.shape[1]} '
+                             '(multimask_output=True has no defined predict path in the reference either)')
         Hb, Wb = img_meta['batch_input_shape']
         crop = (min(int(img_h * sf_h), Hb), min(int(img_w * sf_w), Wb))
         h, w = img_meta['ori_shape'][:2]

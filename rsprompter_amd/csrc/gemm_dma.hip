@@ -751,10 +751,16 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
     case 4: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2>(d, s); break;
     case 5: if (d.N > 64) return launch_dma<128, 128, 2, 2, 4>(d, s); break;
     case 6: if (d.N > 64) return launch_dma<128, 128, 2, 2, 3>(d, s); break;
+#ifdef RSP_S2_ABLATIONS   /* development builds only (RSP_DEV_BUILD=1): these compute WRONG results on purpose */
     case 7: if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 1>(d, s); break;   // ablation: no DMA
     case 8: if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 2>(d, s); break;   // ablation: no MFMA
     case 9: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 1>(d, s); break;
     case 10: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 2>(d, s); break;
+    case 15: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 1, 0, 1>(d, s); break;   // ... without the DMA
+    case 16: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2, 1, 0, 1>(d, s); break;
+#else
+    case 7: case 8: case 9: case 10: case 15: case 16: return RSP_EINVAL;
+#endif
     case 11: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 0, 0, 1>(d, s); break;   // register-pipelined loops
     case 12: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2, 0, 0, 1>(d, s); break;
     case 13: if (d.N > 64) return launch_dma<256, 128, 4, 2, 3, 0, 0, 1>(d, s); break;
@@ -767,8 +773,6 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
     case 22: return launch_dma<128, 64, 2, 2, 4, 0, 0, 1>(d, s);
     case 31: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 0, 0, 2, false, 1>(d, s); break;   // pass-major MFMA order
     case 32: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2, 0, 0, 2, false, 1>(d, s); break;
-    case 15: if (d.N > 128) return launch_dma<256, 256, 2, 4, 2, 1, 0, 1>(d, s); break;   // ... without the DMA
-    case 16: if (d.N > 64) return launch_dma<256, 128, 4, 2, 2, 1, 0, 1>(d, s); break;
     default: break;
   }
   if (d.N > 64) return launch_dma<128, 128, 2, 2, 2, 0, 0, 1>(d, s);

@@ -45,13 +45,23 @@ __global__ __launch_bounds__(512) void sam_t2i_kernel(const float* __restrict__ 
 #pragma unroll
     for (int d = 0; d < HD; ++d) acc[t][d] = 0.f;
   }
-  for (int key = lane >> 1; key < N; key += 32) {
+  // the rows of the NEXT key are requested before the current key's 10 x 26 VALU operations: with two waves per SIMD
+  // and four loads per ~2 us of latency the kernel ran at 2.9 TB/s of its K | V stream (round 3); the wave's last
+  // request reads the row of its last key again (clamped: no out-of-range access)
+  int key = lane >> 1;
+  f32x4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
+  if (key < N) {
+    const float* kr = kbase + (int64_t)key * (2 * W);
+    k0 = *reinterpret_cast<const f32x4*>(kr); k1 = *reinterpret_cast<const f32x4*>(kr + 4);
+    v0 = *reinterpret_cast<const f32x4*>(kr + W); v1 = *reinterpret_cast<const f32x4*>(kr + W + 4);
+  }
+  for (; key < N; key += 32) {
     // the loop-invariant q values fit in registers next to the accumulators up to 10 tokens; beyond that they are
     // re-read from LDS (wave-uniform addresses) every key instead of being hoisted into spills
     if constexpr (TMAX > 10) asm volatile("" ::: "memory");
-    const float* kr = kbase + (int64_t)key * (2 * W);
-    const f32x4 k0 = *reinterpret_cast<const f32x4*>(kr), k1 = *reinterpret_cast<const f32x4*>(kr + 4);
-    const f32x4 v0 = *reinterpret_cast<const f32x4*>(kr + W), v1 = *reinterpret_cast<const f32x4*>(kr + W + 4);
+    const float* kn = kbase + (int64_t)min(key + 32, N - 1) * (2 * W);
+    const f32x4 nk0 = *reinterpret_cast<const f32x4*>(kn), nk1 = *reinterpret_cast<const f32x4*>(kn + 4);
+    const f32x4 nv0 = *reinterpret_cast<const f32x4*>(kn + W), nv1 = *reinterpret_cast<const f32x4*>(kn + W + 4);
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
       const f32x4 q0 = *reinterpret_cast<const f32x4*>(qbase + t * W);
@@ -70,6 +80,7 @@ __global__ __launch_bounds__(512) void sam_t2i_kernel(const float* __restrict__ 
         acc[t][4 + e] = acc[t][4 + e] * a + p * v1[e];
       }
     }
+    k0 = nk0; k1 = nk1; v0 = nv0; v1 = nv1;
   }
   // merge the 32 per-key-slot states of this (head, dim half) with a butterfly, then slot 0 normalises and stores
   for (int o = 32; o > 1; o >>= 1) {

@@ -264,6 +264,12 @@ def gather_results(results_list, dataset_size=None, group=None, stream=None, dst
         state.grow(need0.tolist())
     meta_h = torch.tensor([[k, r.masks.shape[-2], r.masks.shape[-1]] for k, r in zip(ks, results_list)],
                           dtype=torch.int32).reshape(n_img, 3)
+    # host-made pieces travel through PINNED memory: a `torch.tensor(..., device=dev)` is a synchronous copy on the side
+    # stream, i.e. it would hold the host until the whole step before it has run -- the interpreter could never get ahead
+    # of the GPU again (measured round 4: 8.8 ms of idle compute stream per step with the exchange on)
+    nk_h = torch.tensor([n_img, K], dtype=torch.int64)
+    if on_gpu:
+        meta_h, nk_h = meta_h.pin_memory(), nk_h.pin_memory()
 
     def queue():
         """all device work + collectives of one attempt; returns the tensors collect() reads and an event"""
@@ -277,8 +283,8 @@ def gather_results(results_list, dataset_size=None, group=None, stream=None, dst
             rec_parts = [torch.cat([r.bboxes.float(), r.scores.float()[:, None], r.labels.float()[:, None]], 1)
                          for r, k in zip(results_list, ks) if k]
             rec = torch.cat(rec_parts, 0) if rec_parts else torch.zeros((0, 6), dtype=torch.float32, device=dev)
-            header = torch.stack([torch.tensor(n_img, dtype=torch.int64, device=dev), torch.tensor(K, dtype=torch.int64, device=dev),
-                                  total.to(torch.int64).reshape(()), runs_needed.to(torch.int64).reshape(())])
+            header = torch.cat([nk_h.to(dev, non_blocking=True), total.to(torch.int64).reshape(1),
+                                runs_needed.to(torch.int64).reshape(1)])
             payload = [_pad_rows(meta_h.to(dev, non_blocking=True), state.img_cap), _pad_rows(rec, state.inst_cap),
                        _pad_rows(lens.to(torch.int32), state.inst_cap), _pad_rows(flat, state.byte_cap)]
             if world > 1:

@@ -218,10 +218,14 @@ class _Mask2FormerCore(HIPModule):
         self.num_transformer_decoder_layers = td['num_layers']
         self.feat_channels, self.out_channels = feat_channels, out_channels
         self.ffn_dim = td['layer_cfg']['ffn_cfg']['feedforward_channels']
-        if td['layer_cfg']['cross_attn_cfg']['embed_dims'] != feat_channels or enforce_decoder_input_project:
-            raise NotImplementedError('decoder_input_projs other than Identity are not used by any shipped config')
+        # mask2former_head.py:93-100: Conv2d(feat, feat, 1) per level when the widths differ or it is enforced
+        self.input_proj = (td['layer_cfg']['cross_attn_cfg']['embed_dims'] != feat_channels
+                           or bool(enforce_decoder_input_project))
+        if td['layer_cfg']['cross_attn_cfg']['embed_dims'] != feat_channels:
+            raise NotImplementedError('decoder width != feat_channels (pixel decoder memories are feat_channels wide)')
         if num_transformer_feat_level != 3:
-            raise NotImplementedError('three transformer feature levels (every shipped config)')
+            raise NotImplementedError('three transformer feature levels: the MSDeformAttn pixel decoder kernel is built '
+                                      'for 3 levels (every shipped config)')
         pd = copy.deepcopy(dict(pixel_decoder))
         pd.update(in_channels=in_channels, feat_channels=feat_channels, out_channels=out_channels)
         self.pixel_decoder = MODELS.build(pd)
@@ -241,6 +245,10 @@ class _Mask2FormerCore(HIPModule):
         add_param(self, 'query_embed.weight', (num_queries, f))
         add_param(self, 'query_feat.weight', (num_queries, f))
         add_param(self, 'level_embed.weight', (num_transformer_feat_level, f))
+        if self.input_proj:
+            for i in range(num_transformer_feat_level):
+                add_param(self, f'decoder_input_projs.{i}.weight', (f, f, 1, 1))
+                add_param(self, f'decoder_input_projs.{i}.bias', (f,))
         self.test_cfg, self.train_cfg = test_cfg, train_cfg
         self._const = {}
 
@@ -268,8 +276,12 @@ class _Mask2FormerCore(HIPModule):
                 d[f'{a}.o'] = _pw(at.out_proj)
             d['f0'], d['f1'] = _pw(_g(L, 'ffn.layers.0.0')), _pw(_g(L, 'ffn.layers.1'))
             P['layers'].append(d)
-        for nm in ('mask_embed.0', 'mask_embed.2', 'mask_embed.4') + tuple(linears):
+        for nm in tuple(linears):
             P[nm] = _pw(_g(self, nm))
+        if self.input_proj:
+            for i in range(self.num_transformer_feat_level):
+                m = _g(self, f'decoder_input_projs.{i}')
+                P[f'in_proj.{i}'] = ops.PackedWeight(m.weight.detach().reshape(f, f), m.bias)
         return P
 
     def _pos_tables(self, shapes, dev):
@@ -311,8 +323,10 @@ class _Mask2FormerCore(HIPModule):
             ops.gemm(me[b * Nq:(b + 1) * Nq], ops.PlaneWeight(mf_planes, b * HW0, HW0), out=mpp[b], bias=None)
         return dn, mpp
 
-    def _decode(self, x):
-        """-> (dn [B*Nq, f] post-normed last query features, mask logits [B, Nq, H0, W0], trace)"""
+    def _decode(self, x, stage_masks=None):
+        """-> (dn [B*Nq, f] post-normed last query features, mask logits [B, Nq, H0, W0], trace).
+        stage_masks(dn) -> [B, Nq, Hm, Wm] replaces the mask-embedding logits as the source of the next layer's attention
+        mask (RSMask2FormerHead with decoder_plus=False: the SAM decoder's own masks, models.py:380-385)."""
         P = self._packed
         B = x[0].shape[0]
         f, Nq = self.feat_channels, self.num_queries
@@ -325,18 +339,28 @@ class _Mask2FormerCore(HIPModule):
         dec_in, dec_kin = [], []
         for i in range(self.num_transformer_feat_level):
             m = nhwc_view(mem[i]).reshape(-1, f)
+            if self.input_proj:
+                m = ops.gemm(m, P[f'in_proj.{i}'])                                           # Conv2d 1x1 (:404-405)
             d = ops.add_rows(m, self.level_embed.weight[i:i + 1].contiguous(), vmod=1)       # + level_embed (:409-410)
             dec_in.append(d)
             dec_kin.append(ops.add_rows(d, pos_tabs[i], vmod=pos_tabs[i].shape[0]))          # key + key_pos
         qf = self.query_feat.weight.detach().unsqueeze(0).expand(B, -1, -1).reshape(B * Nq, f).contiguous()
         qe = self.query_embed.weight.detach()
         trace = dict(attn_masks=[], query_feats=[], mask_pred_plus_all=[], mask_features=mask_features, memory=mem)
-        dn, mpp = self._head_light(qf, mf_planes, B, H0 * W0)
+
+        def head(qf_):
+            if stage_masks is None:
+                dn_, mpp_ = self._head_light(qf_, mf_planes, B, H0 * W0)
+                return dn_, mpp_.view(B, Nq, H0, W0)
+            pn = _g(self, 'transformer_decoder.post_norm')
+            dn_ = ops.layernorm(qf_, pn.weight, pn.bias, 1e-5)
+            return dn_, stage_masks(dn_)
+        dn, mpp = head(qf)
         trace['mask_pred_plus_all'].append(mpp)
         for i in range(self.num_transformer_decoder_layers):
             lvl = i % self.num_transformer_feat_level
             h, w = shapes[lvl]
-            attn_mask = ops.query_attn_mask(mpp.view(B, Nq, H0, W0), (h, w))                 # :386-391 + :439-442
+            attn_mask = ops.query_attn_mask(mpp.contiguous(), (h, w))                        # :386-391 + :439-442
             trace['attn_masks'].append(attn_mask)
             W, L = P['layers'][i], _g(self, f'transformer_decoder.layers.{i}')
             qp = ops.add_rows(qf, qe, vmod=Nq)
@@ -349,9 +373,9 @@ class _Mask2FormerCore(HIPModule):
             qf = ops.gemm(hmid, W['f1'], res=qf)
             qf = ops.layernorm(qf, _g(L, 'norms.2').weight, _g(L, 'norms.2').bias, 1e-5)
             trace['query_feats'].append(qf)
-            dn, mpp = self._head_light(qf, mf_planes, B, H0 * W0)
+            dn, mpp = head(qf)
             trace['mask_pred_plus_all'].append(mpp)
-        return dn, mpp.view(B, Nq, H0, W0), trace
+        return dn, mpp, trace
 
 
 @MODELS.register_module()
@@ -371,7 +395,7 @@ class Mask2FormerHead(_Mask2FormerCore):
         self._add_mask_embed()
 
     def _pack(self):
-        self._packed = self._pack_core(('cls_embed',))
+        self._packed = self._pack_core(('cls_embed', 'mask_embed.0', 'mask_embed.2', 'mask_embed.4'))
 
     def forward(self, x, batch_data_samples=None):
         """-> (cls [B,Nq,nc+1], mask logits [B,Nq,H0,W0], trace): the LAST decoder stage, which is all predict reads"""
@@ -400,22 +424,26 @@ class RSMask2FormerHead(_Mask2FormerCore):
                  transformer_decoder=None, positional_encoding=None, loss_cls=None, loss_mask=None, loss_dice=None,
                  train_cfg=None, test_cfg=None, init_cfg=None, **kwargs):
         super().__init__()
-        if not decoder_plus:
-            raise NotImplementedError('decoder_plus=False is not used by any shipped RSPrompter config')
-        if multimask_output or not with_sincos:
-            raise NotImplementedError
-        self.per_pointset_point = per_pointset_point
+        if multimask_output:
+            # models.py:380: `mask_pred.reshape(img_bs, -1, h, w)` would fold the three masks into the query axis and the
+            # fusion head then mixes them up with queries -- no defined meaning in the reference
+            raise NotImplementedError('RSMask2FormerHead(multimask_output=True) has no consistent meaning in the reference')
+        self.per_pointset_point, self.decoder_plus, self.with_sincos = per_pointset_point, bool(decoder_plus), bool(with_sincos)
         self._init_core(in_channels, feat_channels, out_channels, num_things_classes, num_stuff_classes, num_queries,
                         num_transformer_feat_level, pixel_decoder, enforce_decoder_input_project, transformer_decoder,
                         positional_encoding, train_cfg, test_cfg)
         f = feat_channels
         _add_linear(self, 'cls_embed.0', f, f)
         _add_linear(self, 'cls_embed.2', self.num_classes + 1, f)
-        self._add_mask_embed()
         _add_linear(self, 'point_emb.0', f // 2, f)
         _add_linear(self, 'point_emb.2', f // 2, f // 2)
-        _add_linear(self, 'point_emb.4', out_channels * 2 * per_pointset_point, f // 2)
+        _add_linear(self, 'point_emb.4', out_channels * (2 if with_sincos else 1) * per_pointset_point, f // 2)
         self.mask_decoder = MODELS.build(mask_decoder)
+        if not self.decoder_plus:
+            # models.py:303-307: no mask-embedding MLP, the prompt encoder's no_mask_embed as the dense prompt
+            add_param(self, 'no_mask_embed.weight', (1, out_channels))
+            return
+        self._add_mask_embed()
         # the reference keeps prompt_encoder.mask_embed as `sam_mask_embed` (models.py:297-305)
         add_param(self, 'sam_mask_embed.conv1.weight', (4, 1, 2, 2))
         add_param(self, 'sam_mask_embed.conv1.bias', (4,))
@@ -427,7 +455,11 @@ class RSMask2FormerHead(_Mask2FormerCore):
         _add_ln(self, 'sam_mask_embed.layer_norm2', 16)
 
     def _pack(self):
-        P = self._pack_core(('cls_embed.0', 'cls_embed.2', 'point_emb.0', 'point_emb.2', 'point_emb.4'))
+        lin = ('cls_embed.0', 'cls_embed.2', 'point_emb.0', 'point_emb.2', 'point_emb.4')
+        if not self.decoder_plus:
+            self._packed = self._pack_core(lin)
+            return
+        P = self._pack_core(lin + ('mask_embed.0', 'mask_embed.2', 'mask_embed.4'))
         sm = self.sam_mask_embed
         P['sam_embed'] = dict(conv1_w=sm.conv1.weight.detach().contiguous(), conv1_b=sm.conv1.bias.detach(),
                               ln1_w=sm.layer_norm1.weight.detach(), ln1_b=sm.layer_norm1.bias.detach(),
@@ -444,15 +476,33 @@ class RSMask2FormerHead(_Mask2FormerCore):
         P = self._packed
         B = x[0].shape[0]
         Nq = self.num_queries
+        emb = nhwc_view(image_embeddings)
+        he, we = emb.shape[1], emb.shape[2]
+        roi_img = torch.arange(B, dtype=torch.int32, device=emb.device).repeat_interleave(Nq).contiguous()
+
+        def prompts(dn_):
+            pe_ = self._mlp(dn_, ('point_emb.0', 'point_emb.2', 'point_emb.4'))
+            if self.with_sincos:
+                pe_ = ops.sincos_pairs(pe_)                   # sin(x[..., ::2]) + x[..., 1::2] (models.py:346-347)
+            return pe_.view(B * Nq, self.per_pointset_point, self.out_channels)
+
+        if not self.decoder_plus:
+            # models.py:361-385: the SAM decoder runs in EVERY stage with the no_mask dense prompt and its masks drive the
+            # next layer's attention mask (the reference expands the dense prompt to img_bs rows, which only broadcasts
+            # for one image per batch; the evident intent -- the same vector for every prompt set -- is what runs here)
+            def sam_stage(dn_):
+                m_, _ = self.mask_decoder.mask_decoder.decode(image_embeddings, image_positional_embeddings, prompts(dn_),
+                                                              self.no_mask_embed.weight.reshape(-1), roi_img, want_iou=False)
+                return m_.view(B, Nq, m_.shape[-2], m_.shape[-1])
+            dn, mask_pred, trace = self._decode(x, stage_masks=sam_stage)
+            cls = self._mlp(dn, ('cls_embed.0', 'cls_embed.2')).view(B, Nq, self.num_classes + 1)
+            trace.update(mask_pred_plus=None, sparse_embeddings=prompts(dn))
+            return cls, mask_pred, trace
         dn, mpp, trace = self._decode(x)
         H0, W0 = mpp.shape[-2:]
         # ---- the last `_forward_head` in full: class logits, prompts, dense prompt, ONE SAM decoder call ----
         cls = self._mlp(dn, ('cls_embed.0', 'cls_embed.2')).view(B, Nq, self.num_classes + 1)
-        pe = self._mlp(dn, ('point_emb.0', 'point_emb.2', 'point_emb.4'))
-        sparse = ops.sincos_pairs(pe).view(B * Nq, self.per_pointset_point, self.out_channels)
-        emb = nhwc_view(image_embeddings)
-        he, we = emb.shape[1], emb.shape[2]
-        roi_img = torch.arange(B, dtype=torch.int32, device=emb.device).repeat_interleave(Nq).contiguous()
+        sparse = prompts(dn)
         src = ops.sam_mask_embed(mpp.reshape(B * Nq, H0, W0), emb.reshape(B * he * we, -1), roi_img, P['sam_embed'], he, we)
         ident = torch.arange(B * Nq, dtype=torch.int32, device=emb.device)
         masks, _ = self.mask_decoder.mask_decoder.decode(None, image_positional_embeddings, sparse, None, ident,

@@ -171,11 +171,13 @@ class SamMaskDecoderHIP(HIPModule):
                       q_strides=st, k_strides=st, v_strides=st, o_strides=st)
         return ops.gemm(o, P[pfx + '.out_proj'], res=res)
 
-    def decode(self, image_embeddings, image_pe, sparse, dense_vec, roi_img, want_iou=True, src_rows=None, hw=None):
+    def decode(self, image_embeddings, image_pe, sparse, dense_vec, roi_img, want_iou=True, src_rows=None, hw=None,
+               multimask_output=False):
         """image_embeddings [B,256,h,w] (logical NCHW, channels-last), image_pe [1|B,256,h,w] (input
         independent; batch entry 0 is used), sparse [R, n_pts, 256], dense_vec [256] (the broadcast
         `no_mask_embed`, models.py:1680), roi_img int32 [R] image index of every RoI (sorted).
-        Returns low_res_masks [R, 1, 4h, 4w] (mask token 0, multimask_output=False) and iou [R, 1]."""
+        Returns low_res_masks [R, 1, 4h, 4w] (mask token 0) and iou [R, 1]; multimask_output=True: the masks of mask
+        tokens 1..3, [R, 3, 4h, 4w], and iou [R, 3] (HF:537-542)."""
         if self._packed is None:
             self._pack()
         P = self._packed
@@ -295,32 +297,39 @@ class SamMaskDecoderHIP(HIPModule):
         q3 = q.view(R, T, HID)
 
         # ---------------- upscaling + hyper-network (HF:513-531) ----------------
-        mt = q3[:, 1, :].contiguous()           # mask token 0 -> the only mask kept (HF:537-542)
-        hy = ops.gemm(mt, P['hyper0.proj_in'], act=ops.ACT_RELU)
-        hy = ops.gemm(hy, P['hyper0.layers.0'], act=ops.ACT_RELU)
-        hy = ops.gemm(hy, P['hyper0.proj_out'])
+        # mask token 0 is the only mask kept with multimask_output=False, tokens 1..3 otherwise (HF:537-542)
+        toks = (1, 2, 3) if multimask_output else (0,)
         # both ConvTransposes run as one GEMM each (columns = (dy, dx, co), planes in); the second one never
         # stores its [R, 4h, 4w, 32] result: GELU and the product with hyper_in happen in its epilogue
         up = ops.conv_transpose2x2(keys_pl.view(R, h, w, HID), *P['up1'], act=ops.ACT_GELU,
                                    ln=(self.upscale_layer_norm.weight, self.upscale_layer_norm.bias, 1e-6))
         del keys_pl                                                                     # [R, 2h, 2w, 64] planes
-        masks = ops.conv_transpose2x2(up, *P['up2'], act=ops.ACT_GELU, hyper=hy).view(R, 1, 4 * h, 4 * w)
+        outs = []
+        for i in toks:
+            mt = q3[:, 1 + i, :].contiguous()
+            hy = ops.gemm(mt, P[f'hyper{i}.proj_in'], act=ops.ACT_RELU)
+            hy = ops.gemm(hy, P[f'hyper{i}.layers.0'], act=ops.ACT_RELU)
+            hy = ops.gemm(hy, P[f'hyper{i}.proj_out'])
+            # (multimask: the last ConvTranspose is recomputed per token -- a rarely used option, no [R,4h,4w,32] tensor)
+            outs.append(ops.conv_transpose2x2(up, *P['up2'], act=ops.ACT_GELU, hyper=hy).view(R, 1, 4 * h, 4 * w))
+        masks = outs[0] if len(outs) == 1 else torch.cat(outs, 1)
         iou = None
         if want_iou:
             it = q3[:, 0, :].contiguous()
             io = ops.gemm(it, P['iou.proj_in'], act=ops.ACT_RELU)
             io = ops.gemm(io, P['iou.layers.0'], act=ops.ACT_RELU)
-            iou = ops.gemm(io, P['iou.proj_out'])[:, 0:1]
+            io = ops.gemm(io, P['iou.proj_out'])
+            iou = io[:, 1:4].contiguous() if multimask_output else io[:, 0:1]
         return masks, iou
 
     def forward(self, image_embeddings, image_positional_embeddings, sparse_prompt_embeddings,
                 dense_prompt_embeddings, multimask_output=False, attention_similarity=None,
                 target_embedding=None, output_attentions=None):
         """HF-compatible signature (HF:461-543) for callers that already repeated the image tensors per
-        prompt set: every batch entry is treated as its own image.  Only the configuration used by
-        RSPrompter (point_batch_size 1, multimask_output=False, constant dense prompt) is supported."""
-        if multimask_output or attention_similarity is not None or target_embedding is not None:
-            raise NotImplementedError('only multimask_output=False without attention_similarity/target_embedding')
+        prompt set: every batch entry is treated as its own image.  point_batch_size 1, constant dense prompt;
+        multimask_output=True returns the three masks of mask tokens 1..3 (HF:537-542)."""
+        if attention_similarity is not None or target_embedding is not None:
+            raise NotImplementedError('attention_similarity / target_embedding (HF SamAttention hooks) are not implemented')
         R = image_embeddings.shape[0]
         if sparse_prompt_embeddings.dim() == 4:
             if sparse_prompt_embeddings.shape[1] != 1:
@@ -334,7 +343,7 @@ class SamMaskDecoderHIP(HIPModule):
         dense_vec = d[0, 0, 0].contiguous()
         roi_img = torch.arange(R, dtype=torch.int32, device=image_embeddings.device)
         masks, iou = self.decode(image_embeddings, image_positional_embeddings, sparse.contiguous(), dense_vec,
-                                 roi_img)
+                                 roi_img, multimask_output=bool(multimask_output))
         return masks.unsqueeze(1), iou.unsqueeze(1), None
 
 

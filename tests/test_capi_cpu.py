@@ -70,6 +70,9 @@ def test_shipped_library_has_no_ablation_kernels():
     want = {4, 5, 21, 12, 28, 8, 10, 6, 64}       # E_C, +RES, +RES+RMAP, C+PL, C+PL+RMAP, PL, PL+GELU, C+GELU, run-time
     assert {int(e) for _, e in inst} == want, sorted(inst)
     assert 'rsp_debug_s2_trace' not in out
+    # gemm_f16x3_dma_kernel<BM, BN, WGM, WGN, NBUF, ABL, ...>: ABL (6th argument) != 0 are the no-DMA / no-MFMA ablations
+    abl = set(re.findall(r'gemm_f16x3_dma_kernel<\d+, \d+, \d+, \d+, \d+, (\d+),', out))
+    assert abl == {'0'}, abl
     lib = _lib.load()
     d = _lib.RspGemmDesc()
     assert lib.rsp_gemm_s2_epilogue(None) == -1 and lib.rsp_gemm_s2_epilogue(ctypes.byref(d)) == -1

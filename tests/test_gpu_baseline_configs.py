@@ -88,9 +88,10 @@ def _flips_are_ties(our_masks, ref_trace, n_img, pick=None):
     touched, flips, worst = None, [], 0.0
     for i, (a, b) in enumerate(zip(our_masks, ref_trace['attn_masks'])):
         nq = b.shape[-2]
-        ours = a.cpu().bool().view(-1, 8, nq, a.shape[-1])[:, 0]
+        ours = a.cpu().bool().view(-1, nq, a.shape[-1])                      # rsp_query_attn_mask: [B, Nq, HW], heads share it
         if pick is not None:
             ours = ours[pick]
+        assert ours.shape[0] == n_img
         ref_m = b.cpu().bool().view(n_img, -1, nq, b.shape[-1])[:, 0]
         size = ref_trace['memory'][i % 3].shape[-2:]
         z = F.interpolate(ref_trace['mask_pred_plus_all'][i].float(), size, mode='bilinear', align_corners=False).flatten(2)
@@ -400,6 +401,59 @@ def test_config4_query_vith_lora_batch4(dev):
         assert int((~same).sum()) <= 4
         mism = float((pi.masks.cpu()[same] != r['masks'][same]).float().mean())
         assert mism < 1e-3
+
+
+@pytest.mark.parametrize('opts', [dict(decoder_plus=False), dict(with_sincos=False), dict(enforce_decoder_input_project=True)])
+def test_query_head_option_branches(dev, opts):
+    """RSMask2FormerHead branches no shipped config selects (models.py:303-307 / 361-385 decoder_plus=False: the SAM decoder
+    runs in all 7 stages and its masks drive the attention masks; :315-318 / 346-347 with_sincos=False;
+    mask2former_head.py:93-100 enforce_decoder_input_project) on the device against the oracle, ViT-B, 2 tiles, Nq = 30."""
+    from oracle.query import QueryOracle
+    from rsprompter_amd.default_configs import rsprompter_query
+    from rsprompter_amd.synth import synth_images, synth_metas
+    NQ = 30
+    cfg = rsprompter_query('base', 1, (NQ, 5), max_per_image=20)
+    cfg['panoptic_head'].update(opts)
+    hk = dict(decoder_plus=opts.get('decoder_plus', True), with_sincos=opts.get('with_sincos', True),
+              input_proj=opts.get('enforce_decoder_input_project', False))
+    oracle = QueryOracle('base', 1, NQ, max_per_image=20, head_kwargs=hk)
+    model = _build(cfg, oracle, dev, seed=5)
+    imgs, metas = synth_images(2, seed=11), synth_metas(2)
+    _check_query(model, oracle, imgs, metas, dev, f'query ViT-B {opts}')
+
+
+def test_anchor_mask_head_multimask_output(dev):
+    """RSPrompterAnchorMaskHead(multimask_output=True): the three masks / iou scores of mask tokens 1..3 (HF:537-542) against
+    the HF decoder fed the oracle's prompts."""
+    from oracle import hf_sam
+    from rsprompter_amd.registry import MODELS
+    from rsprompter_amd.synth import synth_state_dict
+    head = MODELS.build(dict(type='RSPrompterAnchorMaskHead', mask_decoder=dict(type='RSSamMaskDecoder', hf_pretrain_name='sam_vit_base'),
+                             in_channels=256, roi_feat_size=14, per_pointset_point=5, with_sincos=True, multimask_output=True,
+                             class_agnostic=True))
+    sd = synth_state_dict(head, 3)
+    head.load_state_dict(sd)
+    head = head.to(dev)
+    dec = hf_sam.build_mask_decoder()
+    dec.load_state_dict({k[len('mask_decoder.mask_decoder.'):]: v for k, v in sd.items() if k.startswith('mask_decoder.mask_decoder.')})
+    g = torch.Generator().manual_seed(0)
+    R, B = 7, 2
+    x = torch.randn(R, 256, 14, 14, generator=g)
+    emb = torch.randn(B, 256, 64, 64, generator=g)
+    ipe = torch.randn(1, 256, 64, 64, generator=g).expand(B, -1, -1, -1).contiguous()
+    roi_img = torch.tensor([0, 0, 0, 1, 1, 1, 1])
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    low, iou = head(cl(x), cl(emb), cl(ipe), roi_img.to(dev))
+    assert tuple(low.shape) == (R, 3, 256, 256) and tuple(iou.shape) == (R, 3)
+    sparse = head.point_embeddings(cl(x)).cpu()
+    with torch.no_grad():
+        ref_m, ref_i = dec(image_embeddings=emb[roi_img], image_positional_embeddings=ipe[roi_img],
+                           sparse_prompt_embeddings=sparse.unsqueeze(1),
+                           dense_prompt_embeddings=sd['no_mask_embed.weight'].reshape(1, -1, 1, 1).expand(R, -1, 64, 64),
+                           multimask_output=True)[:2]
+    e_m, e_i = _maxerr(low, ref_m.reshape(R, 3, 256, 256)), _maxerr(iou, ref_i.reshape(R, 3))
+    print(f'multimask_output=True: masks err {e_m:.2e} (range {float(ref_m.abs().max()):.1f}), iou err {e_i:.2e}')
+    assert e_m < LOGIT_TOL and e_i < LOGIT_TOL
 
 
 def test_encoder_batch8_row_maps(dev):

@@ -210,42 +210,53 @@ def _step_loop(model, imgs, metas, dev, world, n_steps, group_kw):
     return gathered, local, timing
 
 
-def _build_vitb(dev):
+def _build_vit(dev, arch='base'):
     import warnings
     import rsprompter_amd as ra
     from rsprompter_amd.default_configs import rsprompter_anchor
     from rsprompter_amd.synth import synth_state_dict
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
-        model = ra.build_model(rsprompter_anchor('base', 10))
+        model = ra.build_model(rsprompter_anchor(arch, 10))
     model.load_state_dict(synth_state_dict(model, seed=0), strict=True)
     return model.to(dev)
 
 
-def test_bench_step_loop_host_keeps_ahead_and_gather_overlaps(dev):
+@pytest.mark.parametrize('arch', ['huge', 'base'])
+def test_bench_step_loop_exchange_costs_no_gpu_time(dev, arch):
     """The weak-scaling preconditions of `bench.py --gpus N` that one GPU can show (no 8-GPU node was available to the
-    driver): on the LIGHTEST bench configuration (rsprompter_anchor ViT-B, 8 tiles: configs[1]) (c) the host needs less
-    time to enqueue a step -- ~700 launches, the result codec, the exchange -- than the GPU needs to run it, so N processes
-    on N GPUs do not queue up behind their interpreters; (b) the exchange of step i runs on its side stream while step
-    i + 1 already occupies the compute stream: step i + 1 starts without waiting for it."""
+    driver), on the headline configuration (rsprompter_anchor ViT-H, 8 tiles per GPU: the configs[3] slice) and on the
+    lightest one (ViT-B, configs[1]): the loop WITH the result exchange -- device RLE codec, header / payload collectives,
+    pinned-host copy, all queued on a side stream when a step ends and collected after the next step has been launched --
+    must take the time of the loop WITHOUT it: (b) the exchange of step i finishes on its stream after step i + 1 has
+    started on the compute stream, (c) the compute stream does not wait for the interpreter between steps.  Round 4 found
+    8.8 ms of idle compute stream per step here (synchronous `torch.tensor(..., device=)` copies on the side stream held the
+    host until the step had run); this test keeps that from coming back."""
+    import time
+    from rsprompter_amd.structures import DetDataSample
     from rsprompter_amd.synth import synth_images, synth_metas
-    model = _build_vitb(dev)
+    model = _build_vit(dev, arch)
     imgs = [im.to(dev) for im in synth_images(8, seed=1234)]
     metas = synth_metas(8)
     _step_loop(model, imgs, metas, dev, 1, 2, {})                                      # warm-up (packing, allocator)
-    gathered, local, timing = _step_loop(model, imgs, metas, dev, 1, 4, {})
-    gpu_ms = [t['start'].elapsed_time(t['end']) for t in timing]
-    host_ms = [1e3 * t['host_s'] for t in timing]
+    n = 5
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        model.test_step(dict(inputs=imgs, data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
+    torch.cuda.synchronize()
+    plain_ms = 1e3 * (time.perf_counter() - t0) / n
+    t0 = time.perf_counter()
+    gathered, local, timing = _step_loop(model, imgs, metas, dev, 1, n, {})
+    with_ms = 1e3 * (time.perf_counter() - t0) / n
     gaps = [timing[i]['end'].elapsed_time(timing[i + 1]['start']) for i in range(len(timing) - 1)]
     side_after_next_start = [timing[i + 1]['start'].elapsed_time(timing[i]['side_end']) for i in range(len(timing) - 1)]
-    print(f'ViT-B x 8 tiles: GPU {["%.1f" % v for v in gpu_ms]} ms / step, host enqueue {["%.1f" % v for v in host_ms]} ms, '
-          f'bubble between steps {["%.2f" % v for v in gaps]} ms, exchange of step i ends {["%.2f" % v for v in side_after_next_start]} '
+    print(f'ViT-{arch} x 8 tiles: {plain_ms:.1f} ms / step without the exchange, {with_ms:.1f} ms with it; compute stream idle '
+          f'between steps {["%.2f" % v for v in gaps]} ms; exchange of step i ends {["%.2f" % v for v in side_after_next_start]} '
           f'ms after step i + 1 started')
     assert all(len(g) == 8 for g in gathered)
-    # (c) steady-state steps (the first of a loop pays the previous loop's drain)
-    assert max(host_ms[1:]) < 0.9 * min(gpu_ms[1:]), (host_ms, gpu_ms)
-    # (b) the next step starts right behind the previous one, the exchange finishes later on its own stream
-    assert max(gaps[1:]) < 1.0 and min(side_after_next_start) > 0.0
+    assert with_ms < 1.03 * plain_ms + 1.0, (with_ms, plain_ms)
+    assert max(gaps) < 2.0 and min(side_after_next_start) > 0.0
 
 
 def _worker_loop(rank, world, port, ret):
@@ -257,7 +268,7 @@ def _worker_loop(rank, world, port, ret):
     dev = torch.device('cuda:0')
     try:
         rdist.init_from_env(backend='gloo')
-        model = _build_vitb(dev)
+        model = _build_vit(dev)
         imgs = [im.to(dev) for im in synth_images(2, seed=1234 + 1000 * rank)]       # bench.py's per-rank fixture
         gathered, local, timing = _step_loop(model, imgs, synth_metas(2), dev, world, 3, {})
         ret[rank] = dict(gathered=None if gathered[0] is None else [[dict(b=g['bboxes'], n=len(g['masks'])) for g in step]
