@@ -214,7 +214,7 @@ int rsp_vit_attention_planes_ex(const float* q, int64_t q_ld, const uint16_t* kv
 /* Windowed layers, rel-pos terms computed INSIDE the attention kernel (csrc/attn_win.hip; replaces the pair             */
 /* rsp_vit_relpos_rows + rsp_vit_attention_planes_ex of a windowed SamVisionAttention.forward, HF:803-831 + 761-801):     */
 /* rel_tab = the layer's two tables packed once by rsp_pack_relpos_tables; q / K | V planes / outputs / window grid as    */
-/* above with S = 14.  The kernel is persistent (a block walks the windows of one head); variant: 0 = product (512        */
+/* above with S = 14.  The kernel is persistent (a block walks the windows of one head); variant: 0 = product (768        */
 /* blocks), n > 0 = 16 n blocks (tests and measurements).                                                                 */
 int rsp_vit_window_attention(const float* q, int64_t q_ld, const uint16_t* kv_hi, const uint16_t* kv_lo,
                              int64_t kv_rows, int32_t kv_scale_log2, const uint16_t* rel_tab, float* out,

@@ -30,9 +30,10 @@ constexpr float LAZY_LOG2 = 8.0f;             // the running maximum follows a t
 constexpr float LOG2E_C = 1.4426950408889634f;
 constexpr float NEG_RAW = -60000.0f;          // bias of a padded key in the raw score domain (exp2 underflows to 0)
 constexpr int WT = 196, WS = 14, KT = 32, NTILE = 7;
-// ring of 4 buffers, DMA two tiles ahead: tile kt lives in buffer kt % 4 and the next window's tiles 0, 1 (queued behind
-// tiles 5, 6) land in buffers 0, 1, which tiles 4, 5 have left -- every window starts at buffer 0 (compile-time addresses)
-constexpr int NBUF = 4, AHEAD = 2;
+// ring of 4 buffers, tile kt in buffer kt % 4, worked on in pairs (one barrier per two tiles): while tiles 2p, 2p + 1 are
+// multiplied, tiles 2p + 2, 2p + 3 land in the other two buffers; the next window's tiles 0, 1 are queued behind tile 6
+// into buffers 0, 1 -- every window starts at buffer 0 (compile-time addresses)
+constexpr int NBUF = 4;
 constexpr int OH_PITCH = 80;                  // bytes per key row of the one-hot table (32 halves + pad: conflict-free b128)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -213,8 +214,6 @@ __global__ __launch_bounds__(448) void attn_win_kernel(const AttnWP p, const int
   };
   issue_tile(0, 0, 0);
   issue_tile(1, 1, 0);
-  // DMA instructions this WAVE issues per tile: the last one covers only the first waves (vmcnt counts per wave)
-  const bool dma_full = (NDMA - 1) * NT + wave * 64 < TILE_UNITS;      // wave-uniform
 
   // ---- per item: which query this lane owns.  Windows cut from a padded grid (HF:900-922): the windows of the last
   // row / column hold only win_real real rows / columns; their padded tokens are keys like any other (k = v = bias) but
@@ -457,25 +456,30 @@ __global__ __launch_bounds__(448) void attn_win_kernel(const AttnWP p, const int
       });
     };
 
-    auto tile_body = [&](auto tc) {
-      constexpr int kt = decltype(tc)::value;
-      // this wave's part of tile kt must have landed; the next tile (of this window or the next) may stay in flight.
-      // vmcnt retires in order: older q loads / result stores only make the wait conservative.
-      if (kt + 1 < NTILE || has_next) {
-        if (dma_full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA - 1) : "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __builtin_amdgcn_s_barrier();                        // ... everybody's part; the buffer tile kt - 2 lived in is drained
-      if constexpr (kt + AHEAD < NTILE) issue_tile(kt + AHEAD, (kt + AHEAD) % NBUF, 0);
-      else if (has_next) issue_tile(kt + AHEAD - NTILE, kt + AHEAD - NTILE, 1);
+    // Two tiles per barrier: behind barrier #p (p = 0..3) the waves run tiles 2p and 2p + 1 (the 7th tile stands alone)
+    // and queue the two tiles after those -- the next window's first two behind tile 6 -- into the buffers that tiles
+    // 2p - 2 and 2p - 1 left before the barrier.  Everything a wave waits for at a barrier was queued a whole pair earlier
+    // (vmcnt(0): nothing younger is in flight), and the waves meet 4 times per window instead of 7 (PMC, one tile per
+    // barrier: the waves stood at barriers / waits for half of their cycles).
+    auto pair_body = [&](auto pc) {
+      constexpr int pr = decltype(pc)::value, t0 = 2 * pr, t1 = 2 * pr + 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's parts of tiles t0 and t1 have landed
+      __builtin_amdgcn_s_barrier();                        // ... everybody's; tiles t0 - 2 and t0 - 1 are drained
+      constexpr bool last = t0 + 1 >= NTILE;               // the pair of the window's last tile: the next window's turn
+      if constexpr (t0 + 2 < NTILE) issue_tile(t0 + 2, (t0 + 2) % NBUF, 0);
+      else if constexpr (last) { if (has_next) issue_tile(0, 0, 1); }
+      if (!dead) phase_q(std::integral_constant<int, t0>{});
+      if constexpr (t0 + 3 < NTILE) issue_tile(t0 + 3, (t0 + 3) % NBUF, 0);
+      else if constexpr (last) { if (has_next) issue_tile(1, 1, 1); }
       if (dead) return;                                    // no real query in this wave
-      phase_q(tc);
-      phase_sp(tc);
+      phase_sp(std::integral_constant<int, t0>{});
+      if constexpr (t1 < NTILE) {
+        phase_q(std::integral_constant<int, t1>{});
+        phase_sp(std::integral_constant<int, t1>{});
+      }
     };
 
-    static_for_w<0, NTILE>([&](auto tc) { tile_body(tc); });
+    static_for_w<0, (NTILE + 1) / 2>([&](auto pc) { pair_body(pc); });
 
     // the next window's q rows travel while this one's results are normalised and stored (qh / qlo are dead by now)
     Item nxt = cur;
@@ -555,9 +559,10 @@ int launch_win(const AttnWP& p, int Bp, int grid16, hipStream_t s) {
   // a block keeps its head; `variant` of the C entry sets the grid in units of 16 blocks for tests (1: every block walks
   // several windows even on a small input) and measurements; 0 = 256 blocks
   const int n_items = Bp * p.nh;
-  // 512 blocks = two rounds per CU: the hardware's block dispatch evens out what windows with fewer real queries finish
-  // early (0.301 vs 0.324 ms per ViT-H layer against exactly one block per CU)
-  int grid = 16 * (grid16 > 0 ? grid16 : 32);
+  // 768 blocks = three rounds per CU: the hardware's block dispatch evens out what windows with fewer real queries finish
+  // early (per ViT-H layer, batch 8: 0.325 ms with exactly one block per CU, 0.296 with 512 blocks, 0.274 with 768,
+  // 0.279 with 1024: profiles/r4_attn_win_micro_pairs.txt)
+  int grid = 16 * (grid16 > 0 ? grid16 : 48);
   if (grid > n_items) grid = n_items;
   grid = grid / p.nh * p.nh;
   if (grid < p.nh) grid = p.nh;

@@ -55,7 +55,8 @@ def main():
         real = pad * 4096 / 4900                      # 64 x 64 real tokens of the 5 x 5 x 196 padded ones are queries
         rows = torch.arange(Bp * 196, device=dev, dtype=torch.int32)
         forms = {
-            'fused, 256 persistent blocks (product)': lambda: ops.vit_window_attention(q, kv, tab, Bp, nh, dh, sc, planes=True, win_grid=(5, 8)),
+            'fused, product (768 blocks)': lambda: ops.vit_window_attention(q, kv, tab, Bp, nh, dh, sc, planes=True, win_grid=(5, 8)),
+            'fused, 256 blocks (one per CU)': lambda: ops.vit_window_attention(q, kv, tab, Bp, nh, dh, sc, planes=True, win_grid=(5, 8), variant=16),
             'fused, 512 blocks (two rounds)': lambda: ops.vit_window_attention(q, kv, tab, Bp, nh, dh, sc, planes=True, win_grid=(5, 8), variant=32),
             'fused, 768 blocks': lambda: ops.vit_window_attention(q, kv, tab, Bp, nh, dh, sc, planes=True, win_grid=(5, 8), variant=48),
             'fused, 1024 blocks': lambda: ops.vit_window_attention(q, kv, tab, Bp, nh, dh, sc, planes=True, win_grid=(5, 8), variant=64),

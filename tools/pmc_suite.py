@@ -88,7 +88,11 @@ def main():
             rph = torch.randn(2 * S - 1, dh, device=dev) * 0.05
             rpw = torch.randn(2 * S - 1, dh, device=dev) * 0.05
 
-            def fn():      # the encoder's sequence: rel-pos terms, then the plane-fed attention (csrc/attn_stream.hip)
+            tab = ops.pack_relpos_tables(rph, rpw, S, dh) if S == 14 else None
+
+            def fn():      # the encoder's sequence: global layers rel-pos terms + plane-fed attention (csrc/attn_stream.hip),
+                if S == 14:    # windowed layers ONE kernel (csrc/attn_win.hip), padded queries of the 5 x 5 grid skipped
+                    return ops.vit_window_attention(q, kv, tab, Bp, nh, dh, dh ** -0.5, planes=True, win_grid=(5, 8))
                 rel = ops.vit_relpos(q, rph, rpw, Bp, S, nh, dh, q_ld=D)
                 return ops.vit_attention_planes(q, kv, rel, Bp, S, nh, dh, dh ** -0.5, planes=True)
             ms = timed(fn, args.iters)
