@@ -35,11 +35,11 @@ except Exception as e:
 PY
        ;;
     p) rm -rf "$O/prof_$name"
-       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/$O/prof_$name" -o run -- python "$OLDPWD/bench.py" $args --no-cpu-baseline > "$OLDPWD/$O/prof_$name.json" 2> "$OLDPWD/$O/prof_$name.err"); rc=$?
+       (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$O/prof_$name" -o run -- python "$OLDPWD/bench.py" $args --no-cpu-baseline > "$OLDPWD/$O/prof_$name.json" 2> "$OLDPWD/$O/prof_$name.err"); rc=$?
        f=$(find "$O/prof_$name" -name '*kernel_stats.csv' | head -n 1)
        [ -n "$f" ] && cp "$f" "$O/prof_${name}_kernel_stats.csv" && head -n 6 "$f" | cut -c1-160
-       # the trace itself is large: keep the summary only
-       find "$O/prof_$name" -name '*kernel_trace.csv' -delete ;;
+       # the trace / database files are large (gpurun copies back at most 64 MiB): keep the summary only
+       rm -rf "$O/prof_$name" ;;
     x) timeout 900 bash -c "$args" > "$O/$name.log" 2>&1; rc=$?
        tail -n 4 "$O/$name.log" | cut -c1-300 ;;
     c|m) P="$O/pmc_$name"; rm -rf "$P"; mkdir -p "$P"; rc=0
@@ -55,6 +55,8 @@ PY
        fi
        python tools/pmc_report.py "$P" --json "$O/pmc_${name}_report.json" > "$O/pmc_${name}_report.txt" 2>&1
        find "$P" -name "*agent_info.csv" -delete
+       find "$P" -type f ! -name "*counter_collection.csv" ! -name "*.log" -delete
+       find "$P" -type f -size +4M -delete
        grep -E "^[a-z_A-Z0-9<>, ]+grid=|mfma_busy|pct_of_wave|per_mfma" "$O/pmc_${name}_report.txt" | head -n 40 | cut -c1-150 ;;
     *) echo "unknown step $step"; rc=99 ;;
   esac
