@@ -92,7 +92,9 @@ __device__ __forceinline__ void sfor(F&& f) {
 }
 
 // VAR (experiment switches; 0 = product, the only value instantiated unless the library is built with
-// -DRSP_S2_ABLATIONS -- the ablations compute WRONG results on purpose and do not belong into a shipped library): bit 0 = result stores with the non-temporal hint (was: raised wave priority in the epilogue -- no effect), bit 1 = epilogue without its stores (ablation), bit 2 = no DMA
+// -DRSP_S2_ABLATIONS -- the ablations compute WRONG results on purpose and do not belong into a shipped library): VAR == 1
+// and VAR == 33 are the two scheduling experiments of round 4 (see `step`; profiles/r4_gemm_s2_priority_and_burst_experiments.txt:
+// priority +5 % on proj, -2 % on lin2, 0 elsewhere; burst -3 ... -6 %: neither adopted); otherwise bit 0 = result stores with the non-temporal hint (was: raised wave priority in the epilogue -- no effect), bit 1 = epilogue without its stores (ablation), bit 2 = no DMA
 // inside the K loop (ablation, garbage results), bit 3 = no epilogue (ablation), bit 4 = every DMA reads the first K block
 // (cache-hot sources: separates memory latency from issue / LDS-write cost; garbage results), bit 5 = time stamps
 template <int VAR, int EPI>
@@ -206,6 +208,14 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
     constexpr int VM = decltype(vmc)::value;
     __builtin_amdgcn_s_waitcnt(wc_vm_lgkm0(VM));
     __builtin_amdgcn_s_barrier();
+    // development-build experiments (round 4): VAR == 1 raises the wave's priority while it issues its DMA slots (the
+    // partner wave of the other block then yields issue slots to the 60-185-cycle buffer_load ... lds instructions);
+    // VAR == 33 issues the six DMA instructions in one burst behind the barrier instead of between the last MFMAs
+    constexpr bool X_PRIO = (VAR == 1), X_BURST = (VAR == 33);
+    if constexpr (DMA && X_BURST) {
+      sfor<0, NDMA>([&](auto ic) { issue_slot(ic, tl, t + 3, oc); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
     sfor<0, 24>([&](auto qc) {
       constexpr int q = decltype(qc)::value;
       mfma_q(qc, fc);
@@ -214,8 +224,10 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
         read_frag(qc, fn, on);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if constexpr (DMA && q >= 12 && (q & 1) == 0) {
+      if constexpr (DMA && !X_BURST && q >= 12 && (q & 1) == 0) {
+        if constexpr (X_PRIO && q == 12) __builtin_amdgcn_s_setprio(1);
         issue_slot(std::integral_constant<int, (q - 12) / 2>{}, tl, t + 3, oc);
+        if constexpr (X_PRIO && q == 22) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
       }
     });
@@ -407,7 +419,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
       constexpr int NG = 8;                                   // read-back groups per 32-row pass: 4 rows x 64 columns
       // VAR & 1 (experiment): results stored with the non-temporal hint -- they are not read again by this kernel and
       // should not push operand lines out of the L2 (the K-streams of 64 concurrent tiles per XCD live there)
-      constexpr int ST_AUX = (VAR & 1) ? 2 : 0;
+      constexpr int ST_AUX = 0;      // (round 3: non-temporal result stores, VAR & 1 -- measured +-2 %, not adopted)
       const float alpha = d.alpha;
       const float cs = (EPI & E_PL) ? ldexpf(1.0f, RSP_PLANE_EXP(d.c_scale_log2)) : 1.0f;
       const int cols0 = done.n0 + wn * 64;                    // scalar: first column of this wave
@@ -637,13 +649,13 @@ int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s) {
   S2_CASE(0, E_C | E_GELU);
   S2_CASE(0, E_GENERIC);
 #ifdef RSP_S2_ABLATIONS          /* tools/gemm_s2_exp.py time: RSP_DEV_BUILD=1 python -m rsprompter_amd.build */
-  S2_CASE(1, E_C | E_RES); S2_CASE(1, E_PL | E_GELU);          // non-temporal result stores
+  S2_CASE(1, E_C | E_RES); S2_CASE(1, E_PL | E_GELU);          // raised priority around the DMA slots (round 4)
   S2_CASE(2, E_C | E_RES); S2_CASE(2, E_PL | E_GELU); S2_CASE(2, E_PL); S2_CASE(8, E_PL);   // no stores
   S2_CASE(4, E_C | E_RES); S2_CASE(4, E_PL | E_GELU);          // no DMA in the loop
   S2_CASE(8, E_C | E_RES); S2_CASE(8, E_PL | E_GELU);          // no epilogue
   S2_CASE(16, E_C | E_RES); S2_CASE(16, E_PL | E_GELU);        // cache-hot DMA sources
   S2_CASE(32, E_C | E_RES); S2_CASE(32, E_PL | E_GELU);        // time stamps
-  S2_CASE(33, E_C | E_RES); S2_CASE(33, E_PL | E_GELU);        // time stamps + non-temporal stores
+  S2_CASE(33, E_C | E_RES); S2_CASE(33, E_PL | E_GELU);        // the six DMA slots of a step as one burst (round 4)
   S2_CASE(1, E_C); S2_CASE(1, E_C | E_PL);
 #endif
 #undef S2_CASE

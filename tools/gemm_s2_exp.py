@@ -179,11 +179,11 @@ def time_all():
         'lin2 M=32768 N=1280 K=5120 +res': (Mg, D, MLP, lambda h: ops.gemm(xm, w_lin2, out=o_x, res=res, tile_hint=h)),
     }
     variants = [('product', 0), ('r2 auto', 1), ('r2 256x256', 17), ('s2', S2), ('s2 generic-epi', S2 + 64),
-                ('s2 nt-stores', S2 + 1), ('s2 noDMA*', S2 + 4), ('s2 noEpi*', S2 + 8), ('s2 hotDMA*', S2 + 16)]
+                ('s2 prio-DMA', S2 + 1), ('s2 DMA-burst', S2 + 33), ('s2 noDMA*', S2 + 4), ('s2 noEpi*', S2 + 8), ('s2 hotDMA*', S2 + 16)]
     only = {'qkv_window_scatter': ('product', 'r2 auto', 'r2 256x256', 's2', 's2 generic-epi'),
             'proj_window_gather': ('product', 'r2 auto', 'r2 256x256', 's2', 's2 generic-epi'),
-            'qkv_window': ('product', 'r2 auto', 'r2 256x256', 's2', 's2 generic-epi', 's2 nt-stores'),
-            'qkv_global': ('product', 'r2 auto', 'r2 256x256', 's2', 's2 generic-epi', 's2 nt-stores')}   # variants exist for proj / lin shapes
+            'qkv_window': ('product', 'r2 auto', 'r2 256x256', 's2', 's2 generic-epi', 's2 prio-DMA', 's2 DMA-burst'),
+            'qkv_global': ('product', 'r2 auto', 'r2 256x256', 's2', 's2 generic-epi', 's2 prio-DMA', 's2 DMA-burst')}   # variants exist for proj / lin shapes
     for name, (M, N, K, fn) in cases.items():
         vs = [(vn, h) for vn, h in variants if name.split(' ')[0] not in only or vn in only[name.split(' ')[0]]]
         def guarded(h):
@@ -200,7 +200,7 @@ def time_all():
     a = ops.to_planes(torch.randn(n, n, device=dev))
     w = mk(n, n, bias=False)
     o = torch.empty(n, n, device=dev)
-    vs = [(vn, h) for vn, h in variants if vn in ('product', 'r2 auto', 'r2 256x256', 's2', 's2 nt-stores')]     # plain epilogue: no variants
+    vs = [(vn, h) for vn, h in variants if vn in ('product', 'r2 auto', 'r2 256x256', 's2')]     # plain epilogue: no variants
     ms = timed_rounds({vn: (lambda h=h: ops.gemm(a, w, out=o, tile_hint=h)) for vn, h in vs}, rounds=3, iters=2)
     print('8192^3:  ' + '  '.join(f'[{vn}] {t:.3f} ms {2.0 * n ** 3 / t / 1e9:.0f}' for vn, t in ms.items()), flush=True)
 
