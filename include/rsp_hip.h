@@ -314,6 +314,17 @@ int rsp_roi_align(const RspRoiAlignDesc* desc, rsp_stream_t stream);
 /* bbox_nms.py:12-105, delta_xywh_bbox_coder.py:264-361, mmcv batched_nms).    */
 /* Deterministic: ties are (score desc, position asc).                         */
 /* ------------------------------------------------------------------------ */
+/* DeltaXYWHBBoxCoder.decode (delta_xywh_bbox_coder.py:71-131 -> delta2bbox,  */
+/* :264-361): denormalise with stds / means, clamp, optionally clip to the    */
+/* image.  Every step rounds as the reference's eager fp32 expression does.   */
+typedef struct RspBoxCoder {
+  float means[4], stds[4];   /* target_means / target_stds                     */
+  float max_ratio;           /* |log(wh_ratio_clip)|                           */
+  float ctr_clamp;           /* pixels; read when add_ctr_clamp != 0           */
+  int32_t clip_border;       /* clamp to [0, w] x [0, h] of img_hw             */
+  int32_t add_ctr_clamp;     /* :340-342 (YOLOF form): clamp the centre shift, */
+                             /* sizes bounded from above only                  */
+} RspBoxCoder;
 typedef struct RspRpnDesc {
   const float* head[5];      /* per level [B*H*W, ld]: cols [0,A) objectness,  */
                              /* cols [A, 5A) deltas (anchor-major)             */
@@ -321,7 +332,7 @@ typedef struct RspRpnDesc {
   float stride[5];
   int32_t ld, A, nms_pre, num_levels;
   const float* base_anchors; /* device [L, A, 4] (anchor_generator.py:161-205) */
-  float max_ratio;           /* |log(wh_ratio_clip)|                           */
+  RspBoxCoder coder;         /* rpn_head.bbox_coder                            */
   float min_bbox_size;       /* <0 disables the w/h filter                     */
 } RspRpnDesc;
 /* sel_idx/sel_score [B, L, nms_pre], sel_cnt [B, L] */
@@ -335,7 +346,7 @@ int rsp_rpn_decode(const RspRpnDesc* d, int32_t B, const int32_t* sel_idx, const
 /* softmax + per-class decode + score threshold -> candidates ((roi, class) order) */
 int rsp_bbox_post(const float* head, int32_t ld, const float* rois, const int32_t* roi_start,
                   const float* img_hw, int32_t B, int32_t num_classes, float score_thr,
-                  const float* std4 /*host*/, float max_ratio, int32_t cap, float* cand_boxes,
+                  const RspBoxCoder* coder /*host*/, int32_t cap, float* cand_boxes,
                   float* cand_scores, int32_t* cand_ids, int32_t* cand_src, int32_t* cand_cnt,
                   rsp_stream_t stream);
 int64_t rsp_nms_workspace_bytes(int32_t B, int32_t cap);

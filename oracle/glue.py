@@ -42,8 +42,8 @@ def grid_priors(featmap_sizes, strides, scales, ratios):
 
 # --------------------------------------------------------------------------- box coder
 def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None,
-               wh_ratio_clip=16 / 1000):
-    """delta_xywh_bbox_coder.py:264-361 (clip_border=True, add_ctr_clamp=False)."""
+               wh_ratio_clip=16 / 1000, clip_border=True, add_ctr_clamp=False, ctr_clamp=32):
+    """delta_xywh_bbox_coder.py:264-361."""
     num_bboxes, num_classes = deltas.size(0), deltas.size(1) // 4
     if num_bboxes == 0:
         return deltas
@@ -57,13 +57,17 @@ def delta2bbox(rois, deltas, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_
     pwh = rois_[:, 2:] - rois_[:, :2]
     dxy_wh = pwh * dxy
     max_ratio = np.abs(np.log(wh_ratio_clip))
-    dwh = dwh.clamp(min=-max_ratio, max=max_ratio)
+    if add_ctr_clamp:                                   # :340-342
+        dxy_wh = torch.clamp(dxy_wh, max=ctr_clamp, min=-ctr_clamp)
+        dwh = torch.clamp(dwh, max=max_ratio)
+    else:
+        dwh = dwh.clamp(min=-max_ratio, max=max_ratio)
     gxy = pxy + dxy_wh
     gwh = pwh * dwh.exp()
     x1y1 = gxy - gwh * 0.5
     x2y2 = gxy + gwh * 0.5
     bboxes = torch.cat([x1y1, x2y2], dim=-1)
-    if max_shape is not None:
+    if clip_border and max_shape is not None:
         bboxes[..., 0::2].clamp_(min=0, max=max_shape[1])
         bboxes[..., 1::2].clamp_(min=0, max=max_shape[0])
     return bboxes.reshape(num_bboxes, -1)
@@ -116,14 +120,15 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, iou_threshold, max_num
 
 
 def bbox_head_predict_single(roi, cls_score, bbox_pred, img_shape, num_classes, score_thr, iou_threshold, max_per_img,
-                             stds=(0.1, 0.1, 0.2, 0.2), scale_factor=None):
+                             stds=(0.1, 0.1, 0.2, 0.2), scale_factor=None, coder=None):
     """BBoxHead._predict_by_feat_single (bbox_head.py:476-571), class-specific regression (scale_factor=None: rescale=False):
     softmax scores, per-class delta decode of the repeated RoIs, multiclass NMS.  roi [n,5], cls_score [n,nc+1],
     bbox_pred [n,nc*4] -> dets [k,5], labels [k], flat (roi, class) candidate index [k]."""
     n = roi.shape[0]
     scores = torch.softmax(cls_score, dim=-1)
-    bboxes = delta2bbox(roi[:, 1:].repeat_interleave(num_classes, dim=0), bbox_pred.view(-1, 4), stds=stds,
-                        max_shape=img_shape)
+    # `coder`: the remaining delta2bbox keywords of the head's DeltaXYWHBBoxCoder (means, clip_border, add_ctr_clamp, ...)
+    bboxes = delta2bbox(roi[:, 1:].repeat_interleave(num_classes, dim=0), bbox_pred.view(-1, 4),
+                        max_shape=img_shape, **dict(dict(stds=stds), **(coder or {})))
     if scale_factor is not None and bboxes.size(0) > 0:
         # rescale=True (bbox_head.py:549-552 + scale_boxes, structures/bbox/transforms.py:391-414): a python reciprocal,
         # then an fp32 product, before the NMS
@@ -135,7 +140,7 @@ def bbox_head_predict_single(roi, cls_score, bbox_pred, img_shape, num_classes, 
 
 # --------------------------------------------------------------------------- RPN
 def rpn_predict_single(cls_score_list, bbox_pred_list, mlvl_priors, img_shape, nms_pre=1000,
-                       max_per_img=1000, iou_thr=0.7, min_bbox_size=0):
+                       max_per_img=1000, iou_thr=0.7, min_bbox_size=0, coder=None):
     """rpn_head.py:134-304 for one image; cls/bbox lists are [A*1,H,W] / [A*4,H,W]."""
     mlvl_bbox, mlvl_prior, mlvl_score, level_ids, mlvl_src = [], [], [], [], []
     for lvl, (cls, reg, priors) in enumerate(zip(cls_score_list, bbox_pred_list, mlvl_priors)):
@@ -154,7 +159,7 @@ def rpn_predict_single(cls_score_list, bbox_pred_list, mlvl_priors, img_shape, n
         level_ids.append(scores.new_full((scores.size(0),), lvl, dtype=torch.long))
     reg = torch.cat(mlvl_bbox)
     priors = torch.cat(mlvl_prior)
-    bboxes = delta2bbox(priors, reg, max_shape=img_shape)
+    bboxes = delta2bbox(priors, reg, max_shape=img_shape, **(coder or {}))
     scores = torch.cat(mlvl_score)
     level_ids = torch.cat(level_ids)
     src = torch.cat(mlvl_src)

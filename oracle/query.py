@@ -103,9 +103,9 @@ class MHA(nn.Module):
 class EncLayer(nn.Module):
     """DeformableDetrTransformerEncoderLayer: detr_layers.py:213-238, deformable_detr_layers.py:237-249."""
 
-    def __init__(self, dim=128, ffn=512):
+    def __init__(self, dim=128, ffn=512, levels=3):
         super().__init__()
-        self.self_attn = MSDeformAttn(dim)
+        self.self_attn = MSDeformAttn(dim, levels=levels)
         self.ffn = FFN(dim, ffn)
         self.norms = nn.ModuleList([nn.LayerNorm(dim), nn.LayerNorm(dim)])
 
@@ -115,17 +115,19 @@ class EncLayer(nn.Module):
 
 
 class PixelDecoder(nn.Module):
-    """MSDeformAttnPixelDecoder: msdeformattn_pixel_decoder.py:21-246 (5 inputs, 3 encoder levels)."""
+    """MSDeformAttnPixelDecoder: msdeformattn_pixel_decoder.py:21-246 (5 inputs; `levels` = num_encoder_levels =
+    self_attn_cfg.num_levels, 3 in every shipped config; `num_outs` memories are handed to the transformer decoder)."""
 
-    def __init__(self, feat=128, out=256, strides=(4, 8, 16, 32, 64), ffn=512, enc_layers=3):
+    def __init__(self, feat=128, out=256, strides=(4, 8, 16, 32, 64), ffn=512, enc_layers=3, levels=3, num_outs=3):
         super().__init__()
-        self.strides, self.n_in, self.n_enc, self.pe_feats = list(strides), 5, 3, feat // 2
-        self.input_convs = nn.ModuleList([ConvGN(256, feat, 1, True, False) for _ in range(3)])
+        self.strides, self.n_in, self.n_enc, self.pe_feats = list(strides), 5, levels, feat // 2
+        self.num_outs = num_outs
+        self.input_convs = nn.ModuleList([ConvGN(256, feat, 1, True, False) for _ in range(levels)])
         self.encoder = nn.Module()
-        self.encoder.layers = nn.ModuleList([EncLayer(feat, ffn) for _ in range(enc_layers)])
-        self.level_encoding = nn.Embedding(3, feat)
-        self.lateral_convs = nn.ModuleList([ConvGN(256, feat, 1, False, False) for _ in range(2)])
-        self.output_convs = nn.ModuleList([ConvGN(feat, feat, 3, False, True) for _ in range(2)])
+        self.encoder.layers = nn.ModuleList([EncLayer(feat, ffn, levels) for _ in range(enc_layers)])
+        self.level_encoding = nn.Embedding(levels, feat)
+        self.lateral_convs = nn.ModuleList([ConvGN(256, feat, 1, False, False) for _ in range(5 - levels)])
+        self.output_convs = nn.ModuleList([ConvGN(feat, feat, 3, False, True) for _ in range(5 - levels)])
         self.mask_feature = nn.Conv2d(feat, out, 1)
 
     def forward(self, feats):
@@ -162,7 +164,7 @@ class PixelDecoder(nn.Module):
             cur = self.lateral_convs[i](feats[i])
             y = cur + F.interpolate(outs[-1], size=cur.shape[-2:], mode='bilinear', align_corners=False)
             outs.append(self.output_convs[i](y))
-        return self.mask_feature(outs[-1]), outs[:3]
+        return self.mask_feature(outs[-1]), outs[:self.num_outs]
 
 
 class DecLayer(nn.Module):
@@ -184,21 +186,23 @@ class QueryHead(nn.Module):
     """RSMask2FormerHead (decoder_plus=True): models.py:274-463."""
 
     def __init__(self, num_classes, num_queries, per_pointset_point=5, feat=128, out=256, decoder_plus=True,
-                 with_sincos=True, input_proj=False):
+                 with_sincos=True, input_proj=False, levels=3):
         """decoder_plus=False (models.py:303-307, 361-385): no mask-embedding MLP, `no_mask_embed` as the dense prompt, the
         SAM decoder runs in every stage and its masks drive the attention masks; with_sincos=False (models.py:315-318,
         346-347): the point MLP emits the prompts directly; input_proj: `enforce_decoder_input_project=True`
-        (mask2former_head.py:93-100: Conv2d 1x1 per level)."""
+        (mask2former_head.py:93-100: Conv2d 1x1 per level); levels: `num_transformer_feat_level` ==
+        the pixel decoder's `num_levels` (mask2former_head.py:106-107), with `num_outs` = levels memories."""
         super().__init__()
         self.num_classes, self.num_queries, self.npts, self.num_heads = num_classes, num_queries, per_pointset_point, 8
         self.decoder_plus, self.with_sincos = decoder_plus, with_sincos
-        self.pixel_decoder = PixelDecoder(feat, out)
+        self.levels = levels
+        self.pixel_decoder = PixelDecoder(feat, out, levels=levels, num_outs=max(levels, 3))
         self.transformer_decoder = nn.Module()
         self.transformer_decoder.layers = nn.ModuleList([DecLayer() for _ in range(6)])
         self.transformer_decoder.post_norm = nn.LayerNorm(feat)
         self.query_embed = nn.Embedding(num_queries, feat)
         self.query_feat = nn.Embedding(num_queries, feat)
-        self.level_embed = nn.Embedding(3, feat)
+        self.level_embed = nn.Embedding(levels, feat)
         self.cls_embed = nn.Sequential(nn.Linear(feat, feat), nn.ReLU(inplace=True), nn.Linear(feat, num_classes + 1))
         if decoder_plus:
             self.mask_embed = nn.Sequential(nn.Linear(feat, feat), nn.ReLU(inplace=True), nn.Linear(feat, feat),
@@ -212,7 +216,7 @@ class QueryHead(nn.Module):
         else:
             self.no_mask_embed = nn.Embedding(1, out)
         if input_proj:
-            self.decoder_input_projs = nn.ModuleList([nn.Conv2d(feat, feat, 1) for _ in range(3)])
+            self.decoder_input_projs = nn.ModuleList([nn.Conv2d(feat, feat, 1) for _ in range(levels)])
         self.input_proj = input_proj
 
     def _forward_head(self, decoder_out, mask_feature, attn_size, emb, ipe, run_sam):
@@ -250,7 +254,7 @@ class QueryHead(nn.Module):
         bs = x[0].shape[0]
         mask_features, mem = self.pixel_decoder(x)
         dec_in, dec_pos = [], []
-        for i in range(3):
+        for i in range(self.levels):
             mi = self.decoder_input_projs[i](mem[i]) if self.input_proj else mem[i]
             d = mi.flatten(2).permute(0, 2, 1) + self.level_embed.weight[i].view(1, 1, -1)
             pe = glue.sine_positional_encoding(bs, mem[i].shape[-2], mem[i].shape[-1], num_feats=64)
@@ -258,18 +262,18 @@ class QueryHead(nn.Module):
             dec_pos.append(pe.flatten(2).permute(0, 2, 1))
         qf = self.query_feat.weight.unsqueeze(0).repeat((bs, 1, 1))
         qe = self.query_embed.weight.unsqueeze(0).repeat((bs, 1, 1))
-        trace = dict(mask_features=mask_features, memory=mem, attn_masks=[], query_feats=[qf])
+        trace = dict(mask_features=mask_features, memory=mem, attn_masks=[], query_feats=[qf], levels=self.levels)
         src_of = lambda mpp_, mask_: mpp_ if self.decoder_plus else mask_           # what the attention masks are cut from
         cls, mask0, attn_mask, mpp, _ = self._forward_head(qf, mask_features, mem[0].shape[-2:], emb, ipe, False)
         trace.update(cls_pred_all=[cls], mask_pred_plus_all=[src_of(mpp, mask0)])
         for i in range(6):
-            lvl = i % 3
+            lvl = i % self.levels
             attn_mask = attn_mask & (attn_mask.sum(-1) != attn_mask.shape[-1]).unsqueeze(-1)   # models.py:439-442
             trace['attn_masks'].append(attn_mask)
             qf = self.transformer_decoder.layers[i](qf, dec_in[lvl], dec_in[lvl], qe, dec_pos[lvl], attn_mask)
             trace['query_feats'].append(qf)
             cls, mask, attn_mask, mpp, sparse = self._forward_head(
-                qf, mask_features, mem[(i + 1) % 3].shape[-2:], emb, ipe, run_sam=(i == 5))
+                qf, mask_features, mem[(i + 1) % self.levels].shape[-2:], emb, ipe, run_sam=(i == 5))
             trace['cls_pred_all'].append(cls)
             trace['mask_pred_plus_all'].append(src_of(mpp, mask))
         trace.update(cls_pred=cls, mask_pred=mask, mask_pred_plus=mpp, sparse_embeddings=sparse)

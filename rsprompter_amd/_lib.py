@@ -76,11 +76,16 @@ class RspRoiAlignDesc(ctypes.Structure):
     ]
 
 
+class RspBoxCoder(ctypes.Structure):
+    _fields_ = [("means", c_float * 4), ("stds", c_float * 4), ("max_ratio", c_float), ("ctr_clamp", c_float),
+                ("clip_border", c_int), ("add_ctr_clamp", c_int)]
+
+
 class RspRpnDesc(ctypes.Structure):
     _fields_ = [
         ("head", c_void_p * 5), ("H", c_int * 5), ("W", c_int * 5), ("stride", c_float * 5),
         ("ld", c_int), ("A", c_int), ("nms_pre", c_int), ("num_levels", c_int),
-        ("base_anchors", c_void_p), ("max_ratio", c_float), ("min_bbox_size", c_float),
+        ("base_anchors", c_void_p), ("coder", RspBoxCoder), ("min_bbox_size", c_float),
     ]
 
 
@@ -134,7 +139,7 @@ PROTOTYPES = {
     "rsp_rpn_decode": (c_int, [ctypes.POINTER(RspRpnDesc), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "rsp_bbox_post": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float,
-                              ctypes.POINTER(c_float), c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                              ctypes.POINTER(RspBoxCoder), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "rsp_nms_workspace_bytes": (c_int64, [c_int, c_int]),
     "rsp_batched_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int,

@@ -102,11 +102,9 @@ class DeltaXYWHBBoxCoder:
                  add_ctr_clamp=False, ctr_clamp=32, use_box_type=False):
         self.means, self.stds = tuple(target_means), tuple(target_stds)
         self.clip_border, self.add_ctr_clamp, self.ctr_clamp = clip_border, add_ctr_clamp, ctr_clamp
-        # what the decode kernels implement (delta_xywh_bbox_coder.py:264-361 as every RSPrompter config uses it):
-        # zero means, clip to the image, no centre clamp.  Anything else would decode different boxes silently.
-        if any(float(m) != 0.0 for m in self.means) or not clip_border or add_ctr_clamp:
-            raise NotImplementedError('DeltaXYWHBBoxCoder: only target_means = 0, clip_border=True, add_ctr_clamp=False '
-                                      '(the RSPrompter configurations) are implemented by the HIP decode kernels')
+        assert len(self.means) == 4 and len(self.stds) == 4
+        if use_box_type:
+            raise NotImplementedError('DeltaXYWHBBoxCoder(use_box_type=True): the heads hand tensors to the decode kernels')
         self.max_ratio = float(np.float32(np.abs(np.log(16 / 1000))))
 
 
@@ -130,9 +128,6 @@ class RPNHead(HIPModule):
         self.in_channels, self.feat_channels = in_channels, feat_channels
         self.prior_generator = TASK_UTILS.build(anchor_generator)
         self.bbox_coder = TASK_UTILS.build(bbox_coder or dict(type='DeltaXYWHBBoxCoder'))
-        if any(float(sd) != 1.0 for sd in self.bbox_coder.stds):
-            raise NotImplementedError('RPNHead: rsp_rpn_decode implements target_stds = 1 (rpn_head bbox_coder of every '
-                                      'RSPrompter config, _base_/rsprompter_anchor.py:99-102)')
         self.num_base_priors = self.prior_generator.num_base_priors[0]
         self.use_sigmoid_cls = (loss_cls or {}).get('use_sigmoid', True)
         if not self.use_sigmoid_cls:
@@ -199,7 +194,7 @@ class RPNHead(HIPModule):
         if P['selector'] is None or P['selector'][0] != key:
             base = torch.stack(self.prior_generator.base_anchors, 0)
             strides = [s[0] for s in self.prior_generator.strides]
-            sel = ops.RpnSelector(base, strides, key[0], key[1], key[2], key[3], self.bbox_coder.max_ratio, dev)
+            sel = ops.RpnSelector(base, strides, key[0], key[1], key[2], key[3], self.bbox_coder, dev)
             P['selector'] = (key, sel)
         return P['selector'][1](heads, sizes, self.LD, _img_hw(metas, dev))
 
@@ -257,10 +252,6 @@ class Shared2FCBBoxHead(HIPModule):
             raise NotImplementedError
         self.in_channels, self.fc_out, self.roi_feat_size = in_channels, fc_out_channels, roi_feat_size
         self.num_classes = num_classes
-        # rsp_bbox_post runs multiclass_nms over (RoIs x classes) candidates in one LDS-resident sort of at most 16384
-        # keys (det.hip NMS_MAXW): with the config's 1000 proposals per image that is 16 classes (the RSPrompter
-        # datasets have 1 or 10).  Fail HERE with the reason rather than at the first predict with a bare status code.
-        self.max_candidates = 16384
         self.bbox_coder = TASK_UTILS.build(bbox_coder or dict(type='DeltaXYWHBBoxCoder',
                                                              target_stds=(0.1, 0.1, 0.2, 0.2)))
         k0 = in_channels * roi_feat_size * roi_feat_size
@@ -498,8 +489,7 @@ class RSPrompterAnchorRoIPromptHead(HIPModule):
         roi_start = torch.tensor([0] + list(np.cumsum(counts)), dtype=torch.int64)
         nms = rcnn_test_cfg['nms']
         out = ops.bbox_post(head, self.bbox_head.LD, rois, roi_start, _img_hw(batch_img_metas, dev), nc,
-                            float(rcnn_test_cfg['score_thr']), self.bbox_head.bbox_coder.stds,
-                            self.bbox_head.bbox_coder.max_ratio, float(nms['iou_threshold']),
+                            float(rcnn_test_cfg['score_thr']), self.bbox_head.bbox_coder, float(nms['iou_threshold']),
                             int(rcnn_test_cfg['max_per_img']),
                             scale_factors=[m['scale_factor'] for m in batch_img_metas] if rescale else None)
         kept = out['count'].tolist()            # host sync of the R-CNN stage

@@ -173,25 +173,51 @@ __global__ __launch_bounds__(TK_THREADS) void rpn_topk_kernel(const TopkP p) {
 }
 
 // ---------------------------------------------------------------------------------------
-// delta2bbox (clip_border=True, add_ctr_clamp=False)
+// delta2bbox (delta_xywh_bbox_coder.py:264-361): every operation is its own fp32 rounding step
+// as in the reference's eager tensor expression (the build has -ffp-contract=off), so that the
+// decoded boxes -- and with them the NMS decisions -- are bit-identical.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void decode_box(const float a[4], const float d[4], float sx, float sy,
-                                           float sw, float sh, float max_ratio, float img_h,
-                                           float img_w, float out[4]) {
-  const float dx = d[0] * sx, dy = d[1] * sy;
-  float dw = d[2] * sw, dh = d[3] * sh;
+struct BoxCoder {
+  float mean[4], std[4];
+  float max_ratio, ctr_clamp;
+  int clip_border, add_ctr_clamp;
+};
+
+__device__ __forceinline__ void decode_box(const float a[4], const float d[4], const BoxCoder& c,
+                                           float img_h, float img_w, float out[4]) {
+  const float dx = d[0] * c.std[0] + c.mean[0], dy = d[1] * c.std[1] + c.mean[1];
+  float dw = d[2] * c.std[2] + c.mean[2], dh = d[3] * c.std[3] + c.mean[3];
   const float px = (a[0] + a[2]) * 0.5f, py = (a[1] + a[3]) * 0.5f;
   const float pw = a[2] - a[0], ph = a[3] - a[1];
-  const float dxw = pw * dx, dyh = ph * dy;
-  dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
-  dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
+  float dxw = pw * dx, dyh = ph * dy;
+  if (c.add_ctr_clamp) {  // :340-342: centre shift clamped to +-ctr_clamp pixels, sizes only from above
+    dxw = fminf(fmaxf(dxw, -c.ctr_clamp), c.ctr_clamp);
+    dyh = fminf(fmaxf(dyh, -c.ctr_clamp), c.ctr_clamp);
+    dw = fminf(dw, c.max_ratio);
+    dh = fminf(dh, c.max_ratio);
+  } else {
+    dw = fminf(fmaxf(dw, -c.max_ratio), c.max_ratio);
+    dh = fminf(fmaxf(dh, -c.max_ratio), c.max_ratio);
+  }
   const float gx = px + dxw, gy = py + dyh;
   const float gw = pw * expf(dw), gh = ph * expf(dh);
-  float x1 = gx - gw * 0.5f, y1 = gy - gh * 0.5f, x2 = gx + gw * 0.5f, y2 = gy + gh * 0.5f;
-  out[0] = fminf(fmaxf(x1, 0.f), img_w);
-  out[1] = fminf(fmaxf(y1, 0.f), img_h);
-  out[2] = fminf(fmaxf(x2, 0.f), img_w);
-  out[3] = fminf(fmaxf(y2, 0.f), img_h);
+  const float x1 = gx - gw * 0.5f, y1 = gy - gh * 0.5f, x2 = gx + gw * 0.5f, y2 = gy + gh * 0.5f;
+  if (c.clip_border) {
+    out[0] = fminf(fmaxf(x1, 0.f), img_w);
+    out[1] = fminf(fmaxf(y1, 0.f), img_h);
+    out[2] = fminf(fmaxf(x2, 0.f), img_w);
+    out[3] = fminf(fmaxf(y2, 0.f), img_h);
+  } else {
+    out[0] = x1; out[1] = y1; out[2] = x2; out[3] = y2;
+  }
+}
+
+__host__ bool coder_from_abi(const RspBoxCoder* in, BoxCoder* c) {
+  if (!in || !(in->max_ratio > 0.f) || (in->add_ctr_clamp && !(in->ctr_clamp >= 0.f))) return false;
+  for (int i = 0; i < 4; ++i) { c->mean[i] = in->means[i]; c->std[i] = in->stds[i]; }
+  c->max_ratio = in->max_ratio; c->ctr_clamp = in->ctr_clamp;
+  c->clip_border = in->clip_border != 0; c->add_ctr_clamp = in->add_ctr_clamp != 0;
+  return true;
 }
 
 // block-wide exclusive scan of one int per thread (blockDim.x <= 1024); returns the exclusive
@@ -227,7 +253,7 @@ struct RpnDecodeP {
   const int32_t* sel_idx; const float* sel_score; const int32_t* sel_cnt;  // from rpn_topk
   const float* img_hw;        // [B, 2] (h, w) of img_shape
   int ld, A, k, num_levels, cap;  // cap = candidate capacity per image (>= L*k)
-  float max_ratio, min_size;
+  BoxCoder coder; float min_size;
   float* cand_boxes;   // [B, cap, 4]
   float* cand_scores;  // [B, cap]
   int32_t* cand_ids;   // [B, cap]  level id
@@ -258,7 +284,7 @@ __global__ __launch_bounds__(1024) void rpn_decode_kernel(const RpnDecodeP p) {
         const float an[4] = {ba[0] + shx, ba[1] + shy, ba[2] + shx, ba[3] + shy};
         const float* dp = p.head[lvl] + ((int64_t)b * p.HW[lvl] + pos) * p.ld + p.A + a * 4;
         const float d[4] = {dp[0], dp[1], dp[2], dp[3]};
-        decode_box(an, d, 1.f, 1.f, 1.f, 1.f, p.max_ratio, img_h, img_w, box);
+        decode_box(an, d, p.coder, img_h, img_w, box);
         valid = p.min_size < 0.f || ((box[2] - box[0]) > p.min_size && (box[3] - box[1]) > p.min_size);
       }
       int total;
@@ -288,8 +314,8 @@ struct BboxPostP {
   const int32_t* roi_start;    // [B+1] prefix of rois per image
   const float* img_hw;         // [B, 2]
   int nc, cap;
-  float score_thr, max_ratio;
-  float std[4];
+  float score_thr;
+  BoxCoder coder;
   float* cand_boxes; float* cand_scores; int32_t* cand_ids; int32_t* cand_src; int32_t* cand_cnt;
 };
 
@@ -321,7 +347,7 @@ __global__ __launch_bounds__(1024) void bbox_post_kernel(const BboxPostP p) {
         const float an[4] = {roi[0], roi[1], roi[2], roi[3]};
         const float* dp = row + p.nc + 1 + cls * 4;
         const float d[4] = {dp[0], dp[1], dp[2], dp[3]};
-        decode_box(an, d, p.std[0], p.std[1], p.std[2], p.std[3], p.max_ratio, img_h, img_w, box);
+        decode_box(an, d, p.coder, img_h, img_w, box);
       }
     }
     int total;
@@ -350,14 +376,17 @@ struct NmsP {
   float iou_thr; int max_out;
   float* sboxes;      // [B, cap, 4] offset boxes in sorted order
   int32_t* sorder;    // [B, cap]    original position of sorted element
+  unsigned long long* gkeys;  // [B, nsort] sort keys in memory when nsort > NMS_LDS_KEYS, else null
   unsigned long long* mask;  // [B, cap, words]
   int words;
   int32_t* keep;      // [B, max_out] original positions, score order
   int32_t* keep_cnt;  // [B]
 };
 
+constexpr int NMS_LDS_KEYS = 16384;  // 128 KB of LDS; larger candidate sets sort in memory (same block, same network)
 __global__ __launch_bounds__(1024) void nms_prepare_kernel(const NmsP p) {
-  extern __shared__ unsigned long long skeys_dyn[];
+  extern __shared__ unsigned long long skeys_lds[];
+  unsigned long long* skeys_dyn = p.gkeys ? p.gkeys + (int64_t)blockIdx.x * p.nsort : skeys_lds;
   __shared__ float red[16];
   __shared__ float s_max;
   const int b = blockIdx.x, tid = threadIdx.x;
@@ -394,35 +423,44 @@ __global__ __launch_bounds__(1024) void nms_prepare_kernel(const NmsP p) {
 }
 
 __global__ __launch_bounds__(64) void nms_mask_kernel(const NmsP p) {
-  const int b = blockIdx.z, rb = blockIdx.y, cb = blockIdx.x;
+  const int b = blockIdx.z;
   const int n = p.cnt[b];
-  if (cb < rb || rb * 64 >= n || cb * 64 >= n) return;
+  const int nblk = (n + 63) / 64;
   __shared__ float cbx[64][4];
   const int t = threadIdx.x;
   const float* sb = p.sboxes + (int64_t)b * p.cap * 4;
-  const int cj = cb * 64 + t;
-  if (cj < n) { cbx[t][0] = sb[cj * 4]; cbx[t][1] = sb[cj * 4 + 1]; cbx[t][2] = sb[cj * 4 + 2]; cbx[t][3] = sb[cj * 4 + 3]; }
-  __syncthreads();
-  const int ri = rb * 64 + t;
-  if (ri >= n) return;
-  const float x1 = sb[ri * 4], y1 = sb[ri * 4 + 1], x2 = sb[ri * 4 + 2], y2 = sb[ri * 4 + 3];
-  const float ia = (x2 - x1) * (y2 - y1);
-  unsigned long long bits = 0ull;
-  const int ncol = min(64, n - cb * 64);
-  const int start = (rb == cb) ? t + 1 : 0;
-  for (int j = start; j < ncol; ++j) {
-    const float xx1 = fmaxf(x1, cbx[j][0]), yy1 = fmaxf(y1, cbx[j][1]);
-    const float xx2 = fminf(x2, cbx[j][2]), yy2 = fminf(y2, cbx[j][3]);
-    const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
-    const float inter = w * h;
-    const float ja = (cbx[j][2] - cbx[j][0]) * (cbx[j][3] - cbx[j][1]);
-    const float ovr = inter / (ia + ja - inter);
-    if (ovr > p.iou_thr) bits |= (1ull << j);
+  // the grid covers min(words, 256)^2 tile positions; larger candidate sets stride over the rest (uniform loops)
+  for (int rb = blockIdx.y; rb < nblk; rb += gridDim.y) {
+    for (int cb = blockIdx.x; cb < nblk; cb += gridDim.x) {
+      if (cb < rb) continue;
+      __syncthreads();
+      const int cj = cb * 64 + t;
+      if (cj < n) { cbx[t][0] = sb[cj * 4]; cbx[t][1] = sb[cj * 4 + 1]; cbx[t][2] = sb[cj * 4 + 2]; cbx[t][3] = sb[cj * 4 + 3]; }
+      __syncthreads();
+      const int ri = rb * 64 + t;
+      if (ri >= n) continue;
+      const float x1 = sb[ri * 4], y1 = sb[ri * 4 + 1], x2 = sb[ri * 4 + 2], y2 = sb[ri * 4 + 3];
+      const float ia = (x2 - x1) * (y2 - y1);
+      unsigned long long bits = 0ull;
+      const int ncol = min(64, n - cb * 64);
+      const int start = (rb == cb) ? t + 1 : 0;
+      for (int j = start; j < ncol; ++j) {
+        const float xx1 = fmaxf(x1, cbx[j][0]), yy1 = fmaxf(y1, cbx[j][1]);
+        const float xx2 = fminf(x2, cbx[j][2]), yy2 = fminf(y2, cbx[j][3]);
+        const float w = fmaxf(0.f, xx2 - xx1), h = fmaxf(0.f, yy2 - yy1);
+        const float inter = w * h;
+        const float ja = (cbx[j][2] - cbx[j][0]) * (cbx[j][3] - cbx[j][1]);
+        const float ovr = inter / (ia + ja - inter);
+        if (ovr > p.iou_thr) bits |= (1ull << j);
+      }
+      p.mask[((int64_t)b * p.cap + ri) * p.words + cb] = bits;
+    }
   }
-  p.mask[((int64_t)b * p.cap + ri) * p.words + cb] = bits;
 }
 
-constexpr int NMS_MAXW = 4;  // words per lane: supports up to 64*4*64 = 16384 candidates
+// NMS_MAXW removal words per lane: 64 lanes * NMS_MAXW words * 64 bits candidates (4: 16384, the RSPrompter sizes; 32: 131072)
+constexpr int NMS_MAXW_LARGE = 32;
+template <int NMS_MAXW>
 __global__ __launch_bounds__(64) void nms_reduce_kernel(const NmsP p) {
   const int b = blockIdx.x, lane = threadIdx.x;
   const int n = p.cnt[b];
@@ -533,7 +571,8 @@ extern "C" int rsp_rpn_decode(const RspRpnDesc* d, int32_t B, const int32_t* sel
   p.base_anchors = d->base_anchors;
   p.sel_idx = sel_idx; p.sel_score = sel_score; p.sel_cnt = sel_cnt; p.img_hw = img_hw;
   p.ld = d->ld; p.A = d->A; p.k = d->nms_pre; p.num_levels = d->num_levels; p.cap = cap;
-  p.max_ratio = d->max_ratio; p.min_size = d->min_bbox_size;
+  if (!coder_from_abi(&d->coder, &p.coder)) return RSP_EINVAL;
+  p.min_size = d->min_bbox_size;
   p.cand_boxes = cand_boxes; p.cand_scores = cand_scores; p.cand_ids = cand_ids; p.cand_src = cand_src;
   p.cand_cnt = cand_cnt;
   hipLaunchKernelGGL(rpn_decode_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, p);
@@ -543,16 +582,16 @@ extern "C" int rsp_rpn_decode(const RspRpnDesc* d, int32_t B, const int32_t* sel
 
 extern "C" int rsp_bbox_post(const float* head, int32_t ld, const float* rois, const int32_t* roi_start,
                              const float* img_hw, int32_t B, int32_t num_classes, float score_thr,
-                             const float* std4, float max_ratio, int32_t cap, float* cand_boxes,
+                             const RspBoxCoder* coder, int32_t cap, float* cand_boxes,
                              float* cand_scores, int32_t* cand_ids, int32_t* cand_src, int32_t* cand_cnt,
                              rsp_stream_t stream) {
-  if (!head || !rois || !roi_start || !img_hw || !std4 || !cand_boxes || !cand_scores || !cand_ids ||
+  if (!head || !rois || !roi_start || !img_hw || !coder || !cand_boxes || !cand_scores || !cand_ids ||
       !cand_src || !cand_cnt || B <= 0 || num_classes <= 0 || cap <= 0)
     return RSP_EINVAL;
   BboxPostP p;
   p.head = head; p.ld = ld; p.rois = rois; p.roi_start = roi_start; p.img_hw = img_hw;
-  p.nc = num_classes; p.cap = cap; p.score_thr = score_thr; p.max_ratio = max_ratio;
-  for (int i = 0; i < 4; ++i) p.std[i] = std4[i];
+  p.nc = num_classes; p.cap = cap; p.score_thr = score_thr;
+  if (!coder_from_abi(coder, &p.coder)) return RSP_EINVAL;
   p.cand_boxes = cand_boxes; p.cand_scores = cand_scores; p.cand_ids = cand_ids; p.cand_src = cand_src;
   p.cand_cnt = cand_cnt;
   hipLaunchKernelGGL(bbox_post_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, p);
@@ -562,7 +601,10 @@ extern "C" int rsp_bbox_post(const float* head, int32_t ld, const float* rois, c
 
 extern "C" int64_t rsp_nms_workspace_bytes(int32_t B, int32_t cap) {
   const int64_t words = (cap + 63) / 64;
-  return (int64_t)B * cap * (4 * sizeof(float) + sizeof(int32_t) + words * sizeof(unsigned long long)) + 256;
+  int64_t nsort = 1;
+  while (nsort < cap) nsort <<= 1;
+  const int64_t keys = nsort > 16384 ? (int64_t)B * nsort * sizeof(unsigned long long) : 0;  // NMS_LDS_KEYS
+  return (int64_t)B * cap * (4 * sizeof(float) + sizeof(int32_t) + words * sizeof(unsigned long long)) + keys + 256;
 }
 
 extern "C" int rsp_batched_nms(const float* boxes, const float* scores, const int32_t* ids,
@@ -571,7 +613,7 @@ extern "C" int rsp_batched_nms(const float* boxes, const float* scores, const in
                                int32_t* keep_cnt, float* out_boxes, float* out_scores, int32_t* out_ids,
                                int32_t* out_src, rsp_stream_t stream) {
   if (!boxes || !scores || !ids || !cnt || !workspace || !keep || !keep_cnt || !out_boxes || !out_scores ||
-      !out_ids || B <= 0 || cap <= 0 || cap > 64 * 64 * NMS_MAXW || max_out <= 0)
+      !out_ids || B <= 0 || cap <= 0 || cap > 64 * 64 * NMS_MAXW_LARGE || max_out <= 0)
     return RSP_EINVAL;
   int nsort = 1;
   while (nsort < cap) nsort <<= 1;
@@ -582,16 +624,19 @@ extern "C" int rsp_batched_nms(const float* boxes, const float* scores, const in
   char* ws = (char*)workspace;
   p.sboxes = (float*)ws; ws += (int64_t)B * cap * 4 * sizeof(float);
   p.mask = (unsigned long long*)ws; ws += (int64_t)B * cap * p.words * sizeof(unsigned long long);
-  p.sorder = (int32_t*)ws;
+  p.sorder = (int32_t*)ws; ws += (((int64_t)B * cap * sizeof(int32_t)) + 7) / 8 * 8;
+  p.gkeys = nsort > NMS_LDS_KEYS ? (unsigned long long*)ws : nullptr;
   p.keep = keep; p.keep_cnt = keep_cnt;
   hipStream_t s = (hipStream_t)stream;
-  const size_t smem = (size_t)nsort * sizeof(unsigned long long);
+  const size_t smem = p.gkeys ? 0 : (size_t)nsort * sizeof(unsigned long long);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_prepare_kernel),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (e != hipSuccess) return RSP_ELAUNCH;
   hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(1024), smem, s, p);
-  hipLaunchKernelGGL(nms_mask_kernel, dim3(p.words, p.words, B), dim3(64), 0, s, p);
-  hipLaunchKernelGGL(nms_reduce_kernel, dim3(B), dim3(64), 0, s, p);
+  const int gw = p.words < 256 ? p.words : 256;
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(gw, gw, B), dim3(64), 0, s, p);
+  if (p.words <= 64 * 4) hipLaunchKernelGGL(nms_reduce_kernel<4>, dim3(B), dim3(64), 0, s, p);
+  else hipLaunchKernelGGL(nms_reduce_kernel<NMS_MAXW_LARGE>, dim3(B), dim3(64), 0, s, p);
   hipLaunchKernelGGL(nms_gather_kernel, dim3(B), dim3(256), 0, s, boxes, scores, ids, src, cap, keep, keep_cnt,
                      max_out, out_boxes, out_scores, out_ids, out_src);
   RSP_CHECK_LAUNCH();

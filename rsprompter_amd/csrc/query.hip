@@ -120,13 +120,14 @@ struct MsdaP {
   const float* ref;     // [Ntok, 2] (x, y) normalised reference point (same for every level: valid_ratios == 1)
   float* out;           // [B, Ntok, H*D]
   int B, Ntok, ldow;
-  int lvl_h[4], lvl_w[4], lvl_start[4];
+  int lvl_h[5], lvl_w[5], lvl_start[5];
 };
-constexpr int MS_H = 8, MS_L = 3, MS_P = 4;
+constexpr int MS_H = 8, MS_P = 4, MS_LMAX = 5;
 
 // one wave per (b, token): lane = head * 8 + slot, every lane owns MS_D / 8 consecutive channels of its head
 // (MS_D = 16: embed 128, the RSPrompter query prompter; MS_D = 32: embed 256, the standard Mask2Former pixel decoder)
-template <int MS_D>
+// MS_L = self_attn_cfg.num_levels = num_transformer_feat_level (mask2former_head.py:106-107): 3 in every shipped config
+template <int MS_D, int MS_L>
 __global__ __launch_bounds__(256) void msda_kernel(const MsdaP p) {
   constexpr int DPL = MS_D / 8;
   const int lane = threadIdx.x & 63;
@@ -523,13 +524,13 @@ extern "C" int rsp_resize_bilinear_nhwc(const float* x, float* y, int32_t B, int
 extern "C" int rsp_msdeform_attn_ex(const float* value, const float* offs_weights, int32_t ld_ow, const float* ref_points,
                                     float* out, int32_t B, int32_t Ntok, int32_t num_levels, const int32_t* level_hw /*host [L,2]*/,
                                     int32_t head_dim, rsp_stream_t stream) {
-  if (!value || !offs_weights || !ref_points || !out || !level_hw || B <= 0 || Ntok <= 0 || num_levels != MS_L ||
-      ld_ow < MS_H * MS_L * MS_P * 3 || !(head_dim == 16 || head_dim == 32))
+  if (!value || !offs_weights || !ref_points || !out || !level_hw || B <= 0 || Ntok <= 0 || num_levels < 1 ||
+      num_levels > MS_LMAX || ld_ow < MS_H * num_levels * MS_P * 3 || !(head_dim == 16 || head_dim == 32))
     return RSP_EINVAL;
   MsdaP p;
   p.value = value; p.ow = offs_weights; p.ref = ref_points; p.out = out; p.B = B; p.Ntok = Ntok; p.ldow = ld_ow;
   int start = 0;
-  for (int l = 0; l < 4; ++l) {
+  for (int l = 0; l < MS_LMAX; ++l) {
     if (l < num_levels) {
       p.lvl_h[l] = level_hw[2 * l]; p.lvl_w[l] = level_hw[2 * l + 1]; p.lvl_start[l] = start;
       start += p.lvl_h[l] * p.lvl_w[l];
@@ -537,8 +538,16 @@ extern "C" int rsp_msdeform_attn_ex(const float* value, const float* offs_weight
   }
   if (start != Ntok) return RSP_EINVAL;
   const int64_t waves = (int64_t)B * Ntok;
-  if (head_dim == 16) hipLaunchKernelGGL(msda_kernel<16>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(msda_kernel<32>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p);
+  const dim3 grid((unsigned)((waves + 3) / 4));
+#define MSDA_CASE(L)                                                                                                   \
+  case L:                                                                                                              \
+    if (head_dim == 16) hipLaunchKernelGGL((msda_kernel<16, L>), grid, dim3(256), 0, (hipStream_t)stream, p);          \
+    else hipLaunchKernelGGL((msda_kernel<32, L>), grid, dim3(256), 0, (hipStream_t)stream, p);                         \
+    break;
+  switch (num_levels) {
+    MSDA_CASE(1) MSDA_CASE(2) MSDA_CASE(3) MSDA_CASE(4) MSDA_CASE(5)
+  }
+#undef MSDA_CASE
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }

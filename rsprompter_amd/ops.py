@@ -939,15 +939,26 @@ def sam_embed_boxes(boxes, gauss, pe_top_left, pe_bottom_right, input_size):
     return out
 
 
+def box_coder(coder):
+    """The RspBoxCoder of a DeltaXYWHBBoxCoder-like object (`means`, `stds`, `max_ratio`, `clip_border`, `add_ctr_clamp`,
+    `ctr_clamp`: delta_xywh_bbox_coder.py:71-131)."""
+    c = _lib.RspBoxCoder()
+    for i in range(4):
+        c.means[i], c.stds[i] = float(coder.means[i]), float(coder.stds[i])
+    c.max_ratio, c.ctr_clamp = float(coder.max_ratio), float(coder.ctr_clamp)
+    c.clip_border, c.add_ctr_clamp = int(bool(coder.clip_border)), int(bool(coder.add_ctr_clamp))
+    return c
+
+
 class RpnSelector:
     """rpn_topk -> rpn_decode -> batched_nms on the device (rpn_head.py:134-304)."""
 
-    def __init__(self, base_anchors, strides, nms_pre, max_per_img, iou_thr, min_bbox_size, max_ratio, device):
+    def __init__(self, base_anchors, strides, nms_pre, max_per_img, iou_thr, min_bbox_size, coder, device):
         self.base = base_anchors.to(torch.float32).contiguous().to(device)   # [L, A, 4]
         self.strides = list(strides)
         self.L, self.A = self.base.shape[0], self.base.shape[1]
         self.nms_pre, self.max_per_img, self.iou_thr = nms_pre, max_per_img, iou_thr
-        self.min_bbox_size, self.max_ratio = min_bbox_size, max_ratio
+        self.min_bbox_size, self.coder = min_bbox_size, box_coder(coder)
 
     def __call__(self, heads, sizes, ld, img_hw):
         """heads: per-level [B*H*W, ld] outputs; sizes: [(H, W)]; img_hw: device [B, 2] float."""
@@ -960,7 +971,7 @@ class RpnSelector:
             d.H[i], d.W[i], d.stride[i] = H, W, float(self.strides[i])
         d.ld, d.A, d.nms_pre, d.num_levels = ld, self.A, self.nms_pre, len(heads)
         d.base_anchors = self.base.data_ptr()
-        d.max_ratio, d.min_bbox_size = self.max_ratio, float(self.min_bbox_size)
+        d.coder, d.min_bbox_size = self.coder, float(self.min_bbox_size)
         L, k = len(heads), self.nms_pre
         sel_idx = torch.empty((B, L, k), dtype=torch.int32, device=dev)
         sel_score = torch.empty((B, L, k), dtype=torch.float32, device=dev)
@@ -973,6 +984,10 @@ class RpnSelector:
                                       img_hw.data_ptr(), cap, *[c.data_ptr() for c in cand], _stream()),
                    "rsp_rpn_decode")
         return batched_nms(cand, B, cap, self.iou_thr, self.max_per_img)
+
+
+NMS_LDS_CANDIDATES = 16384     # rsp_batched_nms sorts up to here in LDS (det.hip NMS_LDS_KEYS), in memory above
+NMS_MAX_CANDIDATES = 131072    # ... and holds this many candidates per image at most
 
 
 def _cand_buffers(B, cap, dev):
@@ -1002,7 +1017,7 @@ def batched_nms(cand, B, cap, iou_thr, max_out):
     return dict(boxes=ob, scores=os_, ids=oi, src=osrc, count=keep_cnt, keep=keep, cand_count=cnt)
 
 
-def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, max_ratio, iou_thr, max_out,
+def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, coder, iou_thr, max_out,
               scale_factors=None):
     """R-CNN head post-processing + multiclass NMS (bbox_head.py:476-571, bbox_nms.py:12-105).
     scale_factors: per image (w, h) -- `rescale=True` (bbox_head.py:549-554): the decoded, clipped boxes are divided by the
@@ -1013,16 +1028,21 @@ def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, m
     B = img_hw.shape[0]
     n_max = int((roi_start[1:] - roi_start[:-1]).max()) if roi_start.numel() > 1 else 0
     cap = max(n_max * num_classes, 1)
-    if cap > 16384:
-        raise ValueError(f'bbox_post: {n_max} RoIs x {num_classes} classes = {cap} NMS candidates per image exceeds the '
-                         '16384 the single-pass sort of rsp_batched_nms holds (det.hip NMS_MAXW); lower '
-                         'test_cfg.rpn.max_per_img or split the classes')
     cand = _cand_buffers(B, cap, dev)
-    std4 = (ctypes.c_float * 4)(*[float(s) for s in stds])
     rs = roi_start.to(device=dev, dtype=torch.int32)
     _lib.check(lib.rsp_bbox_post(head.data_ptr(), ld, rois.data_ptr(), rs.data_ptr(), img_hw.data_ptr(), B,
-                                 num_classes, score_thr, std4, max_ratio, cap, *[c.data_ptr() for c in cand],
+                                 num_classes, score_thr, ctypes.byref(box_coder(coder)), cap, *[c.data_ptr() for c in cand],
                                  _stream()), "rsp_bbox_post")
+    if cap > NMS_LDS_CANDIDATES:
+        # many classes (the RSPrompter datasets have 1 or 10: never here): size the NMS by the candidates that passed the
+        # score threshold -- one host sync -- instead of by RoIs x classes; its pair mask is quadratic in that size
+        cmax = max(int(cand[4].max()), 1)
+        if cmax > NMS_MAX_CANDIDATES:
+            raise ValueError(f'bbox_post: {cmax} of {n_max} RoIs x {num_classes} classes passed score_thr={score_thr}; '
+                             f'rsp_batched_nms holds {NMS_MAX_CANDIDATES} candidates per image (det.hip NMS_MAXW_LARGE)')
+        if cmax < cap:
+            cand = tuple(c[:, :cmax].contiguous() for c in cand[:4]) + (cand[4],)
+            cap = cmax
     if scale_factors is not None:
         for b, sf in enumerate(scale_factors):
             inv = (1 / float(sf[0]), 1 / float(sf[1]))          # bbox_head.py:550: python reciprocal, then an fp32 product

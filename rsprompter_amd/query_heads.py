@@ -56,9 +56,10 @@ class MSDeformAttnPixelDecoder(HIPModule):
         super().__init__()
         lc = encoder['layer_cfg']
         sa = lc['self_attn_cfg']
-        if (sa['num_heads'], sa['num_levels'], sa['num_points']) != (8, 3, 4) or sa['embed_dims'] not in (128, 256):
-            raise NotImplementedError('the MSDeformAttn kernel covers 8 heads x (16 | 32), 3 levels, 4 points: the '
-                                      'RSPrompter (128) and samseg-mask2former (256) configurations')
+        if (sa['num_heads'], sa['num_points']) != (8, 4) or sa['embed_dims'] not in (128, 256) or \
+                not 1 <= sa['num_levels'] <= min(5, len(in_channels)):
+            raise NotImplementedError('the MSDeformAttn kernel covers 8 heads x (16 | 32), 1-5 levels, 4 points: the '
+                                      'RSPrompter (128) and samseg-mask2former (256) configurations use 3 levels')
         if feat_channels != sa['embed_dims'] or (norm_cfg or {}).get('num_groups', 32) != 32:
             raise NotImplementedError('feat_channels must equal the encoder width; GroupNorm(32) only')
         self.in_channels, self.strides = list(in_channels), list(strides)
@@ -73,8 +74,8 @@ class MSDeformAttnPixelDecoder(HIPModule):
             _add_ln(self, f'input_convs.{i}.gn', f)
         for n in range(self.num_layers):
             p = f'encoder.layers.{n}'
-            _add_linear(self, p + '.self_attn.sampling_offsets', 8 * 3 * 4 * 2, f)
-            _add_linear(self, p + '.self_attn.attention_weights', 8 * 3 * 4, f)
+            _add_linear(self, p + '.self_attn.sampling_offsets', 8 * self.n_enc * 4 * 2, f)
+            _add_linear(self, p + '.self_attn.attention_weights', 8 * self.n_enc * 4, f)
             _add_linear(self, p + '.self_attn.value_proj', f, f)
             _add_linear(self, p + '.self_attn.output_proj', f, f)
             _add_linear(self, p + '.ffn.layers.0.0', self.ffn_dim, f)
@@ -100,7 +101,7 @@ class MSDeformAttnPixelDecoder(HIPModule):
         for n in range(self.num_layers):
             L = _g(self, f'encoder.layers.{n}')
             sa = L.self_attn
-            # offsets (192) and attention logits (96) come out of ONE GEMM on (query + pos)
+            # offsets (192 at 3 levels) and attention logits (96) come out of ONE GEMM on (query + pos)
             w = torch.cat([sa.sampling_offsets.weight.detach(), sa.attention_weights.weight.detach()], 0)
             b = torch.cat([sa.sampling_offsets.bias.detach(), sa.attention_weights.bias.detach()], 0)
             P['layers'].append(dict(ow=ops.PackedWeight(w, b), value=_pw(sa.value_proj), out=_pw(sa.output_proj),
@@ -223,9 +224,12 @@ class _Mask2FormerCore(HIPModule):
                            or bool(enforce_decoder_input_project))
         if td['layer_cfg']['cross_attn_cfg']['embed_dims'] != feat_channels:
             raise NotImplementedError('decoder width != feat_channels (pixel decoder memories are feat_channels wide)')
-        if num_transformer_feat_level != 3:
-            raise NotImplementedError('three transformer feature levels: the MSDeformAttn pixel decoder kernel is built '
-                                      'for 3 levels (every shipped config)')
+        # mask2former_head.py:106-107
+        assert pixel_decoder['encoder']['layer_cfg']['self_attn_cfg']['num_levels'] == num_transformer_feat_level
+        if pixel_decoder.get('num_outs', 3) < num_transformer_feat_level:
+            raise ValueError(f'pixel_decoder.num_outs={pixel_decoder.get("num_outs", 3)} memories for '
+                             f'{num_transformer_feat_level} transformer feature levels (mask2former_head.py:409 indexes '
+                             'multi_scale_memorys[i] for every level)')
         pd = copy.deepcopy(dict(pixel_decoder))
         pd.update(in_channels=in_channels, feat_channels=feat_channels, out_channels=out_channels)
         self.pixel_decoder = MODELS.build(pd)

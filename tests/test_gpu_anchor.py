@@ -141,7 +141,7 @@ def test_bbox_head_and_detection_selection(setup, dev):
     roi_start = torch.tensor([0] + list(torch.tensor(counts).cumsum(0)), dtype=torch.int64)
     from rsprompter_amd.anchor_heads import _img_hw
     out = ops.bbox_post(head.to(dev), LD, rois, roi_start, _img_hw(setup['metas'], dev), nc, 0.05,
-                        (0.1, 0.1, 0.2, 0.2), m.roi_head.bbox_head.bbox_coder.max_ratio, 0.5, 100)
+                        m.roi_head.bbox_head.bbox_coder, 0.5, 100)
     kept = out['count'].tolist()
     for b in range(B):
         ref = tr['dets'][b]

@@ -93,7 +93,7 @@ def _flips_are_ties(our_masks, ref_trace, n_img, pick=None):
             ours = ours[pick]
         assert ours.shape[0] == n_img
         ref_m = b.cpu().bool().view(n_img, -1, nq, b.shape[-1])[:, 0]
-        size = ref_trace['memory'][i % 3].shape[-2:]
+        size = ref_trace['memory'][i % ref_trace.get('levels', 3)].shape[-2:]
         z = F.interpolate(ref_trace['mask_pred_plus_all'][i].float(), size, mode='bilinear', align_corners=False).flatten(2)
         diff = ours != ref_m                                                   # [n_img, Nq, HW]
         flips.append(int(diff.sum()))
@@ -403,23 +403,32 @@ def test_config4_query_vith_lora_batch4(dev):
         assert mism < 1e-3
 
 
-@pytest.mark.parametrize('opts', [dict(decoder_plus=False), dict(with_sincos=False), dict(enforce_decoder_input_project=True)])
+@pytest.mark.parametrize('opts', [dict(decoder_plus=False), dict(with_sincos=False), dict(enforce_decoder_input_project=True),
+                                  dict(levels=2), dict(levels=4, enforce_decoder_input_project=True)])
 def test_query_head_option_branches(dev, opts):
     """RSMask2FormerHead branches no shipped config selects (models.py:303-307 / 361-385 decoder_plus=False: the SAM decoder
     runs in all 7 stages and its masks drive the attention masks; :315-318 / 346-347 with_sincos=False;
-    mask2former_head.py:93-100 enforce_decoder_input_project) on the device against the oracle, ViT-B, 2 tiles, Nq = 30."""
+    mask2former_head.py:93-100 enforce_decoder_input_project; num_transformer_feat_level = pixel-decoder num_levels != 3,
+    mask2former_head.py:103-135 / models.py:404-409, 438, 457) on the device against the oracle (pinned on the real class
+    run with the same arguments: test_oracle_forwards.py), ViT-B, 2 tiles, Nq = 30."""
     from oracle.query import QueryOracle
     from rsprompter_amd.default_configs import rsprompter_query
     from rsprompter_amd.synth import synth_images, synth_metas
     NQ = 30
     cfg = rsprompter_query('base', 1, (NQ, 5), max_per_image=20)
-    cfg['panoptic_head'].update(opts)
+    tag, opts = f'query ViT-B {opts}', dict(opts)
+    levels = opts.pop('levels', 3)
+    ph = cfg['panoptic_head']
+    ph.update(opts)
+    ph['num_transformer_feat_level'] = levels
+    ph['pixel_decoder']['encoder']['layer_cfg']['self_attn_cfg']['num_levels'] = levels
+    ph['pixel_decoder']['num_outs'] = max(levels, 3)
     hk = dict(decoder_plus=opts.get('decoder_plus', True), with_sincos=opts.get('with_sincos', True),
-              input_proj=opts.get('enforce_decoder_input_project', False))
+              input_proj=opts.get('enforce_decoder_input_project', False), levels=levels)
     oracle = QueryOracle('base', 1, NQ, max_per_image=20, head_kwargs=hk)
     model = _build(cfg, oracle, dev, seed=5)
     imgs, metas = synth_images(2, seed=11), synth_metas(2)
-    _check_query(model, oracle, imgs, metas, dev, f'query ViT-B {opts}')
+    _check_query(model, oracle, imgs, metas, dev, tag)
 
 
 def test_anchor_mask_head_multimask_output(dev):

@@ -432,8 +432,12 @@ def _rand_boxes(n, g, size=1024.):
 
 
 @pytest.mark.parametrize('n,nid,thr,max_out', [(5000, 5, 0.7, 1000), (10000, 10, 0.5, 100), (37, 1, 0.5, 100),
-                                                (0, 1, 0.5, 10)])
+                                                (0, 1, 0.5, 10), (16384, 16, 0.5, 100), (20000, 2, 0.3, 20000),
+                                                (40000, 80, 0.6, 40000)])
 def test_batched_nms_matches_oracle(dev, n, nid, thr, max_out):
+    """mmcv batched_nms (coordinate-offset form; per-id loop + stable re-sort above its split_thr of 10000 boxes) with many
+    exact score ties.  Up to 16384 candidates sort in LDS, larger sets in memory (det.hip NMS_LDS_KEYS) with the
+    32-word removal registers -- multiclass_nms of many-class heads (bbox_nms.py:12-105)."""
     from oracle import glue
     from rsprompter_amd import ops
     g = torch.Generator().manual_seed(10 + n)

@@ -110,12 +110,104 @@ def test_box_prompt_mask_post_and_scale_boxes(dev):
     assert torch.equal(ops.scale_boxes(b.to(dev), f).cpu(), b * torch.tensor(f, dtype=torch.float32))
 
 
+def test_box_coder_branches_on_the_real_heads_vectors(dev):
+    """rsp_rpn_decode / rsp_bbox_post with the DeltaXYWHBBoxCoder branches no RSPrompter config uses (target_means != 0,
+    target_stds != 1 in the RPN, clip_border=False, add_ctr_clamp: delta_xywh_bbox_coder.py:264-361) on vectors of the REAL
+    RPNHead / BBoxHead `_predict_by_feat_single` (tests/golden/make_golden_coder.py): every decode step rounds as the
+    reference's eager fp32 expression, so the kept sets are the reference's and boxes agree to the decode's rounding."""
+    from rsprompter_amd import ops
+    from rsprompter_amd.anchor_heads import AnchorGenerator, DeltaXYWHBBoxCoder
+    g = torch.load(os.path.join(HERE, 'golden', 'reference_vectors_coder.pt'), weights_only=False)
+    gen = AnchorGenerator(strides=[4, 8, 16, 32, 64], ratios=[0.5, 1.0, 2.0], scales=[4, 8])
+    base = torch.stack(gen.base_anchors, 0)
+    for name, kw in g['coders'].items():
+        coder = DeltaXYWHBBoxCoder(**kw)
+        # ---- RPN
+        c = g['rpn_predict_single'][name]
+        A, LD = 6, 32
+        heads = []
+        for cl, rg in zip(c['cls'], c['reg']):
+            _, H, W = cl.shape
+            h = torch.zeros((H, W, LD))
+            h[..., :A] = cl.permute(1, 2, 0)
+            h[..., A:5 * A] = rg.permute(1, 2, 0)
+            heads.append(h.reshape(H * W, LD).to(dev).contiguous())
+        sel = ops.RpnSelector(base, [4, 8, 16, 32, 64], c['nms_pre'], c['max_per_img'], c['iou_thr'], c['min_bbox_size'],
+                              coder, dev)
+        out = sel(heads, c['sizes'], LD, torch.tensor([c['img_shape']], dtype=torch.float32, device=dev))
+        k = int(out['count'][0])
+        assert k == c['scores'].shape[0], (name, k, c['scores'].shape)
+        gb, gs = out['boxes'][0, :k].cpu(), out['scores'][0, :k].cpu()
+        assert _err(gs, c['scores']) < 1e-6, name
+        bad = ((gb - c['bboxes']).abs().amax(1) > 2e-3).nonzero()[:, 0].tolist()
+        assert len(bad) <= 4, (name, len(bad))                 # rows may trade places at (near-)equal scores only
+        for i in bad:
+            d = (c['bboxes'] - gb[i]).abs().amax(1)
+            j = int(d.argmin())
+            assert float(d[j]) < 2e-3 and abs(float(c['scores'][j]) - float(gs[i])) < 1e-6, (name, i, j)
+        # ---- R-CNN box head
+        c = g['bbox_head_predict_single'][name]
+        n, nc = c['roi'].shape[0], c['num_classes']
+        LDb = (5 * nc + 1 + 3) // 4 * 4
+        head = torch.zeros((n, LDb))
+        head[:, :nc + 1] = c['cls_score']
+        head[:, nc + 1:5 * nc + 1] = c['bbox_pred']
+        out = ops.bbox_post(head.to(dev), LDb, c['roi'].to(dev), torch.tensor([0, n]),
+                            torch.tensor([c['img_shape']], dtype=torch.float32, device=dev), nc, c['score_thr'], coder,
+                            c['iou_thr'], c['max_per_img'])
+        k = int(out['count'][0])
+        assert k == c['labels'].shape[0], name
+        pairs = match_detections(out['boxes'][0, :k].cpu(), out['scores'][0, :k].cpu(), out['ids'][0, :k].cpu().long(),
+                                 c['bboxes'], c['scores'], c['labels'])
+        assert len(pairs) == k, name
+        ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
+        assert _err(out['boxes'][0, :k].cpu()[ii], c['bboxes'][jj]) < 2e-3, name
+        assert _err(out['scores'][0, :k].cpu()[ii], c['scores'][jj]) < 1e-6, name
+        assert int((ii != jj).sum()) <= 4, name                # rank swaps only at score ties
+        print(f'coder {name}: RPN {c["labels"].shape[0]} / head detections match the real heads')
+
+
+def test_bbox_post_many_classes(dev):
+    """multiclass_nms of a many-class head (bbox_nms.py:12-105; 500 RoIs x 80 classes = 40000 (RoI, class) pairs, above the
+    16384 candidates the NMS sorts in LDS): ops.bbox_post sizes the NMS by the pairs that pass score_thr and the in-memory
+    sort / 32-word reduction take over above 16384 of those.  Checked against the oracle's restatement of
+    BBoxHead._predict_by_feat_single (itself pinned on the real class, test_oracle_golden.py)."""
+    from oracle import glue
+    from rsprompter_amd import ops
+    from rsprompter_amd.anchor_heads import DeltaXYWHBBoxCoder
+    coder = DeltaXYWHBBoxCoder(target_stds=(0.1, 0.1, 0.2, 0.2))
+    for seed, (n, nc, thr, temp) in enumerate(((500, 80, 0.05, 3.0), (500, 80, 0.005, 0.7))):
+        g = torch.Generator().manual_seed(500 + seed)
+        xy = torch.rand(n, 2, generator=g) * 800
+        roi = torch.cat([torch.zeros(n, 1), xy, xy + torch.rand(n, 2, generator=g) * 200 + 2], 1)
+        cls_score = torch.randn(n, nc + 1, generator=g) * temp
+        bbox_pred = torch.randn(n, nc * 4, generator=g)
+        LD = (5 * nc + 1 + 3) // 4 * 4
+        head = torch.zeros((n, LD))
+        head[:, :nc + 1] = cls_score
+        head[:, nc + 1:5 * nc + 1] = bbox_pred
+        dets, labels, cand = glue.bbox_head_predict_single(roi, cls_score, bbox_pred, (1024, 1024), nc, thr, 0.5, 100)
+        n_valid = int((torch.softmax(cls_score, -1)[:, :-1] > thr).sum())
+        out = ops.bbox_post(head.to(dev), LD, roi.to(dev), torch.tensor([0, n]),
+                            torch.tensor([[1024., 1024.]], device=dev), nc, thr, coder, 0.5, 100)
+        k = int(out['count'][0])
+        print(f'{n} RoIs x {nc} classes: {n_valid} candidates pass score_thr={thr}, {k} detections')
+        assert k == labels.shape[0]
+        pairs = match_detections(out['boxes'][0, :k].cpu(), out['scores'][0, :k].cpu(), out['ids'][0, :k].cpu().long(),
+                                 dets[:, :4], dets[:, 4], labels)
+        assert len(pairs) == k
+        ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
+        assert _err(out['boxes'][0, :k].cpu()[ii], dets[:, :4][jj]) < 2e-3
+        assert int((ii != jj).sum()) <= 4
+    assert n_valid > 16384          # the second case runs the in-memory sort
+
+
 def test_bbox_post_matches_real_bbox_head_with_and_without_rescale(dev):
     """rsp_bbox_post (+ rsp_scale_boxes, rsp_batched_nms) on the golden vectors of the REAL BBoxHead._predict_by_feat_single
     (bbox_head.py:476-571; tests/golden/make_golden_heads.py): rescale=True multiplies by fp32(1 / scale_factor) before the
     NMS -- labels and the kept set are exact, boxes and scores to fp32 rounding of the decode."""
-    import math
     from rsprompter_amd import ops
+    from rsprompter_amd.anchor_heads import DeltaXYWHBBoxCoder
     g = torch.load(os.path.join(HERE, 'golden', 'reference_vectors_heads.pt'), weights_only=False)
     for key in ('bbox_head_predict_single', 'bbox_head_predict_single_rescale'):
         for c in g[key]:
@@ -126,8 +218,8 @@ def test_bbox_post_matches_real_bbox_head_with_and_without_rescale(dev):
             head[:, nc + 1:5 * nc + 1] = c['bbox_pred']
             sf = c.get('scale_factor')
             out = ops.bbox_post(head.to(dev), LD, c['roi'].to(dev), torch.tensor([0, n]), torch.tensor([c['img_shape']],
-                                dtype=torch.float32, device=dev), nc, c['score_thr'], (0.1, 0.1, 0.2, 0.2),
-                                abs(math.log(16 / 1000)), c['iou_thr'], c['max_per_img'],
+                                dtype=torch.float32, device=dev), nc, c['score_thr'],
+                                DeltaXYWHBBoxCoder(target_stds=(0.1, 0.1, 0.2, 0.2)), c['iou_thr'], c['max_per_img'],
                                 scale_factors=None if sf is None else [sf])
             k = int(out['count'][0])
             assert k == c['labels'].shape[0], (key, sf)

@@ -235,7 +235,17 @@ def test_query_pipeline_end_to_end_host_logic(mocked):
     assert float((pi.masks[same] != r['masks'][same]).float().mean()) < 1e-3
 
 
-@pytest.mark.parametrize('opts', [dict(decoder_plus=False), dict(with_sincos=False), dict(enforce_decoder_input_project=True)])
+def _set_feat_levels(head_cfg, levels):
+    """num_transformer_feat_level with what has to follow it: the pixel decoder's num_levels (mask2former_head.py:106-107)
+    and enough memories (num_outs)"""
+    head_cfg['num_transformer_feat_level'] = levels
+    pd = head_cfg['pixel_decoder']
+    pd['encoder']['layer_cfg']['self_attn_cfg']['num_levels'] = levels
+    pd['num_outs'] = max(levels, 3)
+
+
+@pytest.mark.parametrize('opts', [dict(decoder_plus=False), dict(with_sincos=False), dict(enforce_decoder_input_project=True),
+                                  dict(levels=2), dict(levels=4, enforce_decoder_input_project=True)])
 def test_query_head_option_branches_host_logic(mocked, opts):
     """Branches of RSMask2FormerHead that no shipped config selects but the reference implements (VERDICT r3 missing 3):
     decoder_plus=False (models.py:303-307, 361-385: no mask-embedding MLP, the SAM decoder runs in every stage with the
@@ -250,12 +260,15 @@ def test_query_head_option_branches_host_logic(mocked, opts):
     from rsprompter_amd.synth import synth_images, synth_metas, synth_state_dict
     NQ = 12
     cfg = rsprompter_query('base', 1, prompt_shape=(NQ, 5), max_per_image=6)
+    opts = dict(opts)
+    levels = opts.pop('levels', 3)
     cfg['panoptic_head'].update(opts)
+    _set_feat_levels(cfg['panoptic_head'], levels)      # num_transformer_feat_level != 3 (models.py:404-409, 438, 457)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         model = ra.build_model(cfg)
     hk = dict(decoder_plus=opts.get('decoder_plus', True), with_sincos=opts.get('with_sincos', True),
-              input_proj=opts.get('enforce_decoder_input_project', False))
+              input_proj=opts.get('enforce_decoder_input_project', False), levels=levels)
     oracle = QueryOracle('base', 1, num_queries=NQ, max_per_image=6, head_kwargs=hk)
     sd = synth_state_dict(oracle, 0)
     oracle.load_state_dict(sd)
@@ -265,7 +278,7 @@ def test_query_head_option_branches_host_logic(mocked, opts):
     if opts.get('decoder_plus', True) is False:
         assert 'panoptic_head.no_mask_embed.weight' in keys and not any('mask_embed.0' in k or 'sam_mask_embed' in k for k in keys)
     if opts.get('enforce_decoder_input_project'):
-        assert 'panoptic_head.decoder_input_projs.2.weight' in keys
+        assert f'panoptic_head.decoder_input_projs.{levels - 1}.weight' in keys
     imgs, metas = synth_images(1), synth_metas(1)
     x = glue.data_preprocess(imgs, [123.675, 116.28, 103.53], [58.395, 57.12, 57.375], True, 32)
     ref, tr = oracle.predict(x, metas)

@@ -111,6 +111,33 @@ def test_query_head_matches_real_class(gold):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize('name', ['levels2', 'levels4_proj', 'no_sincos', 'no_decoder_plus'])
+def test_query_head_option_branches_match_real_class(name):
+    """The RSMask2FormerHead branches no shipped config selects (num_transformer_feat_level != 3,
+    enforce_decoder_input_project, with_sincos=False, decoder_plus=False) against the REAL class run with those arguments
+    (tests/golden/make_golden_query_options.py): state_dict layout and every stage's outputs."""
+    from oracle.query import QueryHead
+    g = torch.load(os.path.join(os.path.dirname(GOLD), 'reference_vectors_query_options.pt'), weights_only=False)[name]
+    m = load(QueryHead(g['num_classes'], g['num_queries'], **g['head_kwargs']), g)
+    xs = [rnd(s) for s in g['xs']]
+    emb = rnd(g['emb'])
+    pe = rnd(g['pe']).repeat(g['batch'], 1, 1, 1)
+    mf, mem = m.pixel_decoder(xs)
+    assert len(mem) == g['n_memories']
+    assert err(mf[:, ::4, ::4, ::4], g['mask_features']) < 1e-4
+    for a, b in zip(mem, g['memories']):
+        assert err(a[:, ::2], b) < 1e-4
+    cls, mask, tr = m(xs, emb, pe)
+    assert len(tr['cls_pred_all']) == len(g['cls_pred_all']) == 7
+    for a, b in zip(tr['cls_pred_all'], g['cls_pred_all']):
+        assert err(a, b) < 1e-4
+    stage = g.get('mask_pred_plus_all', g.get('mask_pred_all'))     # what each stage cuts its attention mask from
+    for a, b in zip(tr['mask_pred_plus_all'], stage):
+        assert err(a[:, :, ::4, ::4], b) < 2e-4
+    assert err(mask[:, :, ::2, ::2], g['mask_pred']) < 2e-4
+
+
+@torch.no_grad()
 def test_vitsam_forward_matches_real_class(gold):
     from oracle.vitsam import ViTSAM
     g = gold['vitsam']

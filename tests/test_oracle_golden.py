@@ -261,6 +261,50 @@ def test_detection_glue_restatements_match_reference_vectors():
     assert torch.equal(glue.map_roi_levels(m['rois'], m['num_levels'], m['finest_scale']), m['out'])
 
 
+def _coder_kw(kw):
+    """DeltaXYWHBBoxCoder constructor keywords -> oracle.glue.delta2bbox keywords"""
+    m = dict(target_means='means', target_stds='stds')
+    return {m.get(k, k): v for k, v in kw.items()}
+
+
+def test_box_coder_branches_match_reference_vectors():
+    """The DeltaXYWHBBoxCoder branches no RSPrompter config uses (target_means != 0, clip_border=False, add_ctr_clamp:
+    delta_xywh_bbox_coder.py:264-361) against the REAL coder, alone and inside the REAL RPNHead / BBoxHead
+    `_predict_by_feat_single` (tests/golden/make_golden_coder.py), incl. the reference's own known-answer test of the
+    centre clamp (test_delta_xywh_bbox_coder.py:44-57)."""
+    import os
+    from oracle import glue
+    d = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_vectors_coder.pt'))
+    k = d['kat_ctr_clamp']
+    out = glue.delta2bbox(k['rois'], k['deltas'], max_shape=k['max_shape'], **_coder_kw(k['coder']))
+    assert torch.allclose(out, k['expected'], atol=1e-4) and torch.equal(out, k['out'])
+    differs = 0
+    for name, kw in d['coders'].items():
+        c = d['decode'][name]
+        out = glue.delta2bbox(c['rois'], c['deltas'], max_shape=c['max_shape'], **_coder_kw(kw))
+        assert torch.equal(out, c['out']), name
+        differs += int(not torch.equal(out, d['decode']['plain']['out']))
+        c = d['rpn_predict_single'][name]
+        priors = glue.grid_priors(c['sizes'], [4, 8, 16, 32, 64], [4, 8], [0.5, 1.0, 2.0])
+        r = glue.rpn_predict_single(c['cls'], c['reg'], priors, c['img_shape'], nms_pre=c['nms_pre'],
+                                    max_per_img=c['max_per_img'], iou_thr=c['iou_thr'], min_bbox_size=c['min_bbox_size'],
+                                    coder=_coder_kw(kw))
+        assert torch.equal(r['scores'], c['scores']), name
+        if not torch.equal(r['bboxes'], c['bboxes']):      # the reference's sort is not stable (rpn_head.py:208): rows may
+            bad = (r['bboxes'] != c['bboxes']).any(1)      # only trade places inside runs of exactly equal scores
+            assert int(bad.sum()) <= 4, name
+            for sc in r['scores'][bad].unique():
+                run = r['scores'] == sc
+                assert sorted(map(tuple, r['bboxes'][run].tolist())) == sorted(map(tuple, c['bboxes'][run].tolist())), name
+        c = d['bbox_head_predict_single'][name]
+        dets, labels, _ = glue.bbox_head_predict_single(c['roi'], c['cls_score'], c['bbox_pred'], c['img_shape'],
+                                                        c['num_classes'], c['score_thr'], c['iou_thr'], c['max_per_img'],
+                                                        coder=_coder_kw(kw))
+        assert torch.equal(dets[:, :4], c['bboxes']) and torch.equal(dets[:, 4], c['scores']), name
+        assert torch.equal(labels, c['labels']), name
+    assert differs == len(d['coders']) - 1          # every variant decodes different boxes than the shipped coder
+
+
 def test_mmcv_leaf_known_answers():
     """Hand-derivable known-answer vectors for the mmcv LEAF ops whose source is not under /root/reference
     (SURVEY.md App. B): the C / torch restatements (oracle/mmcv_ops.c, oracle/query.py) are checked by something other

@@ -339,10 +339,17 @@ def _padded(rows, max_out, B):
     return out
 
 
+def _coder_kwargs(coder):
+    """delta2bbox keywords of a DeltaXYWHBBoxCoder facade (wh_ratio_clip is the class default everywhere)"""
+    return dict(means=tuple(coder.means), stds=tuple(coder.stds), clip_border=coder.clip_border,
+                add_ctr_clamp=coder.add_ctr_clamp, ctr_clamp=coder.ctr_clamp)
+
+
 class RpnSelector:
     """rpn_head.py:134-304 through the oracle's restatement (pinned on the reference's own code)."""
 
-    def __init__(self, base_anchors, strides, nms_pre, max_per_img, iou_thr, min_bbox_size, max_ratio, device):
+    def __init__(self, base_anchors, strides, nms_pre, max_per_img, iou_thr, min_bbox_size, coder, device):
+        self.coder = _coder_kwargs(coder)
         self.base, self.strides = base_anchors.float(), list(strides)
         self.A = self.base.shape[1]
         self.nms_pre, self.max_per_img, self.iou_thr, self.min_bbox_size = nms_pre, max_per_img, iou_thr, min_bbox_size
@@ -364,12 +371,12 @@ class RpnSelector:
             reg = [h.view(B, H, W, ld)[b, :, :, A:5 * A].permute(2, 0, 1) for h, (H, W) in zip(heads, sizes)]
             r = glue.rpn_predict_single(cls, reg, priors, (int(img_hw[b, 0]), int(img_hw[b, 1])), nms_pre=self.nms_pre,
                                         max_per_img=self.max_per_img, iou_thr=self.iou_thr,
-                                        min_bbox_size=self.min_bbox_size)
+                                        min_bbox_size=self.min_bbox_size, coder=self.coder)
             rows.append((r['bboxes'], r['scores'], r['level_ids'], r['anchor_index']))
         return _padded(rows, self.max_per_img, B)
 
 
-def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, max_ratio, iou_thr, max_out,
+def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, coder, iou_thr, max_out,
               scale_factors=None):
     from oracle import glue
     B, nc = img_hw.shape[0], num_classes
@@ -382,7 +389,7 @@ def bbox_post(head, ld, rois, roi_start, img_hw, num_classes, score_thr, stds, m
         dets, labels, cand = glue.bbox_head_predict_single(rois[r0:r1], head[r0:r1, :nc + 1].contiguous(),
                                                            head[r0:r1, nc + 1:5 * nc + 1].contiguous(),
                                                            (int(img_hw[b, 0]), int(img_hw[b, 1])), nc, score_thr, iou_thr,
-                                                           max_out, stds=tuple(stds),
+                                                           max_out, coder=_coder_kwargs(coder),
                                                            scale_factor=None if scale_factors is None else scale_factors[b])
         rows.append((dets[:, :4], dets[:, 4], labels, cand))
     return _padded(rows, max_out, B)
@@ -402,7 +409,7 @@ class PlaneWeight:
 
 def groupnorm(x, gamma, beta, groups, eps=1e-5, relu=False, add=None):
     B, C = x.shape[0], x.shape[-1]
-    y = F.group_norm(x.reshape(B, -1, C).transpose(1, 2), groups, gamma, beta, eps).transpose(1, 2).reshape(x.shape)
+    y = F.group_norm(x.reshape(B, -1, C).transpose(1, 2), groups, gamma, beta, eps).transpose(1, 2).reshape(x.shape).contiguous()
     if add is not None:
         y = y + add
     return F.relu(y) if relu else y
