@@ -629,8 +629,10 @@ extern "C" int rsp_batched_nms(const float* boxes, const float* scores, const in
   p.keep = keep; p.keep_cnt = keep_cnt;
   hipStream_t s = (hipStream_t)stream;
   const size_t smem = p.gkeys ? 0 : (size_t)nsort * sizeof(unsigned long long);
+  // always the LDS path's maximum: the attribute is per function, not per launch (concurrent callers of either path)
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&nms_prepare_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)(NMS_LDS_KEYS * sizeof(unsigned long long)));
   if (e != hipSuccess) return RSP_ELAUNCH;
   hipLaunchKernelGGL(nms_prepare_kernel, dim3(B), dim3(1024), smem, s, p);
   const int gw = p.words < 256 ? p.words : 256;
