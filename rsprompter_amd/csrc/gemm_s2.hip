@@ -483,6 +483,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
           const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
           *reinterpret_cast<f32x4*>(et + wr_off + (((j * 8 + 2 * q + hh) ^ (l31 & 7)) << 4)) = v;
         });
+        RSP_WAVE_LOCKSTEP();
         // (3) read back: 4 rows x 64 columns per instruction
         f32x4 x[NG];
 #pragma unroll
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_s2_kernel(const S2P p) {
           const int lr = g * 4 + lr0;
           x[g] = *reinterpret_cast<const f32x4*>(et + rd_off + g * 1024 + ((((c4 >> 2)) ^ (lr & 7)) << 4));
         }
+        RSP_WAVE_LOCKSTEP();                                  // (the next pass overwrites the piece)
         if constexpr (i + 1 == TM) {                          // every wave has its last piece: the ring is free
           asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7]));
           __builtin_amdgcn_s_waitcnt(WC_LGKM0);

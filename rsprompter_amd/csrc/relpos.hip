@@ -303,14 +303,17 @@ __global__ __launch_bounds__(256) void vit_relpos_glob_kernel(const float* __res
   };
   // ---- rel_h: A row m of block blk = Rh[qy + S-1 - (32 blk + m)] -> piece[q][j] = rel_h[q, j] ----
   product(sTh[0], sTh[1], (qy - qyb) + S - 1 - l31, S / 32, -1);
+  RSP_WAVE_LOCKSTEP();                                         // the piece is private to the wave: no block barrier
   for (int g = 0; g < 32; g += rpi) {
     const int r_ = g + lr;
     const float* pr = piece + r_ * GS + c4;
     const f32x4 o = {pr[0], pr[1], pr[2], pr[3]};
     *reinterpret_cast<f32x4*>(dst0 + (int64_t)r_ * (2 * S) + c4) = o;
   }
+  RSP_WAVE_LOCKSTEP();
   // ---- rel_w: G_w^T for table rows qx0 .. qx0 + 32 nbw - 1, then rel_w[q, j] = piece[q][(q - q0) + S-1 - j] ----
   product(sTw[0], sTw[1], qx0 + l31, (S + 62) / 32, 0);
+  RSP_WAVE_LOCKSTEP();
   for (int g = 0; g < 32; g += rpi) {
     const int r_ = g + lr;
     const float* pr = piece + r_ * GS + r_ + S - 1 - c4;

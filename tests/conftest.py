@@ -18,6 +18,14 @@ def pytest_configure(config):
 @pytest.fixture(scope='session')
 def dev():
     import torch
+    if os.environ.get('RSP_WAVE_EMU') == '1':
+        # developer mode (tests/wave_emu/README.md): `RSP_WAVE_EMU=1 pytest tests/test_gpu_kernels.py -m gpu -k ...` runs
+        # GPU tests on CPU tensors through the lane-level emulation of the kernels -- slow, small shapes only
+        sys.path.insert(0, os.path.join(ROOT, 'tests', 'wave_emu'))
+        import harness
+        with harness.emulated_ops():
+            yield torch.device('cpu')
+        return
     if not torch.cuda.is_available():
         pytest.skip('no GPU')
-    return torch.device('cuda:0')
+    yield torch.device('cuda:0')

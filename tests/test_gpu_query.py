@@ -95,6 +95,33 @@ def test_query_kernels_unit(dev):
     assert _maxerr(out, want) < 2e-5
 
 
+@pytest.mark.parametrize('shapes,dim', [([(6, 5)], 128), ([(4, 4), (8, 6)], 128), ([(3, 3), (4, 6), (8, 8), (16, 12)], 128),
+                                        ([(2, 2), (3, 3), (4, 4), (6, 6), (8, 8)], 256)])
+def test_msdeform_attn_level_counts(dev, shapes, dim):
+    """MultiScaleDeformableAttention with 1, 2, 4 and 5 levels (num_transformer_feat_level = the pixel decoder's num_levels
+    != 3, mask2former_head.py:103-135; msda_kernel is templated on the level count) against the oracle's restatement,
+    offsets large enough to leave the maps; 8 heads x 16 and x 32."""
+    from oracle.query import MSDeformAttn
+    from rsprompter_amd import ops
+    L = len(shapes)
+    g = torch.Generator().manual_seed(10 + L)
+    torch.manual_seed(77 + L)
+    m = MSDeformAttn(dim=dim, levels=L)
+    ntok = sum(h * w_ for h, w_ in shapes)
+    q, pos = torch.randn(2, ntok, dim, generator=g), torch.randn(2, ntok, dim, generator=g)
+    refp = torch.rand(ntok, 2, generator=g)
+    with torch.no_grad():
+        m.sampling_offsets.weight.mul_(20)
+        qq = q + pos
+        value = m.value_proj(q)
+        ow = torch.cat([m.sampling_offsets(qq), m.attention_weights(qq)], -1)              # [2, ntok, 8 * L * 4 * 3]
+        want = (m(q, pos, refp[None, :, None].repeat(2, 1, L, 1), torch.tensor(shapes)) - q).double()
+    got = ops.msdeform_attn(value.reshape(-1, dim).contiguous().to(dev), ow.reshape(-1, 96 * L).contiguous().to(dev),
+                            refp.to(dev), 2, ntok, shapes, head_dim=dim // 8)
+    got_full = got.cpu().double().view(2, ntok, dim) @ m.output_proj.weight.double().t() + m.output_proj.bias.double()
+    assert _maxerr(got_full, want) < 1e-4
+
+
 def test_pixel_decoder_given_oracle_fpn(setup, dev):
     m, tr = setup['model'], setup['trace']
     feats = [_cl(f, dev) for f in tr['fpn']]

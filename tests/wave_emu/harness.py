@@ -1,0 +1,50 @@
+"""TEST INFRASTRUCTURE: run `rsprompter_amd.ops` wrappers on CPU tensors through the lane-level emulation of the kernels
+(tests/wave_emu/emu_hip.h).  Used by tests/test_wave_emu_cpu.py only -- a pytest fixture swaps the library handle, the
+stream getter and the device checks of `ops` for the duration of one test and restores them afterwards; nothing in the
+package can reach this module."""
+import contextlib
+import ctypes
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+_EMU = None
+
+
+def load_emu():
+    global _EMU
+    if _EMU is None:
+        import build
+        from rsprompter_amd import _lib
+        srcs = sorted(f for f in os.listdir(build.CSRC) if f.endswith('.hip'))
+        lib = ctypes.CDLL(build.build(srcs))
+        for name, (res, args) in _lib.PROTOTYPES.items():
+            fn = getattr(lib, name)        # every symbol of include/rsp_hip.h must exist in the emulated build too
+            fn.restype, fn.argtypes = res, args
+        _EMU = lib
+    return _EMU
+
+
+@contextlib.contextmanager
+def emulated_ops():
+    """inside the context `ops.*` launches run in the emulator on CPU tensors"""
+    from rsprompter_amd import _lib, ops
+    lib = load_emu()
+    import torch
+    saved = (_lib._lib, ops._stream, ops._chk_f32, ops.require_device)
+    saved_sync = torch.cuda.synchronize
+    _lib._lib = lib
+    torch.cuda.synchronize = lambda *a, **k: None          # launches complete before they return
+
+    def chk(t, name):
+        import torch
+        if t.dtype != torch.float32:
+            raise ValueError(f'{name}: expected float32')
+    ops._stream, ops._chk_f32, ops.require_device = (lambda: 0), chk, (lambda dev: None)
+    try:
+        yield ops
+    finally:
+        _lib._lib, ops._stream, ops._chk_f32, ops.require_device = saved
+        torch.cuda.synchronize = saved_sync
