@@ -325,6 +325,7 @@ __global__ __launch_bounds__(448) void attn_win_kernel(const AttnWP p, const int
             const int idx = (r & 3) + 8 * (r >> 2) + 4 * hh;
             if (idx < 2 * WS - 1) piece[l31 * PIECE_LD + idx] = g[r] * gs;     // (rows 27..31 of the tables are padding)
           }
+          RSP_WAVE_LOCKSTEP();                          // a query's row comes from both half waves (lanes q and q + 32)
           const int pos = (tb ? qx : qy) + WS - 1;
 #pragma unroll
           for (int n = 0; n < 16; ++n) {
@@ -332,6 +333,7 @@ __global__ __launch_bounds__(448) void attn_win_kernel(const AttnWP p, const int
             const int j = kp - tb * WS;                 // kh (table 0) / kw (table 1)
             if (j >= 0 && j < WS) vals[n] = piece[l31 * PIECE_LD + pos - j];
           }
+          RSP_WAVE_LOCKSTEP();
         }
 #pragma unroll
         for (int n = 0; n < 16; ++n) vals[n] = qv ? vals[n] : 0.f;

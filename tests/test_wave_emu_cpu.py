@@ -1,0 +1,86 @@
+"""CPU (`-m "not gpu"`): the HIP kernels themselves, executed lane by lane on the host.
+
+tests/wave_emu compiles the UNCHANGED sources of rsprompter_amd/csrc against a lane-level emulation of the gfx950
+execution model (64-lane waves as fibers; MFMA 32x32x16 fragment layouts, DMA-to-LDS addressing, the transposing LDS
+read, buffer-resource bounds, shuffles, barriers, divergence by EXEC mask) and these tests call `rsprompter_amd.ops`
+through it on CPU tensors -- the same wrappers, descriptors and dispatch rules the GPU suite uses, at shapes that take
+seconds.  They reuse the bodies of the `-m gpu` tests, so what is asserted here is what is asserted on the MI355X.
+Not a product path: the package cannot load the emulated library (tests/wave_emu/harness.py swaps it in for one test)."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, 'wave_emu'))
+
+DEV = torch.device('cpu')
+
+
+@pytest.fixture(scope='module')
+def emu():
+    if not os.path.exists(os.environ.get('EMU_CXX', '/opt/rocm/lib/llvm/bin/clang++')):
+        pytest.skip('no host clang++ with _Float16 vector support for the emulated build')
+    import harness
+    with harness.emulated_ops() as ops:
+        yield ops
+
+
+def test_emu_persistent_gemm_every_epilogue_form(emu):
+    """gemm_f16x3_s2_kernel (buffer_load ... lds DMA ring, per-XCD tile tickets, per-wave LDS-transposed epilogues) and
+    gemm_f16x3_dma_kernel: fp64 product and bit-equality between the two, specialised and run-time epilogues, ragged
+    M / N, residual forms, GELU + plane outputs, column ranges, row maps with unwritten rows"""
+    import test_gpu_gemm_s2 as t
+    t.test_s2_plain_and_residual(DEV, 300, 64, 128)
+    t.test_s2_gelu_and_plane_outputs(DEV, 200, 128, 64)
+    t.test_s2_column_ranges_and_row_maps(DEV, 64, 128, 203)
+
+
+def test_emu_window_attention_with_relpos_inside(emu):
+    """attn_win_kernel: one-hot bias product, rel-pos tables through the matrix cores, Toeplitz gather through the per-wave
+    LDS piece, lazy online softmax, transposing V reads, persistent blocks over windows incl. partly padded ones"""
+    import test_gpu_kernels as t
+    t.test_vit_window_attention_fused_relpos(DEV, 2, 10, 2, 64, 1, 0)
+    t.test_vit_window_attention_fused_relpos(DEV, 3, 4, 2, 80, 1, 1)      # 18 (window, head) items over 16 persistent blocks
+
+
+def test_emu_layernorm_and_plane_emitters(emu):
+    import test_gpu_kernels as t
+    t.test_layernorm(DEV)
+
+
+def test_emu_detection_kernels_with_every_box_coder(emu):
+    """rpn_topk / rpn_decode / bbox_post / batched NMS on the vectors of the REAL RPNHead / BBoxHead with the coder
+    branches (means, stds, clip_border, add_ctr_clamp), and multiclass NMS above 16384 candidates (in-memory sort,
+    32-word reduction)"""
+    import test_gpu_samdet as t
+    t.test_box_coder_branches_on_the_real_heads_vectors(DEV)
+    t.test_bbox_post_many_classes(DEV)
+
+
+def test_emu_nms_in_memory_sort_path(emu):
+    """rsp_batched_nms with a capacity above the LDS sort (cap 20000 -> 32768 keys sorted in memory) and many exact score
+    ties against the oracle's mmcv restatement"""
+    from oracle import glue
+    g = torch.Generator().manual_seed(3)
+    n, cap, nid = 1500, 20000, 3
+    xy = torch.rand(cap, 2, generator=g) * 300
+    boxes = torch.cat([xy, xy + torch.rand(cap, 2, generator=g) * 80 + 1], 1)[None]
+    scores = ((torch.rand(cap, generator=g) * 40).round() / 40)[None]
+    ids = torch.randint(0, nid, (cap,), generator=g, dtype=torch.int32)[None]
+    cnt = torch.tensor([n], dtype=torch.int32)
+    cand = (boxes.contiguous(), scores.contiguous(), ids.contiguous(), torch.arange(cap, dtype=torch.int32)[None].contiguous(), cnt)
+    out = emu.batched_nms(cand, 1, cap, 0.5, 2000)
+    dets, keep = glue.batched_nms(boxes[0, :n], scores[0, :n], ids[0, :n].long(), 0.5)
+    k = int(out['count'][0])
+    assert k == keep.numel()
+    assert torch.equal(out['keep'][0, :k].long(), keep)
+
+
+def test_emu_msdeform_attn_level_counts(emu):
+    import test_gpu_query as t
+    t.test_msdeform_attn_level_counts(DEV, [(4, 4), (8, 6)], 128)
+    t.test_msdeform_attn_level_counts(DEV, [(3, 3), (4, 6), (8, 8), (16, 12)], 128)
+    t.test_msdeform_attn_level_counts(DEV, [(2, 2), (3, 3), (4, 4), (6, 6), (8, 8)], 256)
