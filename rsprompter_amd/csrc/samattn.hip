@@ -481,6 +481,7 @@ __global__ __launch_bounds__(F2_THREADS) void sam_i2t_fused_mfma_kernel(const I2
           const f32x4 x = *reinterpret_cast<const f32x4*>(p.q + (qb * N + pos) * (int64_t)W + half * 64 + c4);
           *reinterpret_cast<f32x4*>(tb_row + g * 4 * TBR) = x;
         }
+        RSP_WAVE_LOCKSTEP();                                // row layout in, position-per-lane layout out: one wave's piece
 #pragma unroll
         for (int hl = 0; hl < 4; ++hl) {
           const int h = half * 4 + hl;
@@ -500,6 +501,7 @@ __global__ __launch_bounds__(F2_THREADS) void sam_i2t_fused_mfma_kernel(const I2
           }
           __builtin_amdgcn_sched_barrier(0);                // one head's K reads in flight at a time (register pressure)
         }
+        RSP_WAVE_LOCKSTEP();                                // (the piece is overwritten: second half, then the P fragments)
       }
       // softmax over the 2 NKS token slots of every head: NKS here, NKS in lane + 32; probabilities * 2^14, split
 #pragma unroll

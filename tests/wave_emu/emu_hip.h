@@ -388,7 +388,6 @@ inline void emu_amdgcn_s_barrier() { emu::block_barrier(); }
 inline void emu_amdgcn_sched_barrier(int) {}
 inline void emu_amdgcn_s_waitcnt(int) {}
 inline void emu_amdgcn_s_setprio(int) {}
-inline void emu_amdgcn_wave_barrier() {}
 #define emu_amdgcn_fence(...) ((void)0)
 inline uint64_t emu_amdgcn_s_memtime() { return emu::g.n_switch; }
 inline unsigned emu_amdgcn_s_getreg(int) { return 0; }
@@ -489,6 +488,8 @@ __attribute__((noinline)) inline void emu_wave_lockstep() {
   emu::wave_rendezvous([](emu::Wave&) {}, emu::OP_LOCKSTEP, __builtin_return_address(0));
 }
 #define RSP_WAVE_LOCKSTEP() emu_wave_lockstep()
+// s_wave_barrier: the explicit form of the same point (csrc/samattn.hip uses it with wavefront-scope fences)
+__forceinline__ void emu_amdgcn_wave_barrier() { emu_wave_lockstep(); }
 
 __attribute__((noinline)) inline unsigned long long __ballot(int pred) {
   emu::Fiber& f = emu::cur();
