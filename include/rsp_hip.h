@@ -356,6 +356,18 @@ int rsp_batched_nms(const float* boxes, const float* scores, const int32_t* ids,
                     void* workspace, int32_t* keep, int32_t* keep_cnt, float* out_boxes,
                     float* out_scores, int32_t* out_ids, int32_t* out_src, rsp_stream_t stream);
 
+/* Token -> image attention of the SAM two-way transformer with the K | V projections of the PER-RoI keys folded in   */
+/* (HF:326-331, 397-400; csrc/t2i_fold.hip): keys = fp16 planes of [k_rows >= R*N, 256]; pek = planes of k_proj(pe) +    */
+/* bias [N, 128]; qp = planes of q' [q_rows >= R*96, 256] with q'[r*96 + h*T + t] = Wk_h^T tq[r, t, h] (softmax scale     */
+/* inside); tqx = planes of the block-diagonal tq [q_rows, 128]; *_e = plane scale exponents.  u [R*96, 256] fp32 receives */
+/* sum_n softmax(score)[n] * keys[n] per column (rows of columns >= ncols = 8 T <= 96 stay untouched); the caller applies  */
+/* v_proj to it.  N % 32 == 0.                                                                                           */
+int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo, int64_t k_rows, int32_t keys_e,
+                     const uint16_t* pek_hi, const uint16_t* pek_lo, int32_t pek_e, const uint16_t* qp_hi,
+                     const uint16_t* qp_lo, int32_t qp_e, const uint16_t* tqx_hi, const uint16_t* tqx_lo,
+                     int32_t tqx_e, int64_t q_rows, float* u, int32_t R, int32_t N, int32_t ncols,
+                     rsp_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* SAM decoder tail / mask post-process                                        */
 /* ------------------------------------------------------------------------ */

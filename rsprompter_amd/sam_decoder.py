@@ -25,6 +25,7 @@ HID = 256          # SamMaskDecoderConfig.hidden_size
 HEADS = 8
 MLP_DIM = 2048
 N_MASK_TOKENS = 4  # num_multimask_outputs + 1
+T2I_FOLD_DEFAULT = False   # set by the round's measurements
 
 
 def _add_linear(root, name, cout, cin):
@@ -81,6 +82,8 @@ class SamMaskDecoderHIP(HIPModule):
         _add_linear(self, 'iou_prediction_head.layers.0', HID, HID)
         _add_linear(self, 'iou_prediction_head.proj_out', N_MASK_TOKENS, HID)
         self._pe_cache = {}
+        # token -> image attention of layer 1 / final with the K | V projections folded in (csrc/t2i_fold.hip)
+        self.t2i_fold = T2I_FOLD_DEFAULT
 
     # ------------------------------------------------------------------ packing
     def _pw(self, name, with_bias=True):
@@ -107,6 +110,8 @@ class SamMaskDecoderHIP(HIPModule):
                        ('final', 'transformer.final_attn_token_to_image')):
             kp, vp = _g(self, p + '.k_proj'), _g(self, p + '.v_proj')
             P[pre + '.kv_proj'] = ops.PackedWeight(torch.cat([kp.weight, vp.weight], 0))
+            # the folded form (csrc/t2i_fold.hip) projects the QUERIES into key space instead: q' = Wk_h^T tq
+            P[pre + '.k_projT'] = ops.PackedWeight(kp.weight.detach().t().contiguous())
         for i in range(N_MASK_TOKENS):
             for l in ('proj_in', 'layers.0', 'proj_out'):
                 P[f'hyper{i}.{l}'] = self._pw(f'output_hypernetworks_mlps.{i}.{l}')
@@ -131,6 +136,7 @@ class SamMaskDecoderHIP(HIPModule):
                 vb = _g(self, p + '.v_proj').bias
                 t[pre + '.kv_proj'] = torch.cat([t[pre + '.k_proj'], vb.unsqueeze(0).expand(pe_rows.shape[0], -1)],
                                                 1).contiguous()
+                t[pre + '.pek_planes'] = ops.to_planes(t[pre + '.k_proj'])       # PEK of the folded token -> image form
             self._pe_cache = {key: t}
         return self._pe_cache[key]
 
@@ -148,6 +154,29 @@ class SamMaskDecoderHIP(HIPModule):
         return ops.attention(tq, kv, kv[:, d2:], ao, B=R, nh=HEADS, dh=dh2, Tq=T, Tk=N, scale=dh2 ** -0.5,
                              q_strides=(T * d2, d2, dh2), k_strides=kvs, v_strides=kvs,
                              o_strides=(T * d2, d2, dh2), kv_batch_map=kv_map)
+
+    def _t2i_folded(self, pre, tq, keys_pl, pe_t, R, T, N):
+        """tokens -> image attention over PER-RoI keys without their K | V projection (csrc/t2i_fold.hip): the queries are
+        projected into key space (q' = Wk_h^T tq, one small GEMM on the block-diagonal tq), the kernel returns
+        sum_n p[n] keys[n] per (head, token) column, v_proj is applied to that -- HF:326-331 / 397-400 re-associated.
+        tq [R*T, 128] projected queries; returns the attention output [R*T, 128] (before out_proj)."""
+        P = self._packed
+        d2, dh2 = HID // 2, (HID // 2) // HEADS
+        dev = tq.device
+        key = ('fold_idx', T, str(dev))
+        if key not in self._pe_cache:
+            cols = torch.arange(HEADS * T, device=dev)
+            self._pe_cache[key] = (cols, cols // T)                # column h * T + t belongs to head h
+        cols, head = self._pe_cache[key]
+        tqs = (tq.view(R, T, HEADS, dh2) * dh2 ** -0.5).permute(0, 2, 1, 3).reshape(R, HEADS * T, dh2)
+        exp = torch.zeros((R, 96, HEADS, dh2), dtype=torch.float32, device=dev)
+        exp[:, cols, head] = tqs                                    # block diagonal: own head's 16 columns, zeros elsewhere
+        tqx = ops.to_planes(exp.view(R * 96, d2))
+        qp = ops.gemm(tqx, P[pre + '.k_projT'], bias=None, out_planes=True, out_f32=False)      # [R*96, 256] planes
+        u = ops.sam_t2i_fold(keys_pl, pe_t[pre + '.pek_planes'], qp, tqx, R=R, N=N, ncols=HEADS * T)
+        full = ops.gemm(u, P[pre + '.v_proj'])                      # [R*96, 128]: every head's Wv on every column
+        ao = full.view(R, 96, HEADS, dh2)[:, cols, head]            # keep the column's own head: [R, 8 T, 16]
+        return ao.view(R, HEADS, T, dh2).permute(0, 2, 1, 3).reshape(R * T, d2).contiguous()
 
     def _i2t(self, qi, kt, vt, ai, R, T, N, q_map=None):
         """image -> tokens attention; the result feeds the out_proj GEMM as planes (HF:340-345)."""
@@ -262,9 +291,14 @@ class SamMaskDecoderHIP(HIPModule):
         q = self._ln(q, 'transformer.layers.1.layer_norm1')
         qpe = ops.add_rows(q, tokens0)
         tq = ops.gemm(qpe, P['1.cross_attn_token_to_image.q_proj'])
-        kv = ops.gemm(keys_pl, P['1.cross_attn_token_to_image.kv_proj'], bias=None,
-                      res=pe_t['1.cross_attn_token_to_image.kv_proj'], res_mod=N)
-        self._t2i(tq, kv, ao, R, T, N)
+        fold = self.t2i_fold and T <= ops.SAM_T2I_FOLD_MAX_TOKENS and N % 32 == 0
+        kv = None
+        if fold:
+            ao = self._t2i_folded('1.cross_attn_token_to_image', tq, keys_pl, pe_t, R, T, N)
+        else:
+            kv = ops.gemm(keys_pl, P['1.cross_attn_token_to_image.kv_proj'], bias=None,
+                          res=pe_t['1.cross_attn_token_to_image.kv_proj'], res_mod=N)
+            self._t2i(tq, kv, ao, R, T, N)
         q = ops.gemm(ao, P['1.cross_attn_token_to_image.out_proj'], res=q)
         q = self._ln(q, 'transformer.layers.1.layer_norm2')
         hmid = ops.gemm(q, P['1.lin1'], act=ops.ACT_RELU)
@@ -289,8 +323,11 @@ class SamMaskDecoderHIP(HIPModule):
         # ---------------- final token -> image attention (HF:396-404; LayerNorm default eps 1e-5) ----
         qpe = ops.add_rows(q, tokens0)
         tq = ops.gemm(qpe, P['final.q_proj'])
-        kv = ops.gemm(keys_pl, P['final.kv_proj'], bias=None, res=pe_t['final.kv_proj'], res_mod=N, out=kv)
-        self._t2i(tq, kv, ao, R, T, N)
+        if fold:
+            ao = self._t2i_folded('final', tq, keys_pl, pe_t, R, T, N)
+        else:
+            kv = ops.gemm(keys_pl, P['final.kv_proj'], bias=None, res=pe_t['final.kv_proj'], res_mod=N, out=kv)
+            self._t2i(tq, kv, ao, R, T, N)
         q = ops.gemm(ao, P['final.out_proj'], res=q)
         q = self._ln(q, 'transformer.layer_norm_final_attn', eps=1e-5)
         del kv, qi, ai

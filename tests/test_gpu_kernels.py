@@ -820,3 +820,39 @@ def test_sam_i2t_fused_matches_composition(dev, T, N, planes_res, form):
     with pytest.raises(RuntimeError):
         ops.sam_i2t_fused(*[t.to(dev) for t in (q, torch.randn(R * 11, 128), torch.randn(R * 11, 128), wo, bo, gamma, beta)],
                           R=R, T=11, N=N, scale=scale, res=torch.zeros(R * N, 256, device=dev))
+
+
+@pytest.mark.parametrize('R,N,T', [(3, 64, 10), (2, 256, 7), (1, 96, 12)])
+def test_sam_t2i_fold_matches_fp64_attention(dev, R, N, T):
+    """token -> image attention with the K | V projections of the per-RoI keys folded into the kernel
+    (csrc/t2i_fold.hip; SamMaskDecoderHIP._t2i_folded): q' = Wk_h^T tq, scores over the key planes + the PEK term, softmax,
+    sum_n p keys[n], v_proj afterwards -- against the fp64 statement of HF:326-331 (k = k_proj(keys + pe), v = v_proj(keys),
+    8 heads x 16, scale 16^-0.5) and against the unfolded kernels on the same planes."""
+    from rsprompter_amd import ops
+    from rsprompter_amd.sam_decoder import SamMaskDecoderHIP
+    from rsprompter_amd.synth import synth_state_dict
+    dec = SamMaskDecoderHIP()
+    dec.load_state_dict(synth_state_dict(dec, 21))
+    dec = dec.to(dev)
+    dec._pack()
+    g = torch.Generator().manual_seed(R * 1000 + N + T)
+    keys = torch.randn(R * N, 256, generator=g) * 1.5
+    pe = torch.randn(N, 256, generator=g)
+    tq = torch.randn(R * T, 128, generator=g) * 2.0
+    at = dec.transformer.final_attn_token_to_image
+    Wk, bk, Wv, bv = (t.detach().double().cpu() for t in (at.k_proj.weight, at.k_proj.bias, at.v_proj.weight, at.v_proj.bias))
+    K = ((keys.view(R, N, 256) + pe[None]).double() @ Wk.t() + bk).view(R, N, 8, 16).permute(0, 2, 1, 3)
+    V = (keys.view(R, N, 256).double() @ Wv.t() + bv).view(R, N, 8, 16).permute(0, 2, 1, 3)
+    Q = tq.double().view(R, T, 8, 16).permute(0, 2, 1, 3)
+    ref = (((Q * 0.25) @ K.transpose(-1, -2)).softmax(-1) @ V).permute(0, 2, 1, 3).reshape(R * T, 128)
+    keys_pl = ops.to_planes(keys.to(dev))
+    pe_t = dec._pe_terms(pe.to(dev).contiguous())
+    got = dec._t2i_folded('final', tq.to(dev), keys_pl, pe_t, R, T, N)
+    e_fold = float((got.cpu().double() - ref).abs().max())
+    # the unfolded kernels on the same planes
+    kv = ops.gemm(keys_pl, dec._packed['final.kv_proj'], bias=None, res=pe_t['final.kv_proj'], res_mod=N)
+    ao = torch.empty((R * T, 128), dtype=torch.float32, device=dev)
+    dec._t2i(tq.to(dev), kv, ao, R, T, N)
+    e_unf = float((ao.cpu().double() - ref).abs().max())
+    print(f't2i fold R={R} N={N} T={T}: folded err {e_fold:.2e}, unfolded err {e_unf:.2e} (max |ref| {float(ref.abs().max()):.2f})')
+    assert e_fold < 2e-5 and e_unf < 2e-5
