@@ -321,6 +321,9 @@ def main():
     ap.add_argument('--f8corr', action='store_true',
                     help='opt-in fast mode: encoder GEMMs as fp16 hi.hi + one fp8 correction MFMA (DESIGN.md section 3); '
                          'NOT the headline configuration -- parity margins are 8x smaller')
+    ap.add_argument('--t2i-fold', dest='t2i_fold', choices=['on', 'off'], default=None,
+                    help='token -> image attention of the SAM decoder with the K | V projections folded in '
+                         '(csrc/t2i_fold.hip); default: the library default (rsprompter_amd.sam_decoder.T2I_FOLD_DEFAULT)')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -344,6 +347,9 @@ def main():
     from rsprompter_amd import ops
     if args.f8corr:
         ops.F8_CORR = True
+    if args.t2i_fold is not None:
+        import rsprompter_amd.sam_decoder as _sd
+        _sd.T2I_FOLD_DEFAULT = args.t2i_fold == 'on'
     from rsprompter_amd.structures import DetDataSample
     from rsprompter_amd.synth import synth_images, synth_metas
     import torch.distributed as tdist

@@ -465,6 +465,47 @@ def test_anchor_mask_head_multimask_output(dev):
     assert e_m < LOGIT_TOL and e_i < LOGIT_TOL
 
 
+@pytest.mark.parametrize('hw', [16, 64])
+def test_anchor_mask_head_with_folded_token_to_image_attention(dev, hw):
+    """SamMaskDecoderHIP with the token -> image attentions of layer 1 and the final layer in their FOLDED form
+    (csrc/t2i_fold.hip: no K | V projection of the per-RoI keys) against the HF decoder fed the same prompts, and against
+    the unfolded HIP path; RoIs of two images, hw x hw embeddings (64 = the shipped size: 4096 keys per RoI)."""
+    from oracle import hf_sam
+    from rsprompter_amd.registry import MODELS
+    from rsprompter_amd.synth import synth_state_dict
+    head = MODELS.build(dict(type='RSPrompterAnchorMaskHead', mask_decoder=dict(type='RSSamMaskDecoder', hf_pretrain_name='sam_vit_base'),
+                             in_channels=256, roi_feat_size=14, per_pointset_point=5, with_sincos=True, multimask_output=False,
+                             class_agnostic=True))
+    sd = synth_state_dict(head, 3)
+    head.load_state_dict(sd)
+    head = head.to(dev)
+    dec = hf_sam.build_mask_decoder()
+    dec.load_state_dict({k[len('mask_decoder.mask_decoder.'):]: v for k, v in sd.items() if k.startswith('mask_decoder.mask_decoder.')})
+    g = torch.Generator().manual_seed(1)
+    R, B = 5, 2
+    x = torch.randn(R, 256, 14, 14, generator=g)
+    emb = torch.randn(B, 256, hw, hw, generator=g)
+    ipe = torch.randn(1, 256, hw, hw, generator=g).expand(B, -1, -1, -1).contiguous()
+    roi_img = torch.tensor([0, 0, 1, 1, 1])
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    hip = head.mask_decoder.mask_decoder
+    hip.t2i_fold = False
+    low0, iou0 = head(cl(x), cl(emb), cl(ipe), roi_img.to(dev))
+    hip.t2i_fold = True
+    low1, iou1 = head(cl(x), cl(emb), cl(ipe), roi_img.to(dev))
+    sparse = head.point_embeddings(cl(x)).cpu()
+    with torch.no_grad():
+        ref_m, ref_i = dec(image_embeddings=emb[roi_img], image_positional_embeddings=ipe[roi_img],
+                           sparse_prompt_embeddings=sparse.unsqueeze(1),
+                           dense_prompt_embeddings=sd['no_mask_embed.weight'].reshape(1, -1, 1, 1).expand(R, -1, hw, hw),
+                           multimask_output=False)[:2]
+    ref_m = ref_m.reshape(R, 1, 4 * hw, 4 * hw)
+    e0, e1, d01 = _maxerr(low0, ref_m), _maxerr(low1, ref_m), _maxerr(low0, low1)
+    print(f'mask decoder {hw}x{hw}: unfolded vs HF {e0:.2e}, folded vs HF {e1:.2e}, folded vs unfolded {d01:.2e} '
+          f'(range {float(ref_m.abs().max()):.1f}); iou {_maxerr(iou1, ref_i.reshape(R, 1)):.2e}')
+    assert e0 < LOGIT_TOL and e1 < LOGIT_TOL and _maxerr(iou1, ref_i.reshape(R, 1)) < LOGIT_TOL
+
+
 def test_encoder_batch8_row_maps(dev):
     """window partition / unpartition row maps with B = 8 (the bench batch): every image of the batch must equal the
     oracle's single-image forward of that image (HF:900-952; images are independent)."""

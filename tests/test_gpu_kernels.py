@@ -822,7 +822,7 @@ def test_sam_i2t_fused_matches_composition(dev, T, N, planes_res, form):
                           R=R, T=11, N=N, scale=scale, res=torch.zeros(R * N, 256, device=dev))
 
 
-@pytest.mark.parametrize('R,N,T', [(3, 64, 10), (2, 256, 7), (1, 96, 12)])
+@pytest.mark.parametrize('R,N,T', [(3, 64, 10), (2, 256, 7), (1, 96, 12), (2, 64, 3)])
 def test_sam_t2i_fold_matches_fp64_attention(dev, R, N, T):
     """token -> image attention with the K | V projections of the per-RoI keys folded into the kernel
     (csrc/t2i_fold.hip; SamMaskDecoderHIP._t2i_folded): q' = Wk_h^T tq, scores over the key planes + the PEK term, softmax,

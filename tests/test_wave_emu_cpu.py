@@ -84,3 +84,15 @@ def test_emu_msdeform_attn_level_counts(emu):
     t.test_msdeform_attn_level_counts(DEV, [(4, 4), (8, 6)], 128)
     t.test_msdeform_attn_level_counts(DEV, [(3, 3), (4, 6), (8, 8), (16, 12)], 128)
     t.test_msdeform_attn_level_counts(DEV, [(2, 2), (3, 3), (4, 4), (6, 6), (8, 8)], 256)
+
+
+def test_emu_folded_token_to_image_attention(emu):
+    """csrc/t2i_fold.hip (a kernel written and debugged on this emulator before it saw a GPU): both head-count
+    instantiations against fp64 and the unfolded kernels, then the whole SAM mask decoder -- token attention, folded
+    token -> image attention, the matrix-core image -> token block, ConvTranspose GEMMs with their LayerNorm epilogue, the
+    upscale tail -- against the HuggingFace decoder on 16 x 16 embeddings"""
+    import test_gpu_baseline_configs as tb
+    import test_gpu_kernels as tk
+    tk.test_sam_t2i_fold_matches_fp64_attention(DEV, 3, 64, 10)
+    tk.test_sam_t2i_fold_matches_fp64_attention(DEV, 2, 64, 3)
+    tb.test_anchor_mask_head_with_folded_token_to_image_attention(DEV, 16)

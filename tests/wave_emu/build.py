@@ -102,7 +102,9 @@ def build(sources=None, verbose=False):
             sys.stderr.write(f'--- {cpp}\n{out[:6000]}\n')
     if failed:
         raise RuntimeError('wave_emu build failed')
-    cmd = [CLANG, '-shared', '-fPIC', '-o', lib + '.tmp'] + [o for _, o in objs]
+    # -Bsymbolic: the library's references to hipGetLastError, hipLaunch... bind to ITS OWN (inline) definitions even when
+    # the real HIP runtime is already in the process (librsp_hip.so loads it with RTLD_GLOBAL in the same test session)
+    cmd = [CLANG, '-shared', '-fPIC', '-Wl,-Bsymbolic', '-o', lib + '.tmp'] + [o for _, o in objs]
     subprocess.check_call(cmd)
     os.replace(lib + '.tmp', lib)
     open(stamp, 'w').write(h.hexdigest())
