@@ -25,7 +25,11 @@ HID = 256          # SamMaskDecoderConfig.hidden_size
 HEADS = 8
 MLP_DIM = 2048
 N_MASK_TOKENS = 4  # num_multimask_outputs + 1
-T2I_FOLD_DEFAULT = __import__('os').environ.get('RSP_T2I_FOLD', '0') == '1'   # measurement switch of round 4
+# The folded form of the layer-1 / final token -> image attention (csrc/t2i_fold.hip).  Round 4 measured it on the bench
+# fixture (ViT-H, 800 RoIs): 167.1 ms per step folded vs 168.1 projected on the same box, mask logits / detections equal;
+# the kernel itself needs 2.2 ms per call where its matrix work would allow ~1: it stays OPT-IN (this flag, or
+# `decoder.t2i_fold = True`, or `bench.py --t2i-fold on`) until it has been tuned and the whole GPU suite has run with it.
+T2I_FOLD_DEFAULT = __import__('os').environ.get('RSP_T2I_FOLD', '0') == '1'
 
 
 def _add_linear(root, name, cout, cin):
@@ -291,7 +295,8 @@ class SamMaskDecoderHIP(HIPModule):
         q = self._ln(q, 'transformer.layers.1.layer_norm1')
         qpe = ops.add_rows(q, tokens0)
         tq = ops.gemm(qpe, P['1.cross_attn_token_to_image.q_proj'])
-        fold = self.t2i_fold and T <= ops.SAM_T2I_FOLD_MAX_TOKENS and N % 32 == 0
+        # (the kernel addresses a key plane with 32-bit byte offsets: R * N * 512 < 2^31, i.e. 1023 RoIs at N = 4096)
+        fold = self.t2i_fold and T <= ops.SAM_T2I_FOLD_MAX_TOKENS and N % 32 == 0 and R * N * 512 < 2 ** 31
         kv = None
         if fold:
             ao = self._t2i_folded('1.cross_attn_token_to_image', tq, keys_pl, pe_t, R, T, N)
