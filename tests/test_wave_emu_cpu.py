@@ -96,3 +96,41 @@ def test_emu_folded_token_to_image_attention(emu):
     tk.test_sam_t2i_fold_matches_fp64_attention(DEV, 3, 64, 10)
     tk.test_sam_t2i_fold_matches_fp64_attention(DEV, 2, 64, 3)
     tb.test_anchor_mask_head_with_folded_token_to_image_attention(DEV, 16)
+
+
+# (module, test function, arguments after `dev`): bodies of the `-m gpu` suite that take about a second each on the emulator
+SWEEP = [
+    ('test_gpu_kernels', 'test_patchify_preprocess', ()),
+    ('test_gpu_kernels', 'test_gemm_conv3x3', (1,)),
+    ('test_gpu_kernels', 'test_gemm_conv3x3', (2,)),
+    ('test_gpu_kernels', 'test_gemm_rowmaps_and_broadcast_residual', ()),
+    ('test_gpu_kernels', 'test_gemm_small_values_precision', ()),
+    ('test_gpu_kernels', 'test_gemm_plane_residual', ()),
+    ('test_gpu_kernels', 'test_gemm_column_range_outputs', ()),
+    ('test_gpu_kernels', 'test_outlier_activations_do_not_poison_the_split', ()),
+    ('test_gpu_kernels', 'test_conv_transpose_pool_add_sincos', ()),
+    ('test_gpu_kernels', 'test_generic_attention_with_batch_maps', (32, 10, 10, 8)),
+    ('test_gpu_kernels', 'test_generic_attention_with_batch_maps', (64, 70, 130, 2)),
+    ('test_gpu_kernels', 'test_sam_cross_attention_kernels', (7,)),
+    ('test_gpu_kernels', 'test_sam_cross_attention_kernels', (10,)),
+    ('test_gpu_kernels', 'test_sam_i2t_fused_matches_composition', (3, 64, False, 'valu')),
+    ('test_gpu_kernels', 'test_sam_i2t_fused_matches_composition', (3, 64, False, 'mfma')),
+    ('test_gpu_kernels', 'test_sam_i2t_fused_matches_composition', (7, 520, True, 'mfma')),
+    ('test_gpu_kernels', 'test_roi_align_matches_oracle', ()),
+    ('test_gpu_kernels', 'test_mask_post_matches_reference_formula', ()),
+    ('test_gpu_kernels', 'test_hyper_mask', ()),
+    ('test_gpu_kernels', 'test_batched_nms_matches_oracle', (5000, 5, 0.7, 1000)),
+    ('test_gpu_query', 'test_query_kernels_unit', ()),
+    ('test_gpu_samdet', 'test_bbox_post_matches_real_bbox_head_with_and_without_rescale', ()),
+    ('test_gpu_samdet', 'test_resnet_leaf_kernels', ()),
+    ('test_gpu_samseg', 'test_paste_masks_kernel_matches_reference_vectors', ()),
+]
+
+
+@pytest.mark.parametrize('mod,fn,args', SWEEP, ids=[f'{f}{list(a) if a else ""}' for _, f, a in SWEEP])
+def test_emu_sweep_of_gpu_test_bodies(emu, mod, fn, args):
+    """the fp32 / plane GEMM kernels with their loaders and epilogues (row maps, implicit-GEMM convs, ConvTranspose modes,
+    plane residuals, column ranges), generic and SAM-decoder attentions, the matrix-core image -> token block, RoIAlign,
+    mask post-processing, NMS, GroupNorm / resize / masked attention of the query path, ResNet leaves, mask paste"""
+    import importlib
+    getattr(importlib.import_module(mod), fn)(DEV, *args)
