@@ -134,3 +134,24 @@ def test_emu_sweep_of_gpu_test_bodies(emu, mod, fn, args):
     mask post-processing, NMS, GroupNorm / resize / masked attention of the query path, ResNet leaves, mask paste"""
     import importlib
     getattr(importlib.import_module(mod), fn)(DEV, *args)
+
+
+def test_emu_dma_kernels_with_latest_possible_completion(emu):
+    """The DMA engine at its other extreme: LDS is written only when an `s_waitcnt vmcnt(n)` of the issuing wave demands it
+    (the default mode writes at issue).  The ring kernels -- persistent GEMM (whose waits count the tile-ticket atomic),
+    gemm_f16x3_dma_kernel, window / global attention, the folded attention -- must give the same results: a wait that is
+    too weak, or missing in front of the barrier, reads a stale buffer here.  Self-test first: with the waits ignored the
+    folded attention must come out wrong."""
+    import harness
+    import test_gpu_gemm_s2 as tg
+    import test_gpu_kernels as tk
+    with harness.lazy_dma(ignore_waits=True):
+        with pytest.raises(AssertionError):
+            tk.test_sam_t2i_fold_matches_fp64_attention(DEV, 3, 64, 10)
+    with harness.lazy_dma():
+        tg.test_s2_plain_and_residual(DEV, 300, 64, 128)
+        tg.test_s2_column_ranges_and_row_maps(DEV, 64, 128, 203)
+        tk.test_plane_gemm_tile_variants(DEV, 1)
+        tk.test_vit_window_attention_fused_relpos(DEV, 3, 4, 2, 80, 1, 1)
+        tk.test_vit_attention_planes(DEV, 32, 2, 64, 2)
+        tk.test_sam_t2i_fold_matches_fp64_attention(DEV, 3, 64, 10)

@@ -2,7 +2,8 @@
 emulator (emu_hip.h) -> tests/wave_emu/_build/libemu_rsp.so with the same C entry points as librsp_hip.so.
 
 The sources are not edited; a textual pre-pass over a copy does three things the host compiler needs:
-  * `asm volatile(...)` statements (s_waitcnt / empty optimisation fences only) become empty statements;
+  * `asm volatile(...)` statements: `s_waitcnt vmcnt(n)` becomes the emulator's wait (it drives the lazy-DMA mode), the
+    empty optimisation fences become empty statements;
   * `__builtin_amdgcn_*` becomes `emu_amdgcn_*` (the host clang has no such builtins; emu_hip.h defines the functions);
   * `extern __shared__ T name[];` becomes a pointer to the emulator's dynamic-LDS buffer;
   * `__attribute__((amdgpu_waves_per_eu(..)))` (an occupancy hint) is dropped.
@@ -47,7 +48,15 @@ def strip_asm(src):
             elif c == ')':
                 depth -= 1
             j += 1
-        out.append('((void)0)')
+        text = src[m.end():j - 1]
+        w = re.search(r'"s_waitcnt vmcnt\((%0|\d+)\)"', text)
+        if w and w.group(1) == '%0':                     # asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EXPR) : "memory")
+            e = re.search(r'"n"\((.*)\)\s*:', text, re.S)
+            out.append(f'emu_vmcnt_wait({e.group(1)})')
+        elif w:
+            out.append(f'emu_vmcnt_wait({w.group(1)})')
+        else:
+            out.append('((void)0)')
         i = j
     return ''.join(out)
 
@@ -55,6 +64,7 @@ def strip_asm(src):
 def prepass(text):
     text = strip_asm(text)
     text = text.replace('__builtin_amdgcn_', 'emu_amdgcn_')
+    text = text.replace('__hip_atomic_fetch_add(', 'emu_hip_atomic_fetch_add(')
     text = re.sub(r'__attribute__\(\(amdgpu_waves_per_eu\([^)]*\)\)\)', '', text)
     text = re.sub(r'extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s+)?([A-Za-z_][\w ]*?)\s+(\w+)\[\];',
                   r'\1* \2 = reinterpret_cast<\1*>(emu::dyn_smem());', text)

@@ -5,9 +5,9 @@
 // so that `-m "not gpu"` tests can execute the very code paths the GPU runs -- MFMA fragment layouts, LDS images, the DMA
 // (`buffer_load ... lds`) address rule, the transposing LDS read, buffer-resource bounds, wave shuffles, block barriers,
 // tile tickets -- on tiny shapes, lane by lane, before a GPU minute is spent.  What it does NOT model: timing, bank
-// conflicts, register pressure, asynchrony (DMA and loads complete at issue, so a missing s_waitcnt / barrier is invisible
-// here) and the exact rounding of MFMA accumulation or of v_exp / v_rcp (results agree with the GPU to fp32 round-off, not
-// bit for bit).
+// conflicts, register pressure, the asynchrony of register loads (they complete at issue) and the exact rounding of MFMA accumulation or of v_exp / v_rcp (results agree with the GPU to fp32 round-off, not
+// bit for bit).  Asynchrony of the DMA engine is modelled at its two extremes (State::lazy_dma): LDS is written at issue, or
+// only when an s_waitcnt vmcnt of the wave forces it.
 //
 // Execution model: one fiber per work-item (own stack, hand-written x86-64 context switch), blocks run one after the
 // other, a wave is 64 consecutive fibers.  Cross-lane operations (MFMA, shuffles, ballot, readfirstlane, ds_read_tr,
@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <functional>
 #include <type_traits>
 #include <vector>
@@ -117,7 +118,16 @@ struct Group {
   uint64_t mask;
 };
 
+// a DMA-to-LDS instruction whose data has not been written to LDS yet (lazy mode, see dma_commit)
+struct DmaOp {
+  uint64_t mask;
+  unsigned char* base;
+  int size;
+  unsigned char data[WAVE][16];
+};
+
 struct Wave {
+  std::deque<DmaOp> dmaq;
   int nlanes = 0;                 // lanes that exist (the last wave of a block may be partial)
   int live = 0;                   // lanes that have not returned
   uint64_t live_mask = 0;
@@ -153,11 +163,23 @@ struct State {
   void* sched_sp = nullptr;
   std::vector<char*> stack_pool;
   uint64_t n_switch = 0, n_collective = 0;
+  // 0: a DMA-to-LDS instruction writes LDS when it is issued (the EARLIEST the hardware may do it: exposes a buffer that is
+  // refilled while another wave still reads it); 1: it writes LDS only when an `s_waitcnt vmcnt(n)` of the wave demands it
+  // (the LATEST the hardware may do it: exposes a missing wait in front of the barrier).  Tests run DMA kernels both ways.
+  int lazy_dma = 0;
 };
 extern State g;
 #ifdef EMU_IMPLEMENTATION
 State g;
 #endif
+
+inline void dma_apply(const DmaOp& op) {
+  for (int l = 0; l < WAVE; ++l)
+    if ((op.mask >> l) & 1ull) memcpy(op.base + (size_t)l * op.size, op.data[l], op.size);
+}
+inline void dma_flush(Wave& w, size_t keep) {
+  while (w.dmaq.size() > keep) { dma_apply(w.dmaq.front()); w.dmaq.pop_front(); }
+}
 
 inline void yield_to_scheduler() {
   Fiber* f = g.cur;
@@ -243,6 +265,7 @@ inline void lane_exit() {
   f->done = true;
   --w.live; --b.live;
   w.live_mask &= ~(1ull << f->lane);
+  if (w.live == 0) dma_flush(w, 0);                             // the wave ends: its memory operations complete
   if (w.live > 0) wave_try_fire(w);
   if (b.live > 0 && b.bar_arrived == b.live) {
     b.bar_arrived = 0; ++b.bar_gen;
@@ -284,7 +307,7 @@ void run_launch() {
         for (int w = 0; w < nw; ++w) {
           Wave& W = blk.waves[w];
           W.nlanes = std::min(WAVE, T - w * WAVE);
-          W.live = W.nlanes; W.arrived = 0; W.arrived_mask = 0; W.barrier_mask = 0; W.groups.clear();
+          W.live = W.nlanes; W.arrived = 0; W.arrived_mask = 0; W.barrier_mask = 0; W.groups.clear(); W.dmaq.clear();
           W.live_mask = W.nlanes == 64 ? ~0ull : ((1ull << W.nlanes) - 1);
         }
         for (int i = 0; i < T; ++i) {
@@ -334,6 +357,7 @@ void run_launch() {
 alignas(64) extern unsigned char dyn_smem_buf[160 * 1024];
 #ifdef EMU_IMPLEMENTATION
 alignas(64) unsigned char dyn_smem_buf[160 * 1024];
+extern "C" void emu_set_lazy_dma(int on) { g.lazy_dma = on; }
 #endif
 inline void* dyn_smem() { return dyn_smem_buf; }
 
@@ -386,7 +410,25 @@ inline int64_t max(int a, int64_t b) { return a < b ? b : a; }
 inline void __syncthreads() { emu::block_barrier(); }
 inline void emu_amdgcn_s_barrier() { emu::block_barrier(); }
 inline void emu_amdgcn_sched_barrier(int) {}
-inline void emu_amdgcn_s_waitcnt(int) {}
+// s_waitcnt vmcnt(n): at most n of the wave's vector-memory operations stay outstanding.  Only DMA-to-LDS operations are
+// tracked (register loads complete at issue here), i.e. the count is the WEAKEST the hardware could apply: interleaved
+// loads / stores only make the real wait stronger (vmcnt retires in order).
+// (lazy_dma == 2 ignores the waits -- the emulator's self-test that a kernel WITHOUT its waits is caught in mode 1)
+inline void emu_vmcnt_wait(int n) { if (emu::g.lazy_dma != 2) emu::dma_flush(*emu::cur().wave, (size_t)(n < 0 ? 0 : n)); }
+// A returning global atomic is a vector-memory operation of the wave: it takes a place in the vmcnt order (the persistent
+// GEMM counts its tile-ticket atomic into its waits: "vmcnt(NDMA + 1)").  build.py routes __hip_atomic_fetch_add here.
+template <class T, class U>
+inline T emu_hip_atomic_fetch_add(T* p, U v, int order, int scope) {
+  const T old = __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, 4 /* agent scope */);
+  if (emu::g.lazy_dma) {
+    emu::DmaOp op;
+    op.mask = 0; op.base = nullptr; op.size = 0;
+    emu::cur().wave->dmaq.push_back(op);
+  }
+  return old;
+}
+// gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt_hi[15:14]
+inline void emu_amdgcn_s_waitcnt(int imm) { emu_vmcnt_wait((imm & 15) | (((imm >> 14) & 3) << 4)); }
 inline void emu_amdgcn_s_setprio(int) {}
 #define emu_amdgcn_fence(...) ((void)0)
 inline uint64_t emu_amdgcn_s_memtime() { return emu::g.n_switch; }
@@ -632,12 +674,16 @@ inline void dma_commit(const void* src16, void* lds, int size, const void* site)
   wave_rendezvous([](Wave& W) {
     const int first = __builtin_ctzll(W.arrived_mask);
     unsigned char* base = arg_at<DmaArg>(W, first).lds;
+    DmaOp op;
+    op.mask = W.arrived_mask; op.base = base; op.size = arg_at<DmaArg>(W, first).size;
     for (int l = 0; l < WAVE; ++l) {
       if (!lane_in(W, l)) continue;
       const DmaArg& a = arg_at<DmaArg>(W, l);
       if (a.lds != base) die("DMA to LDS with a lane-varying LDS base (M0 is wave-uniform)");
-      memcpy(base + (size_t)l * a.size, a.data, a.size);
+      memcpy(op.data[l], a.data, 16);
     }
+    if (g.lazy_dma) W.dmaq.push_back(op);
+    else dma_apply(op);
   }, OP_DMA, site);
 }
 }  // namespace emu

@@ -23,8 +23,22 @@ def load_emu():
         for name, (res, args) in _lib.PROTOTYPES.items():
             fn = getattr(lib, name)        # every symbol of include/rsp_hip.h must exist in the emulated build too
             fn.restype, fn.argtypes = res, args
+        lib.emu_set_lazy_dma.argtypes = [ctypes.c_int]
         _EMU = lib
     return _EMU
+
+
+@contextlib.contextmanager
+def lazy_dma(ignore_waits=False):
+    """inside: a DMA-to-LDS instruction writes LDS only when an `s_waitcnt vmcnt` of its wave forces it (the latest the
+    hardware may), so a wait that is missing in front of a barrier shows as a wrong result.  ignore_waits=True drops every
+    wait on top (self-test: such a kernel must FAIL)"""
+    lib = load_emu()
+    lib.emu_set_lazy_dma(2 if ignore_waits else 1)
+    try:
+        yield
+    finally:
+        lib.emu_set_lazy_dma(0)
 
 
 @contextlib.contextmanager
