@@ -366,6 +366,7 @@ int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo, int64_t k
                      const uint16_t* pek_hi, const uint16_t* pek_lo, int32_t pek_e, const uint16_t* qp_hi,
                      const uint16_t* qp_lo, int32_t qp_e, const uint16_t* tqx_hi, const uint16_t* tqx_lo,
                      int32_t tqx_e, int64_t q_rows, float* u, int32_t R, int32_t N, int32_t ncols,
+                     int32_t variant /* 0 = the form measured in round 4; 1 = DMA issue spread between the MFMAs (unmeasured) */,
                      rsp_stream_t stream);
 
 /* ------------------------------------------------------------------------ */

@@ -76,7 +76,7 @@ struct T2iFoldP {
 };
 
 // NPE: heads whose PEK term a wave evaluates (its 32 columns h * T + t touch at most 5 heads when T >= 7, else all 8)
-template <int NPE>
+template <int NPE, bool SPREAD>
 __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[FNBUF][FBUF_BYTES];
   __shared__ __attribute__((aligned(1024))) unsigned char sQl[FNW * 16 * 1024];      // q' lo fragments: [wave][k-step][lane] x 16 B
@@ -108,19 +108,16 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
     voff_p[i] = (row < FKT && pc < 16) ? (unsigned)(((int64_t)(pc >> 2) * N + row) * 64 + (pc & 3) * 16) : F_OOB;
   }
   const unsigned so_k0 = (unsigned)((int64_t)r * N * 64);  // first key row of the RoI (bytes inside a 32-column block)
-  auto issue_tile = [&](int kt, int buf) {
-    unsigned char* lbase = &smem[buf][0];
+  auto issue_slot = [&](auto ic, int kt, int buf) {        // DMA instruction i of tile kt
+    constexpr int i = decltype(ic)::value;
     const unsigned so_k = so_k0 + (unsigned)kt * (FKT * 64), so_p = (unsigned)kt * (FKT * 64);
-    static_for_f<0, FNDMA>([&](auto ic) {
-      constexpr int i = decltype(ic)::value;
-      lptr_f l = (lptr_f)(lbase + (i * FNT + wave * 64) * 16);
-      if constexpr (i < 6) __builtin_amdgcn_raw_ptr_buffer_load_lds(rKh, l, 16, (int)voff_k[i], (int)so_k, 0, 0);
-      else if constexpr (i < 12) __builtin_amdgcn_raw_ptr_buffer_load_lds(rKl, l, 16, (int)voff_k[i - 6], (int)so_k, 0, 0);
-      else if constexpr (i < 15) __builtin_amdgcn_raw_ptr_buffer_load_lds(rPh, l, 16, (int)voff_p[i - 12], (int)so_p, 0, 0);
-      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rPl, l, 16, (int)voff_p[i - 15], (int)so_p, 0, 0);
-    });
+    lptr_f l = (lptr_f)(&smem[buf][0] + (i * FNT + wave * 64) * 16);
+    if constexpr (i < 6) __builtin_amdgcn_raw_ptr_buffer_load_lds(rKh, l, 16, (int)voff_k[i], (int)so_k, 0, 0);
+    else if constexpr (i < 12) __builtin_amdgcn_raw_ptr_buffer_load_lds(rKl, l, 16, (int)voff_k[i - 6], (int)so_k, 0, 0);
+    else if constexpr (i < 15) __builtin_amdgcn_raw_ptr_buffer_load_lds(rPh, l, 16, (int)voff_p[i - 12], (int)so_p, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rPl, l, 16, (int)voff_p[i - 15], (int)so_p, 0, 0);
   };
-  issue_tile(0, 0);
+  static_for_f<0, FNDMA>([&](auto ic) { issue_slot(ic, 0, 0); });
 
   // ---- B operands of this lane's column for the whole RoI: q' (16 k-steps; lo halves parked in the lane's own LDS
   // slots: written and read by the same lane) and the block-diagonal tq of heads hb .. hb + NPE - 1 ----
@@ -163,7 +160,13 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
     const int buf = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of tile kt has landed
     __builtin_amdgcn_s_barrier();                         // ... everybody's; the other buffer has been read
-    if (kt + 1 < nt) issue_tile(kt + 1, buf ^ 1);
+    // the 18 DMA instructions of tile kt + 1 (into the buffer everybody has just left) are issued one per k-step BETWEEN
+    // the score MFMAs below (SPREAD), not as a burst here: a `buffer_load ... lds` occupies the issue port for 60+ cycles,
+    // with one wave per SIMD nothing else would run meanwhile
+    const bool has_next = kt + 1 < nt;
+    if constexpr (!SPREAD) {
+      if (has_next) static_for_f<0, FNDMA>([&](auto ic) { issue_slot(ic, kt + 1, buf ^ 1); });
+    }
     const unsigned char* sb = &smem[buf][0];
     const unsigned char* sK0 = sb;
     const unsigned char* sK1 = sb + FK_UNITS * 16;
@@ -212,6 +215,10 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
           sp = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], th[i - 16], sp, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (SPREAD && i < FNDMA) {
+          if (has_next) issue_slot(ic, kt + 1, buf ^ 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       });
     }
 
@@ -300,10 +307,10 @@ extern "C" int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo
                                 const uint16_t* pek_hi, const uint16_t* pek_lo, int32_t pek_e, const uint16_t* qp_hi,
                                 const uint16_t* qp_lo, int32_t qp_e, const uint16_t* tqx_hi, const uint16_t* tqx_lo,
                                 int32_t tqx_e, int64_t q_rows, float* u, int32_t R, int32_t N, int32_t ncols,
-                                rsp_stream_t stream) {
+                                int32_t variant, rsp_stream_t stream) {
   if (!keys_hi || !keys_lo || !pek_hi || !pek_lo || !qp_hi || !qp_lo || !tqx_hi || !tqx_lo || !u || R < 0 || N <= 0 ||
       (N % FKT) || ncols <= 0 || ncols > 96 || (ncols & 7) || k_rows < (int64_t)R * N || q_rows < (int64_t)R * 96 ||
-      k_rows * 512 > 0x7fffffffLL || (int64_t)N * 256 > 0x7fffffffLL)
+      k_rows * 512 > 0x7fffffffLL || (int64_t)N * 256 > 0x7fffffffLL || variant < 0 || variant > 1)
     return RSP_EINVAL;
   if (R == 0) return RSP_OK;
   T2iFoldP p;
@@ -317,8 +324,17 @@ extern "C" int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo
   p.c_pe = ldexpf(1.0f, -(pek_e + tqx_e)) * LOG2E_F;
   p.u_unscale = ldexpf(1.0f, -keys_e);                   // (the 2^14 of the probabilities cancels against their sum)
   // columns are ordered h * T + t: 32 consecutive ones touch at most 5 heads when T >= 7
-  if ((ncols & 7) == 0 && ncols >= 56) hipLaunchKernelGGL(sam_t2i_fold_kernel<5>, dim3(R), dim3(FNT), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(sam_t2i_fold_kernel<8>, dim3(R), dim3(FNT), 0, (hipStream_t)stream, p);
+  // variant 0: the DMA instructions of the next tile as a burst behind the barrier -- the form that ran on the MI355X in
+  // round 4 (2.2 ms per call at R = 800); variant 1: one per k-step between the score MFMAs (verified on the emulator
+  // only; a candidate for the next round's measurements)
+  const bool five = ncols >= 56;
+  if (variant == 0) {
+    if (five) hipLaunchKernelGGL((sam_t2i_fold_kernel<5, false>), dim3(R), dim3(FNT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((sam_t2i_fold_kernel<8, false>), dim3(R), dim3(FNT), 0, (hipStream_t)stream, p);
+  } else {
+    if (five) hipLaunchKernelGGL((sam_t2i_fold_kernel<5, true>), dim3(R), dim3(FNT), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((sam_t2i_fold_kernel<8, true>), dim3(R), dim3(FNT), 0, (hipStream_t)stream, p);
+  }
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }

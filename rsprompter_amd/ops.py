@@ -770,7 +770,7 @@ def sam_t2i_attention(q, kv, out, *, R, T, N, scale, kv_map=None):
 SAM_T2I_FOLD_MAX_TOKENS = 12    # 8 heads x T query columns fit the kernel's 96
 
 
-def sam_t2i_fold(keys, pek, qp, tqx, *, R, N, ncols):
+def sam_t2i_fold(keys, pek, qp, tqx, *, R, N, ncols, variant=0):
     """token -> image attention over the per-RoI key planes with the K | V projections folded in (csrc/t2i_fold.hip):
     keys Planes [R*N, 256]; pek Planes [N, 128] = k_proj(pe) + bias; qp Planes [R*96, 256] and tqx Planes [R*96, 128] (see
     rsp_sam_t2i_fold).  Returns u fp32 [R*96, 256] = sum_n softmax[n] keys[n] per (RoI, column); the rows of the columns
@@ -782,12 +782,12 @@ def sam_t2i_fold(keys, pek, qp, tqx, *, R, N, ncols):
     if qp.rows != tqx.rows or qp.rows < R * 96 or keys.rows < R * N or pek.rows != N:
         raise ValueError('sam_t2i_fold: row counts')
     u = torch.zeros((R * 96, 256), dtype=torch.float32, device=keys.device)
-    _timed('sam_t2i_fold_kernel', 2.0 * R * N * 96 * (256 + 128 + 256), 4.0 * R * N * 256,
+    _timed('sam_t2i_fold_kernel' + ('<spread>' if variant else ''), 2.0 * R * N * 96 * (256 + 128 + 256), 4.0 * R * N * 256,
            lambda: _lib.check(lib.rsp_sam_t2i_fold(keys.hi.data_ptr(), keys.lo.data_ptr(), keys.rows, keys.scale_log2,
                                                    pek.hi.data_ptr(), pek.lo.data_ptr(), pek.scale_log2,
                                                    qp.hi.data_ptr(), qp.lo.data_ptr(), qp.scale_log2,
                                                    tqx.hi.data_ptr(), tqx.lo.data_ptr(), tqx.scale_log2, qp.rows,
-                                                   u.data_ptr(), R, N, ncols, _stream()), "rsp_sam_t2i_fold"))
+                                                   u.data_ptr(), R, N, ncols, variant, _stream()), "rsp_sam_t2i_fold"))
     return u
 
 

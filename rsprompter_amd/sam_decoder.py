@@ -88,6 +88,7 @@ class SamMaskDecoderHIP(HIPModule):
         self._pe_cache = {}
         # token -> image attention of layer 1 / final with the K | V projections folded in (csrc/t2i_fold.hip)
         self.t2i_fold = T2I_FOLD_DEFAULT
+        self.t2i_fold_variant = 0          # rsp_sam_t2i_fold `variant`
 
     # ------------------------------------------------------------------ packing
     def _pw(self, name, with_bias=True):
@@ -177,7 +178,8 @@ class SamMaskDecoderHIP(HIPModule):
         exp[:, cols, head] = tqs                                    # block diagonal: own head's 16 columns, zeros elsewhere
         tqx = ops.to_planes(exp.view(R * 96, d2))
         qp = ops.gemm(tqx, P[pre + '.k_projT'], bias=None, out_planes=True, out_f32=False)      # [R*96, 256] planes
-        u = ops.sam_t2i_fold(keys_pl, pe_t[pre + '.pek_planes'], qp, tqx, R=R, N=N, ncols=HEADS * T)
+        u = ops.sam_t2i_fold(keys_pl, pe_t[pre + '.pek_planes'], qp, tqx, R=R, N=N, ncols=HEADS * T,
+                             variant=self.t2i_fold_variant)
         full = ops.gemm(u, P[pre + '.v_proj'])                      # [R*96, 128]: every head's Wv on every column
         ao = full.view(R, 96, HEADS, dh2)[:, cols, head]            # keep the column's own head: [R, 8 T, 16]
         return ao.view(R, HEADS, T, dh2).permute(0, 2, 1, 3).reshape(R * T, d2).contiguous()
