@@ -369,6 +369,17 @@ int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo, int64_t k
                      int32_t variant /* 0 = the form measured in round 4; 1 = DMA issue spread between the MFMAs (unmeasured) */,
                      rsp_stream_t stream);
 
+/* The upscaler tail of the SAM mask decoder in one pass over the per-RoI keys (HF:513-531; csrc/upscale.hip,          */
+/* sam_upscale_fused_kernel): ConvTranspose2d(256 -> 64, k2 s2) + LayerNorm2d(64) + GELU + ConvTranspose2d(64 -> 32) + GELU */
+/* + <., hyper_in>.  x: planes of [x_rows >= rows, 256] (rows = R*h*w, rows_per_roi = h*w, W = w); w1: planes of the packed  */
+/* weight [(dy, dx, co), 256], bias1 [256] (tiled x4); w2: planes of [(dy2, dx2, c2), 64] with its K columns in the order    */
+/* k' = 16 s + 8 hh + j <- channel 32 (s >> 1) + 8 ((8 (s & 1) + j) >> 2) + 4 hh + (j & 3), bias2 [128]; out [R, 4h, 4w].   */
+int rsp_sam_upscale_fused(const uint16_t* x_hi, const uint16_t* x_lo, int64_t x_rows, int32_t x_scale_log2,
+                          const uint16_t* w1_hi, const uint16_t* w1_lo, int32_t w1_scale_log2, const float* bias1,
+                          const float* gamma, const float* beta, float eps, const uint16_t* w2_hi,
+                          const uint16_t* w2_lo, int32_t w2_scale_log2, const float* bias2, const float* hyper,
+                          float* out, int64_t rows, int32_t rows_per_roi, int32_t W, rsp_stream_t stream);
+
 /* ------------------------------------------------------------------------ */
 /* SAM decoder tail / mask post-process                                        */
 /* ------------------------------------------------------------------------ */

@@ -143,6 +143,9 @@ PROTOTYPES = {
                               c_void_p, c_void_p]),
     "rsp_sam_t2i_fold": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                  c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "rsp_sam_upscale_fused": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                      c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                      c_void_p]),
     "rsp_nms_workspace_bytes": (c_int64, [c_int, c_int]),
     "rsp_batched_nms": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_int,
                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

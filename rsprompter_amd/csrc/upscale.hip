@@ -101,6 +101,211 @@ __global__ __launch_bounds__(256) void sam_upscale2_kernel(const Up2P p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// The whole upscaler tail in ONE pass over the per-RoI keys (round 4; verified on the lane-level emulator, not yet on a
+// GPU: opt-in):   masks[r, 4y + 2dy + dy2, 4x + 2dx + dx2] =
+//     sum_c2 GELU( ConvT2(64 -> 32)( GELU( LN_64( ConvT1(256 -> 64)(keys)[r, :, 2y + dy, 2x + dx] ) ) )[c2, dy2, dx2] ) hyper[r, c2]
+// (HF:513-531).  The two-kernel form writes the [R, 2h, 2w, 64] intermediate as fp16 planes (3.4 GB at R = 800) and reads it
+// back; here a wave owns 32 input pixels end to end:
+//   GEMM 1  acc1[(pos, co)][pixel] (8 blocks of 32 rows) = W1 (256 x 256, streamed through a 2 x 32 KB LDS ring in K chunks
+//           of 32 by the DMA engine, shared by the block's waves) x the pixels' plane rows (B operand straight from global
+//           memory, 16 bytes per lane, k-step and plane);
+//   LN      over the 64 channels of a (pixel, pos): 32 values in the lane + 32 in lane ^ 32; GELU;
+//   GEMM 2  per pos: the normalised values ARE the B fragments (accumulator registers [8 (s & 1), +8) of channel block
+//           s >> 1 feed k-step s; W2's K columns are packed in that order by the host), A = W2 resident in LDS;
+//   GELU, dot with hyper_in in the lane, + lane ^ 32; 16 outputs per pixel leave as four 16-byte rows.
+struct UpFP {
+  const half_t* Xhi; const half_t* Xlo; int64_t x_rows;     // keys planes KB32 [8][x_rows][32]
+  const half_t* W1hi; const half_t* W1lo;                   // [8][256][32], rows (dy, dx, co)
+  const half_t* W2hi; const half_t* W2lo;                   // [2][128][32], rows (dy2, dx2, c2), K columns permuted (see above)
+  const float* bias1; const float* gamma; const float* beta; const float* bias2;   // [256] (tiled x4), [64], [64], [128]
+  const float* hyper;                                       // [R, 32]
+  float* out;                                               // [R, 4h, 4w]
+  int64_t rows; int rows_per, W;                            // R * h * w, h * w, w
+  float alpha1, alpha2, eps;
+  int ntiles;                                               // tiles of 128 pixels
+};
+constexpr int UF_YS = 8;                                    // the normalised activations are split at scale 2^8
+
+__global__ __launch_bounds__(256) void sam_upscale_fused_kernel(const UpFP p) {
+  // W2 image as in sam_upscale2_kernel; W1 ring: 2 x [plane][256 rows][64 B], 16-byte chunks XOR-swizzled with (row >> 2) & 3
+  __shared__ __attribute__((aligned(16))) unsigned char sW2[2 * 2 * 128 * 64];
+  __shared__ __attribute__((aligned(1024))) unsigned char sW1[2][2 * 256 * 64];
+  typedef const __attribute__((address_space(1))) void* gptr_u;
+  typedef __attribute__((address_space(3))) void* lptr_u;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int hh = lane >> 5, l31 = lane & 31;
+  for (int u = tid; u < 2 * 2 * 128 * 4; u += 256) {
+    const int c = u & 3, row = (u >> 2) & 127, kb = (u >> 9) & 1, pl = u >> 10;
+    const half_t* src = (pl == 0 ? p.W2hi : p.W2lo) + ((int64_t)(kb * 128 + row) * 32 + c * 8);
+    *reinterpret_cast<uint4*>(sW2 + (((pl * 2 + kb) * 128 + row) * 4 + (c ^ ((row >> 2) & 3))) * 16) =
+        *reinterpret_cast<const uint4*>(src);
+  }
+  __syncthreads();                                          // (the W2 image is first read a whole K loop later; made explicit)
+  // DMA slots of a W1 chunk: unit u = i * 256 + tid of [plane][row][4 chunks]; the LDS side is lane-linear, so the swizzle
+  // is applied to the SOURCE chunk
+  int dsrc[8];                                              // byte offset inside the chunk's 16 KB plane block
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int u = (i & 3) * 256 + tid;                      // 1024 units per plane: slots 0-3 hi, 4-7 lo
+    const int row = u >> 2, c = (u & 3) ^ ((row >> 2) & 3);
+    dsrc[i] = (row * 4 + c) * 16;
+  }
+  auto issue_chunk = [&](int kc, int buf) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const unsigned char* base = reinterpret_cast<const unsigned char*>(i < 4 ? p.W1hi : p.W1lo) + (int64_t)kc * (256 * 64);
+      __builtin_amdgcn_global_load_lds((gptr_u)(base + dsrc[i]),
+                                       (lptr_u)(&sW1[buf][0] + ((i >> 2) * 1024 + (i & 3) * 256 + wave * 64) * 16), 16, 0, 0);
+    }
+  };
+  issue_chunk(0, 0);
+  int cs = 0;                                               // chunks consumed so far: buffer cs & 1, K chunk cs & 7
+
+  for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
+    const int64_t row = (int64_t)tile * 128 + wave * 32 + l31;
+    const bool rok = row < p.rows;
+    const int64_t rowc = rok ? row : p.rows - 1;
+    f32x16 acc1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
+    half8_t xh[2], xl[2];
+    auto load_x = [&](int kc, half8_t (&h8)[2], half8_t (&l8)[2]) {
+#pragma unroll
+      for (int s_ = 0; s_ < 2; ++s_) {
+        const int64_t o = ((int64_t)kc * p.x_rows + rowc) * 32 + 16 * s_ + 8 * hh;
+        h8[s_] = *reinterpret_cast<const half8_t*>(p.Xhi + o);
+        l8[s_] = *reinterpret_cast<const half8_t*>(p.Xlo + o);
+      }
+    };
+    load_x(0, xh, xl);
+    for (int kc = 0; kc < 8; ++kc, ++cs) {
+      const int buf = cs & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the chunk (and its pixel rows) have landed
+      __builtin_amdgcn_s_barrier();                         // ... everybody's; the other buffer has been read
+      const bool last = (kc == 7) && (tile + (int)gridDim.x >= p.ntiles);
+      if (!last) issue_chunk((kc + 1) & 7, buf ^ 1);
+      half8_t nh[2], nl[2];
+      if (kc < 7) load_x(kc + 1, nh, nl);
+      const unsigned char* w0 = &sW1[buf][0];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int wrow = j * 32 + l31;
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) {
+          const int off = (wrow * 4 + ((2 * s_ + hh) ^ ((wrow >> 2) & 3))) * 16;
+          const half8_t wh = *reinterpret_cast<const half8_t*>(w0 + off);
+          const half8_t wl = *reinterpret_cast<const half8_t*>(w0 + 256 * 64 + off);
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[s_], acc1[j], 0, 0, 0);
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[s_], acc1[j], 0, 0, 0);
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[s_], acc1[j], 0, 0, 0);
+        }
+      }
+      if (kc < 7) {
+#pragma unroll
+        for (int s_ = 0; s_ < 2; ++s_) { xh[s_] = nh[s_]; xl[s_] = nl[s_]; }
+      }
+    }
+
+    // ---- per sub-pixel (dy, dx): bias, LayerNorm over its 64 channels, GELU, second ConvTranspose, GELU, hyper dot ----
+    const int roi = (int)(rowc / p.rows_per);
+    const int pix = (int)(rowc - (int64_t)roi * p.rows_per);
+    const int y = pix / p.W, x = pix - y * p.W;
+    f32x4 hy[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) hy[g] = *reinterpret_cast<const f32x4*>(p.hyper + (int64_t)roi * 32 + 8 * g + 4 * hh);
+    float res[4][4];
+    const float ys = ldexpf(1.0f, UF_YS);
+#pragma unroll
+    for (int pos = 0; pos < 4; ++pos) {
+      __builtin_amdgcn_sched_barrier(0);
+      float v[2][16];
+      float sum = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias1 + pos * 64 + jj * 32 + 8 * g + 4 * hh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[jj][4 * g + e] = acc1[2 * pos + jj][4 * g + e] * p.alpha1 + b4[e];
+            sum += v[jj][4 * g + e];
+          }
+        }
+      sum += __shfl_xor(sum, 32, 64);
+      const float mean = sum * (1.0f / 64.0f);
+      float sq = 0.f;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { const float dl = v[jj][e] - mean; sq += dl * dl; }
+      sq += __shfl_xor(sq, 32, 64);
+      const float rstd = 1.0f / sqrtf(sq * (1.0f / 64.0f) + p.eps);
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int ch = jj * 32 + 8 * g + 4 * hh;
+          const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + ch);
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + ch);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[jj][4 * g + e] = rsp_gelu((v[jj][4 * g + e] - mean) * rstd * g4[e] + b4[e]) * ys;
+        }
+      // B fragments of the second product: k-step s = registers [8 (s & 1), +8) of channel block s >> 1
+      half8_t yh[4], yl[4];
+#pragma unroll
+      for (int s_ = 0; s_ < 4; ++s_) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          half_t a, b;
+          rsp_split1(v[s_ >> 1][8 * (s_ & 1) + t], a, b);
+          yh[s_][t] = a; yl[s_][t] = b;
+        }
+      }
+#pragma unroll
+      for (int jb = 0; jb < 4; ++jb) {                        // (dy2, dx2) = (jb >> 1, jb & 1)
+        f32x16 acc2;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[e] = 0.f;
+        const int wrow = jb * 32 + l31;
+#pragma unroll
+        for (int s_ = 0; s_ < 4; ++s_) {
+          const int off = (((s_ >> 1) * 128 + wrow) * 4 + ((((s_ & 1) * 2 + hh)) ^ ((wrow >> 2) & 3))) * 16;
+          const half8_t wh = *reinterpret_cast<const half8_t*>(sW2 + off);
+          const half8_t wl = *reinterpret_cast<const half8_t*>(sW2 + 2 * 128 * 64 + off);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, yh[s_], acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, yl[s_], acc2, 0, 0, 0);
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, yh[s_], acc2, 0, 0, 0);
+        }
+        float dot = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias2 + jb * 32 + 8 * g + 4 * hh);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dot += rsp_gelu(acc2[4 * g + e] * p.alpha2 + b4[e]) * hy[g][e];
+        }
+        dot += __shfl_xor(dot, 32, 64);
+        res[pos][jb] = dot;
+        __builtin_amdgcn_sched_barrier(0);                  // (keeps the next block's loads from piling up registers)
+      }
+    }
+    if (rok) {
+      // output rows 4y + 2dy + dy2; the half waves split them: hh == 0 writes dy = 0, hh == 1 dy = 1
+      float* o = p.out + (int64_t)roi * (16 * (int64_t)p.rows_per) + (int64_t)(4 * y + 2 * hh) * (4 * p.W) + 4 * x;
+#pragma unroll
+      for (int dy2 = 0; dy2 < 2; ++dy2) {
+        const float a0 = hh ? res[2][2 * dy2] : res[0][2 * dy2], a1 = hh ? res[2][2 * dy2 + 1] : res[0][2 * dy2 + 1];
+        const float a2 = hh ? res[3][2 * dy2] : res[1][2 * dy2], a3 = hh ? res[3][2 * dy2 + 1] : res[1][2 * dy2 + 1];
+        *reinterpret_cast<f32x4*>(o + (int64_t)dy2 * (4 * p.W)) = f32x4{a0, a1, a2, a3};
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int rsp_sam_upscale2(const uint16_t* a_hi, const uint16_t* a_lo, int64_t rows, int32_t a_scale_log2,
@@ -121,6 +326,36 @@ extern "C" int rsp_sam_upscale2(const uint16_t* a_hi, const uint16_t* a_lo, int6
   int64_t blocks = (nt + 3) / 4;
   if (blocks > 256 * 8) blocks = 256 * 8;          // persistent: up to 8 blocks (32 waves) per CU
   hipLaunchKernelGGL(sam_upscale2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+// keys: planes of [rows = R * h * w, 256]; w1: packed [(dy, dx, co), 256] with bias1 tiled x4; LayerNorm2d(64) gamma / beta /
+// eps; w2: packed [(dy2, dx2, c2), 64] whose K columns are in the order k' = 16 s + 8 hh + j <- channel
+// 32 (s >> 1) + 8 ((8 (s & 1) + j) >> 2) + 4 hh + (j & 3)  (see sam_upscale_fused_kernel), bias2 tiled x4; hyper [R, 32];
+// out [R, 4h, 4w].
+extern "C" int rsp_sam_upscale_fused(const uint16_t* x_hi, const uint16_t* x_lo, int64_t x_rows, int32_t x_scale_log2,
+                                     const uint16_t* w1_hi, const uint16_t* w1_lo, int32_t w1_scale_log2, const float* bias1,
+                                     const float* gamma, const float* beta, float eps, const uint16_t* w2_hi,
+                                     const uint16_t* w2_lo, int32_t w2_scale_log2, const float* bias2, const float* hyper,
+                                     float* out, int64_t rows, int32_t rows_per_roi, int32_t W, rsp_stream_t stream) {
+  if (!x_hi || !x_lo || !w1_hi || !w1_lo || !bias1 || !gamma || !beta || !w2_hi || !w2_lo || !bias2 || !hyper || !out ||
+      rows <= 0 || x_rows < rows || rows_per_roi <= 0 || W <= 0 || (rows_per_roi % W) != 0 || (rows % rows_per_roi) != 0)
+    return RSP_EINVAL;
+  UpFP p;
+  p.Xhi = reinterpret_cast<const half_t*>(x_hi); p.Xlo = reinterpret_cast<const half_t*>(x_lo); p.x_rows = x_rows;
+  p.W1hi = reinterpret_cast<const half_t*>(w1_hi); p.W1lo = reinterpret_cast<const half_t*>(w1_lo);
+  p.W2hi = reinterpret_cast<const half_t*>(w2_hi); p.W2lo = reinterpret_cast<const half_t*>(w2_lo);
+  p.bias1 = bias1; p.gamma = gamma; p.beta = beta; p.bias2 = bias2; p.hyper = hyper; p.out = out;
+  p.rows = rows; p.rows_per = rows_per_roi; p.W = W;
+  p.alpha1 = ldexpf(1.0f, -(x_scale_log2 + w1_scale_log2));
+  p.alpha2 = ldexpf(1.0f, -(UF_YS + w2_scale_log2));
+  p.eps = eps;
+  const int64_t nt = (rows + 127) / 128;
+  if (nt > 0x7fffffffLL) return RSP_EINVAL;
+  p.ntiles = (int)nt;
+  const int64_t blocks = nt < 256 ? nt : 256;               // persistent: one block (4 waves, 96 KB of LDS) per CU
+  hipLaunchKernelGGL(sam_upscale_fused_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }

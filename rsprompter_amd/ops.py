@@ -767,6 +767,36 @@ def sam_t2i_attention(q, kv, out, *, R, T, N, scale, kv_map=None):
     return out
 
 
+def upscale2_k_order():
+    """K (input channel) order of the second ConvTranspose's packed weight for rsp_sam_upscale_fused: packed column
+    16 s + 8 hh + j holds channel 32 (s >> 1) + 8 ((8 (s & 1) + j) >> 2) + 4 hh + (j & 3) -- the order in which the first
+    product's accumulator registers become the second product's B fragments."""
+    perm = []
+    for kp in range(64):
+        s_, hh, j = kp >> 4, (kp >> 3) & 1, kp & 7
+        perm.append(32 * (s_ >> 1) + 8 * ((8 * (s_ & 1) + j) >> 2) + 4 * hh + (j & 3))
+    return perm
+
+
+def sam_upscale_fused(x, w1, bias1, gamma, beta, eps, w2p, bias2, hyper, h, w):
+    """x Planes [R*h*w, 256] -> masks [R, 4h, 4w] (ConvT + LN + GELU + ConvT + GELU + hyper dot in one kernel, csrc/upscale.hip);
+    w1 = PackedWeight [(dy, dx, co), 256], w2p = PackedWeight [(dy2, dx2, c2), 64] with K in upscale2_k_order()."""
+    lib = _lib.load()
+    if not isinstance(x, Planes) or x.shape[-1] != 256 or x.f8:
+        raise ValueError('sam_upscale_fused: x must be fp16 planes with 256 columns')
+    rows = x.rows
+    R = rows // (h * w)
+    out = torch.empty((R, 4 * h, 4 * w), dtype=torch.float32, device=x.device)
+    _timed('sam_upscale_fused_kernel', 2.0 * rows * (256 * 256 + 4 * 128 * 64), 4.0 * rows * 256 + 64.0 * rows,
+           lambda: _lib.check(lib.rsp_sam_upscale_fused(x.hi.data_ptr(), x.lo.data_ptr(), x.rows, x.scale_log2,
+                                                        w1.hi.data_ptr(), w1.lo.data_ptr(), w1.scale_log2, bias1.data_ptr(),
+                                                        gamma.data_ptr(), beta.data_ptr(), float(eps), w2p.hi.data_ptr(),
+                                                        w2p.lo.data_ptr(), w2p.scale_log2, bias2.data_ptr(),
+                                                        hyper.data_ptr(), out.data_ptr(), rows, h * w, w, _stream()),
+                              "rsp_sam_upscale_fused"))
+    return out
+
+
 SAM_T2I_FOLD_MAX_TOKENS = 12    # 8 heads x T query columns fit the kernel's 96
 
 

@@ -89,6 +89,8 @@ class SamMaskDecoderHIP(HIPModule):
         # token -> image attention of layer 1 / final with the K | V projections folded in (csrc/t2i_fold.hip)
         self.t2i_fold = T2I_FOLD_DEFAULT
         self.t2i_fold_variant = 0          # rsp_sam_t2i_fold `variant`
+        # the upscaler tail in one kernel (csrc/upscale.hip, sam_upscale_fused_kernel): verified on the emulator only
+        self.upscale_fused = False
 
     # ------------------------------------------------------------------ packing
     def _pw(self, name, with_bias=True):
@@ -109,6 +111,9 @@ class SamMaskDecoderHIP(HIPModule):
             P[f'final.{pr}'] = self._pw(f'transformer.final_attn_token_to_image.{pr}')
         P['up1'] = convt_weights4(self.upscale_conv1.weight, self.upscale_conv1.bias)
         P['up2'] = convt_weights4(self.upscale_conv2.weight, self.upscale_conv2.bias)
+        # ... and with its input channels in the order the fused upscaler consumes them (ops.upscale2_k_order)
+        w2 = self.upscale_conv2.weight.detach()[ops.upscale2_k_order()]
+        P['up2p'] = convt_weights4(w2, self.upscale_conv2.bias)
         # K and V projections of the token->image attentions share their A operand: one [256 -> 128+128] GEMM
         for pre, p in (('0.cross_attn_token_to_image', 'transformer.layers.0.cross_attn_token_to_image'),
                        ('1.cross_attn_token_to_image', 'transformer.layers.1.cross_attn_token_to_image'),
@@ -345,15 +350,23 @@ class SamMaskDecoderHIP(HIPModule):
         toks = (1, 2, 3) if multimask_output else (0,)
         # both ConvTransposes run as one GEMM each (columns = (dy, dx, co), planes in); the second one never
         # stores its [R, 4h, 4w, 32] result: GELU and the product with hyper_in happen in its epilogue
-        up = ops.conv_transpose2x2(keys_pl.view(R, h, w, HID), *P['up1'], act=ops.ACT_GELU,
-                                   ln=(self.upscale_layer_norm.weight, self.upscale_layer_norm.bias, 1e-6))
-        del keys_pl                                                                     # [R, 2h, 2w, 64] planes
+        fused_up = self.upscale_fused and len(toks) == 1
+        if not fused_up:
+            up = ops.conv_transpose2x2(keys_pl.view(R, h, w, HID), *P['up1'], act=ops.ACT_GELU,
+                                       ln=(self.upscale_layer_norm.weight, self.upscale_layer_norm.bias, 1e-6))
+            del keys_pl                                                                 # [R, 2h, 2w, 64] planes
         outs = []
         for i in toks:
             mt = q3[:, 1 + i, :].contiguous()
             hy = ops.gemm(mt, P[f'hyper{i}.proj_in'], act=ops.ACT_RELU)
             hy = ops.gemm(hy, P[f'hyper{i}.layers.0'], act=ops.ACT_RELU)
             hy = ops.gemm(hy, P[f'hyper{i}.proj_out'])
+            if fused_up:
+                # one pass over the keys: no [R, 2h, 2w, 64] intermediate (csrc/upscale.hip, sam_upscale_fused_kernel)
+                outs.append(ops.sam_upscale_fused(keys_pl, P['up1'][0], P['up1'][1], self.upscale_layer_norm.weight,
+                                                  self.upscale_layer_norm.bias, 1e-6, P['up2p'][0], P['up2p'][1], hy,
+                                                  h, w).view(R, 1, 4 * h, 4 * w))
+                continue
             # (multimask: the last ConvTranspose is recomputed per token -- a rarely used option, no [R,4h,4w,32] tensor)
             outs.append(ops.conv_transpose2x2(up, *P['up2'], act=ops.ACT_GELU, hyper=hy).view(R, 1, 4 * h, 4 * w))
         masks = outs[0] if len(outs) == 1 else torch.cat(outs, 1)

@@ -155,3 +155,45 @@ def test_emu_dma_kernels_with_latest_possible_completion(emu):
         tk.test_vit_window_attention_fused_relpos(DEV, 3, 4, 2, 80, 1, 1)
         tk.test_vit_attention_planes(DEV, 32, 2, 64, 2)
         tk.test_sam_t2i_fold_matches_fp64_attention(DEV, 3, 64, 10)
+
+
+def test_emu_fused_upscaler_tail(emu):
+    """sam_upscale_fused_kernel (csrc/upscale.hip): ConvTranspose + LayerNorm2d + GELU + ConvTranspose + GELU + hyper-network
+    product in one pass over the keys -- written on the emulator at the end of round 4 and not yet run on a GPU (opt-in:
+    SamMaskDecoderHIP.upscale_fused).  The whole mask decoder with it against the HuggingFace decoder, and against the
+    two-kernel form."""
+    from oracle import hf_sam
+    from rsprompter_amd.registry import MODELS
+    from rsprompter_amd.synth import synth_state_dict
+    head = MODELS.build(dict(type='RSPrompterAnchorMaskHead', mask_decoder=dict(type='RSSamMaskDecoder', hf_pretrain_name='sam_vit_base'),
+                             in_channels=256, roi_feat_size=14, per_pointset_point=5, with_sincos=True, multimask_output=False,
+                             class_agnostic=True))
+    sd = synth_state_dict(head, 5)
+    head.load_state_dict(sd)
+    dec = hf_sam.build_mask_decoder()
+    dec.load_state_dict({k[len('mask_decoder.mask_decoder.'):]: v for k, v in sd.items() if k.startswith('mask_decoder.mask_decoder.')})
+    g = torch.Generator().manual_seed(2)
+    R, B, hw = 5, 2, 12                       # 144 pixels per RoI: tiles of 128 straddle RoIs, the last tile is ragged
+    x = torch.randn(R, 256, 14, 14, generator=g)
+    emb = torch.randn(B, 256, hw, hw, generator=g)
+    ipe = torch.randn(1, 256, hw, hw, generator=g).expand(B, -1, -1, -1).contiguous()
+    roi_img = torch.tensor([0, 0, 1, 1, 1])
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last)
+    hip = head.mask_decoder.mask_decoder
+    low0, _ = head(cl(x), cl(emb), cl(ipe), roi_img)
+    hip.upscale_fused = True
+    low1, iou1 = head(cl(x), cl(emb), cl(ipe), roi_img)
+    import harness
+    with harness.lazy_dma():                      # ... and with the W1 ring's DMA completing as late as its waits allow
+        low2, _ = head(cl(x), cl(emb), cl(ipe), roi_img)
+    assert torch.equal(low1, low2)
+    sparse = head.point_embeddings(cl(x))
+    with torch.no_grad():
+        ref_m, ref_i = dec(image_embeddings=emb[roi_img], image_positional_embeddings=ipe[roi_img],
+                           sparse_prompt_embeddings=sparse.unsqueeze(1),
+                           dense_prompt_embeddings=sd['no_mask_embed.weight'].reshape(1, -1, 1, 1).expand(R, -1, hw, hw),
+                           multimask_output=False)[:2]
+    ref_m = ref_m.reshape(R, 1, 4 * hw, 4 * hw)
+    e0, e1 = float((low0 - ref_m).abs().max()), float((low1 - ref_m).abs().max())
+    print(f'upscaler tail: two kernels vs HF {e0:.2e}, fused vs HF {e1:.2e}, fused vs two kernels {float((low0 - low1).abs().max()):.2e}')
+    assert e0 < 1e-4 and e1 < 1e-4
