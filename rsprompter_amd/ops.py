@@ -767,20 +767,10 @@ def sam_t2i_attention(q, kv, out, *, R, T, N, scale, kv_map=None):
     return out
 
 
-def upscale2_k_order():
-    """K (input channel) order of the second ConvTranspose's packed weight for rsp_sam_upscale_fused: packed column
-    16 s + 8 hh + j holds channel 32 (s >> 1) + 8 ((8 (s & 1) + j) >> 2) + 4 hh + (j & 3) -- the order in which the first
-    product's accumulator registers become the second product's B fragments."""
-    perm = []
-    for kp in range(64):
-        s_, hh, j = kp >> 4, (kp >> 3) & 1, kp & 7
-        perm.append(32 * (s_ >> 1) + 8 * ((8 * (s_ & 1) + j) >> 2) + 4 * hh + (j & 3))
-    return perm
-
-
 def sam_upscale_fused(x, w1, bias1, gamma, beta, eps, w2p, bias2, hyper, h, w):
     """x Planes [R*h*w, 256] -> masks [R, 4h, 4w] (ConvT + LN + GELU + ConvT + GELU + hyper dot in one kernel, csrc/upscale.hip);
-    w1 = PackedWeight [(dy, dx, co), 256], w2p = PackedWeight [(dy2, dx2, c2), 64] with K in upscale2_k_order()."""
+    w1 = PackedWeight [(dy, dx, co), 256], w2p = PackedWeight [(dy2, dx2, c2), 64] with its K columns in the order
+    rsp_sam_upscale_fused documents (sam_decoder._upscale2_k_order)."""
     lib = _lib.load()
     if not isinstance(x, Planes) or x.shape[-1] != 256 or x.f8:
         raise ValueError('sam_upscale_fused: x must be fp16 planes with 256 columns')

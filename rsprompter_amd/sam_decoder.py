@@ -32,6 +32,12 @@ N_MASK_TOKENS = 4  # num_multimask_outputs + 1
 T2I_FOLD_DEFAULT = __import__('os').environ.get('RSP_T2I_FOLD', '0') == '1'
 
 
+def _upscale2_k_order():
+    """input-channel order of the second ConvTranspose's packed weight for rsp_sam_upscale_fused (include/rsp_hip.h): packed
+    column 16 s + 8 hh + j holds channel 32 (s >> 1) + 8 ((8 (s & 1) + j) >> 2) + 4 hh + (j & 3)"""
+    return [32 * ((kp >> 4) >> 1) + 8 * ((8 * ((kp >> 4) & 1) + (kp & 7)) >> 2) + 4 * ((kp >> 3) & 1) + (kp & 3) for kp in range(64)]
+
+
 def _add_linear(root, name, cout, cin):
     add_param(root, name + '.weight', (cout, cin))
     add_param(root, name + '.bias', (cout,))
@@ -112,7 +118,7 @@ class SamMaskDecoderHIP(HIPModule):
         P['up1'] = convt_weights4(self.upscale_conv1.weight, self.upscale_conv1.bias)
         P['up2'] = convt_weights4(self.upscale_conv2.weight, self.upscale_conv2.bias)
         # ... and with its input channels in the order the fused upscaler consumes them (ops.upscale2_k_order)
-        w2 = self.upscale_conv2.weight.detach()[ops.upscale2_k_order()]
+        w2 = self.upscale_conv2.weight.detach()[_upscale2_k_order()]
         P['up2p'] = convt_weights4(w2, self.upscale_conv2.bias)
         # K and V projections of the token->image attentions share their A operand: one [256 -> 128+128] GEMM
         for pre, p in (('0.cross_attn_token_to_image', 'transformer.layers.0.cross_attn_token_to_image'),
