@@ -324,6 +324,8 @@ def main():
     ap.add_argument('--t2i-fold', dest='t2i_fold', choices=['on', 'off'], default=None,
                     help='token -> image attention of the SAM decoder with the K | V projections folded in '
                          '(csrc/t2i_fold.hip); default: the library default (rsprompter_amd.sam_decoder.T2I_FOLD_DEFAULT)')
+    ap.add_argument('--upscale-fused', dest='upscale_fused', choices=['on', 'off'], default=None,
+                    help='the SAM upscaler tail as one kernel (csrc/upscale.hip sam_upscale_fused_kernel, DESIGN 4.3c)')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -350,6 +352,9 @@ def main():
     if args.t2i_fold is not None:
         import rsprompter_amd.sam_decoder as _sd
         _sd.T2I_FOLD_DEFAULT = args.t2i_fold == 'on'
+    if args.upscale_fused is not None:
+        import rsprompter_amd.sam_decoder as _sd2
+        _sd2.UPSCALE_FUSED_DEFAULT = args.upscale_fused == 'on'
     from rsprompter_amd.structures import DetDataSample
     from rsprompter_amd.synth import synth_images, synth_metas
     import torch.distributed as tdist

@@ -30,6 +30,8 @@ N_MASK_TOKENS = 4  # num_multimask_outputs + 1
 # the kernel itself needs 2.2 ms per call where its matrix work would allow ~1: it stays OPT-IN (this flag, or
 # `decoder.t2i_fold = True`, or `bench.py --t2i-fold on`) until it has been tuned and the whole GPU suite has run with it.
 T2I_FOLD_DEFAULT = __import__('os').environ.get('RSP_T2I_FOLD', '0') == '1'
+# The upscaler tail as one kernel: emulator-verified, unmeasured -- `bench.py --upscale-fused on` for round 5.
+UPSCALE_FUSED_DEFAULT = False
 
 
 def _upscale2_k_order():
@@ -96,7 +98,7 @@ class SamMaskDecoderHIP(HIPModule):
         self.t2i_fold = T2I_FOLD_DEFAULT
         self.t2i_fold_variant = 0          # rsp_sam_t2i_fold `variant`
         # the upscaler tail in one kernel (csrc/upscale.hip, sam_upscale_fused_kernel): verified on the emulator only
-        self.upscale_fused = False
+        self.upscale_fused = UPSCALE_FUSED_DEFAULT
 
     # ------------------------------------------------------------------ packing
     def _pw(self, name, with_bias=True):
