@@ -506,6 +506,49 @@ def test_anchor_mask_head_with_folded_token_to_image_attention(dev, hw):
     assert e0 < LOGIT_TOL and e1 < LOGIT_TOL and _maxerr(iou1, ref_i.reshape(R, 1)) < LOGIT_TOL
 
 
+@pytest.mark.skipif(_os.environ.get('RSP_UNMEASURED') != '1', reason='kernels verified on the lane-level emulator only '
+                    '(tests/test_wave_emu_cpu.py): set RSP_UNMEASURED=1 for their first run on a GPU')
+@pytest.mark.parametrize('hw', [12, 64])
+def test_unmeasured_decoder_kernels_first_gpu_run(dev, hw):
+    """The two kernels that round 4 finished on the emulator after its GPU budget was spent -- the upscaler tail as one
+    kernel (SamMaskDecoderHIP.upscale_fused) and the folded attention with its DMA issue spread between the
+    MFMAs (t2i_fold_variant = 1) -- against the HF decoder and against the measured forms.  Not part of the default suite
+    until it has passed on an MI355X once."""
+    from oracle import hf_sam
+    from rsprompter_amd.registry import MODELS
+    from rsprompter_amd.synth import synth_state_dict
+    head = MODELS.build(dict(type='RSPrompterAnchorMaskHead', mask_decoder=dict(type='RSSamMaskDecoder', hf_pretrain_name='sam_vit_base'),
+                             in_channels=256, roi_feat_size=14, per_pointset_point=5, with_sincos=True, multimask_output=False,
+                             class_agnostic=True))
+    sd = synth_state_dict(head, 5)
+    head.load_state_dict(sd)
+    head = head.to(dev)
+    dec = hf_sam.build_mask_decoder()
+    dec.load_state_dict({k[len('mask_decoder.mask_decoder.'):]: v for k, v in sd.items() if k.startswith('mask_decoder.mask_decoder.')})
+    g = torch.Generator().manual_seed(2)
+    R, B = 5, 2
+    x = torch.randn(R, 256, 14, 14, generator=g)
+    emb = torch.randn(B, 256, hw, hw, generator=g)
+    ipe = torch.randn(1, 256, hw, hw, generator=g).expand(B, -1, -1, -1).contiguous()
+    roi_img = torch.tensor([0, 0, 1, 1, 1])
+    cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    hip = head.mask_decoder.mask_decoder
+    low0, _ = head(cl(x), cl(emb), cl(ipe), roi_img.to(dev))
+    hip.upscale_fused = True
+    low1, _ = head(cl(x), cl(emb), cl(ipe), roi_img.to(dev))
+    hip.upscale_fused, hip.t2i_fold, hip.t2i_fold_variant = False, hw % 8 == 0, 1
+    low2, _ = head(cl(x), cl(emb), cl(ipe), roi_img.to(dev))
+    sparse = head.point_embeddings(cl(x)).cpu()
+    with torch.no_grad():
+        ref_m = dec(image_embeddings=emb[roi_img], image_positional_embeddings=ipe[roi_img],
+                    sparse_prompt_embeddings=sparse.unsqueeze(1),
+                    dense_prompt_embeddings=sd['no_mask_embed.weight'].reshape(1, -1, 1, 1).expand(R, -1, hw, hw),
+                    multimask_output=False)[0].reshape(R, 1, 4 * hw, 4 * hw)
+    e0, e1, e2 = _maxerr(low0, ref_m), _maxerr(low1, ref_m), _maxerr(low2, ref_m)
+    print(f'{hw}x{hw}: shipped {e0:.2e}, fused upscaler {e1:.2e}, folded attention variant 1 {e2:.2e} vs HF')
+    assert max(e0, e1, e2) < LOGIT_TOL
+
+
 def test_encoder_batch8_row_maps(dev):
     """window partition / unpartition row maps with B = 8 (the bench batch): every image of the batch must equal the
     oracle's single-image forward of that image (HF:900-952; images are independent)."""
