@@ -57,6 +57,7 @@ def emulated_ops():
         if t.dtype != torch.float32:
             raise ValueError(f'{name}: expected float32')
     ops._stream, ops._chk_f32, ops.require_device = (lambda: 0), chk, (lambda dev: None)
+    lib.emu_set_lazy_dma(1 if os.environ.get('RSP_WAVE_EMU_LAZY') == '1' else 0)     # audit mode: see lazy_dma()
     try:
         yield ops
     finally:
