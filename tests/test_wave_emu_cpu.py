@@ -124,6 +124,9 @@ SWEEP = [
     ('test_gpu_samdet', 'test_bbox_post_matches_real_bbox_head_with_and_without_rescale', ()),
     ('test_gpu_samdet', 'test_resnet_leaf_kernels', ()),
     ('test_gpu_samseg', 'test_paste_masks_kernel_matches_reference_vectors', ()),
+    ('test_gpu_dist', 'test_pack_masks_matches_numpy', ()),
+    ('test_gpu_dist', 'test_mask_rle_matches_coco_restatement', ()),          # byte-equal to the reference's COCO strings
+    ('test_gpu_dist', 'test_all_gather_results_single_process_on_device', ()),
 ]
 
 
