@@ -200,3 +200,40 @@ def test_emu_fused_upscaler_tail(emu):
     e0, e1 = float((low0 - ref_m).abs().max()), float((low1 - ref_m).abs().max())
     print(f'upscaler tail: two kernels vs HF {e0:.2e}, fused vs HF {e1:.2e}, fused vs two kernels {float((low0 - low1).abs().max()):.2e}')
     assert e0 < 1e-4 and e1 < 1e-4
+
+
+def test_emu_rle_codec_round_trip_property(emu):
+    """encode -> decode round trip of the evaluation hand-off: random masks of random sizes -- W a multiple of
+    4 (mask_rle4_kernel) or not (the byte-wise kernel), blobs, stripes, empty and full masks, capacities that have to grow --
+    through the DEVICE codec (rsp_mask_rle + rsp_rle_to_string on the emulator) must decode, with the oracle's restatement of
+    cocoapi's rleFrString / rleDecode, to the mask again, and the string must be the one pycocotools would write."""
+    from hypothesis import given, settings, strategies as st
+    import numpy as np
+    from oracle import rle as orle
+    from rsprompter_amd import rle as prle
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.integers(1, 3), st.integers(1, 40), st.integers(1, 45), st.integers(0, 5), st.integers(0, 2 ** 31 - 1))
+    def check(k, h, w, kind, seed):
+        g = np.random.default_rng(seed)
+        if kind == 0:
+            m = g.random((k, h, w)) < 0.5                                   # noise: many runs
+        elif kind == 1:
+            m = np.zeros((k, h, w), bool)
+        elif kind == 2:
+            m = np.ones((k, h, w), bool)
+        elif kind == 3:
+            m = np.zeros((k, h, w), bool); m[:, :, ::2] = True               # column stripes (column-major runs of h)
+        elif kind == 4:
+            m = np.zeros((k, h, w), bool); m[:, ::2, :] = True               # row stripes: runs of 1
+        else:
+            m = np.zeros((k, h, w), bool)
+            y0, x0 = int(g.integers(0, h)), int(g.integers(0, w))
+            m[:, y0:y0 + int(g.integers(1, h + 1)), x0:x0 + int(g.integers(1, w + 1))] = True   # a box
+        flat, offs = prle.encode_rle_strings(torch.from_numpy(m), cap=8)     # tiny capacity: the grow-and-retry path
+        buf, o = flat.numpy().tobytes(), offs.tolist()
+        for i in range(k):
+            s_ = buf[o[i]:o[i + 1]]
+            assert s_ == orle.encode(m[i])['counts']
+            assert np.array_equal(orle.rle_decode(orle.rle_from_string(s_), h, w), m[i])
+    check()
