@@ -237,3 +237,71 @@ def test_emu_rle_codec_round_trip_property(emu):
             assert s_ == orle.encode(m[i])['counts']
             assert np.array_equal(orle.rle_decode(orle.rle_from_string(s_), h, w), m[i])
     check()
+
+
+def test_emu_gemm_ragged_shapes_property(emu):
+    """C = act(A W^T + b) + res for random ragged shapes through whatever kernel the dispatcher picks (fp32 A: the
+    register-staged kernel; planes: gemm_f16x3_dma_kernel; hint 40: the persistent kernel) against the fp64 product"""
+    from hypothesis import given, settings, strategies as st
+    import torch.nn.functional as F
+
+    @settings(max_examples=100, deadline=None)
+    @given(st.integers(1, 300), st.integers(1, 40), st.integers(1, 8), st.sampled_from(['f32', 'planes', 's2']),
+           st.booleans(), st.booleans(), st.sampled_from([0, 1, 2]), st.integers(0, 2 ** 31 - 1))
+    def check(M, n4, k32, path, with_bias, with_res, act, seed):
+        N, K = 4 * n4, 32 * k32
+        if path == 's2':
+            N = 64 * ((n4 + 15) // 16)                      # the persistent kernel's specialised epilogues: N % 64 == 0
+        g = torch.Generator().manual_seed(seed)
+        a = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g) if with_bias else None
+        res = torch.randn(M, N, generator=g) if with_res else None
+        ref = a.double() @ w.double().t()
+        if b is not None:
+            ref = ref + b.double()
+        kw = {}
+        if act == 1 and not with_res:
+            ref, kw['act'] = F.gelu(ref), emu.ACT_GELU
+        elif act == 2:
+            ref, kw['act'] = F.relu(ref), emu.ACT_RELU
+        if res is not None:
+            ref = ref + res.double()
+        pw = emu.PackedWeight(w, b)
+        if path == 'f32':
+            got = emu.gemm(a, pw, res=res, dma=False, **kw)
+        else:
+            got = emu.gemm(emu.to_planes(a), pw, res=res, tile_hint=40 if path == 's2' else 0, **kw)
+        err = float((got.double() - ref).abs().max() / (ref.abs().max() + 1e-30))
+        assert err < 3e-6, (M, N, K, path, with_bias, with_res, act, err)
+    check()
+
+
+def test_emu_batched_nms_property(emu):
+    """greedy NMS with the coordinate-offset trick on random candidate sets -- duplicates, exact score ties, empty sets,
+    counts below the capacity, one to several ids -- against the oracle's restatement of mmcv batched_nms: kept indices in
+    the same order"""
+    from hypothesis import given, settings, strategies as st
+    from oracle import glue
+
+    @settings(max_examples=100, deadline=None)
+    @given(st.integers(0, 400), st.integers(1, 6), st.sampled_from([0.3, 0.5, 0.7]), st.integers(1, 120), st.integers(2, 60),
+           st.integers(0, 2 ** 31 - 1))
+    def check(n, nid, thr, max_out, levels, seed):
+        g = torch.Generator().manual_seed(seed)
+        cap = max(n + int(torch.randint(0, 50, (1,), generator=g)), 1)
+        xy = (torch.rand(cap, 2, generator=g) * 8).floor() * 16              # a coarse grid: many identical boxes
+        wh = (torch.rand(cap, 2, generator=g) * 4).floor() * 16 + 16
+        boxes = torch.cat([xy, xy + wh], 1)[None].contiguous()
+        scores = ((torch.rand(cap, generator=g) * levels).round() / levels)[None].contiguous()     # few score levels: ties
+        ids = torch.randint(0, nid, (cap,), generator=g, dtype=torch.int32)[None].contiguous()
+        cand = (boxes, scores, ids, torch.arange(cap, dtype=torch.int32)[None].contiguous(), torch.tensor([n], dtype=torch.int32))
+        out = emu.batched_nms(cand, 1, cap, thr, max_out)
+        if n:
+            _, keep = glue.batched_nms(boxes[0, :n], scores[0, :n], ids[0, :n].long(), thr)
+            keep = keep[:max_out]
+        else:
+            keep = torch.zeros(0, dtype=torch.long)
+        k = int(out['count'][0])
+        assert k == keep.numel() and torch.equal(out['keep'][0, :k].long(), keep), (n, nid, thr, max_out)
+    check()
