@@ -305,3 +305,42 @@ def test_emu_batched_nms_property(emu):
         k = int(out['count'][0])
         assert k == keep.numel() and torch.equal(out['keep'][0, :k].long(), keep), (n, nid, thr, max_out)
     check()
+
+
+def test_emu_window_attention_grid_property(emu):
+    """rsp_vit_window_attention over random window grids: windows per side 1-3, 1-14 real rows / columns in the last window
+    of a row / column (the padded queries are skipped, the padded keys masked), 1-3 heads of 64 or 80, both block counts"""
+    from hypothesis import given, settings, strategies as st
+    import test_gpu_kernels as tk
+
+    @settings(max_examples=10, deadline=None)
+    @given(st.integers(1, 3), st.integers(1, 14), st.integers(1, 3), st.sampled_from([64, 80]), st.integers(0, 1))
+    def check(nw, real, nh, dh, variant):
+        if (nh * dh) % 32:
+            nh += 1                                          # the K | V planes need nh * dh % 32 == 0 (else EINVAL)
+        tk.test_vit_window_attention_fused_relpos(DEV, nw, real, nh, dh, 1, variant)
+    check()
+
+
+def test_emu_layernorm_shapes_property(emu):
+    """LayerNorm over random row counts and widths (the four-rows-per-wave kernel for C % 64 == 0 in [256, 1280] with plane
+    outputs, the wave-per-row kernel otherwise), fp32 and plane outputs against fp64"""
+    from hypothesis import given, settings, strategies as st
+    import torch.nn.functional as F
+    import test_gpu_kernels as tk
+
+    @settings(max_examples=40, deadline=None)
+    @given(st.integers(1, 130), st.sampled_from([32, 64, 96, 128, 256, 320, 768, 1280]), st.booleans(), st.integers(0, 2 ** 31 - 1))
+    def check(rows, C, planes, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(rows, C, generator=g) * 3 + 1
+        w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        ref = F.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-6)
+        got = emu.layernorm(x, w, b, 1e-6, planes=planes)
+        if planes:
+            y, pl = got if isinstance(got, tuple) else (None, got)
+            assert float((tk._planes_to_f32(pl) - ref).abs().max()) < 2e-5
+            got = y
+        if got is not None:
+            assert float((got.double() - ref).abs().max()) < 2e-5
+    check()
