@@ -27,3 +27,4 @@ for cfg in "base:" "fold:--t2i-fold on" "up:--upscale-fused on" "both:--t2i-fold
   echo "[bench $name] rc=$? $(( $(date +%s) - t0 )) s: $(line $O/bench_$name.json)"
 done
 bash tools/gpu_job.sh r5/first "p:both:--t2i-fold on --upscale-fused on"
+timeout 120 python tools/decoder_tail_micro.py 800 10 > $O/decoder_tail_micro.txt 2>&1; echo "[decoder tail micro] rc=$? $(( $(date +%s) - t0 )) s"; cat $O/decoder_tail_micro.txt
