@@ -344,3 +344,22 @@ def test_emu_layernorm_shapes_property(emu):
         if got is not None:
             assert float((got.double() - ref).abs().max()) < 2e-5
     check()
+
+
+def test_emu_attention_shapes_property(emu):
+    """the generic flash attention (token self attention, masked Mask2Former cross attention: rsp_attention) and the fused
+    image -> token block over random token / key counts -- ragged last tiles, one key, T below and at the kernels' limits"""
+    from hypothesis import given, settings, strategies as st
+    import test_gpu_kernels as tk
+
+    @settings(max_examples=25, deadline=None, derandomize=True)
+    @given(st.sampled_from([16, 32, 64]), st.integers(1, 70), st.integers(1, 200), st.integers(1, 8))
+    def generic(dh, Tq, Tk, nh):
+        tk.test_generic_attention_with_batch_maps(DEV, dh, Tq, Tk, nh)
+    generic()
+
+    @settings(max_examples=16, deadline=None, derandomize=True)
+    @given(st.integers(1, 10), st.integers(1, 300), st.booleans(), st.sampled_from(['valu', 'mfma']))
+    def i2t(T, N, planes_res, form):
+        tk.test_sam_i2t_fused_matches_composition(DEV, T, N, planes_res, form)
+    i2t()
