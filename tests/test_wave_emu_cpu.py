@@ -363,3 +363,41 @@ def test_emu_attention_shapes_property(emu):
     def i2t(T, N, planes_res, form):
         tk.test_sam_i2t_fused_matches_composition(DEV, T, N, planes_res, form)
     i2t()
+
+
+def test_emu_rpn_selection_property(emu):
+    """rpn_topk -> rpn_decode -> batched NMS (rsp_rpn_topk / _decode / rsp_batched_nms) against the oracle's restatement of
+    RPNHead._predict_by_feat_single (pinned on the real class) on random pyramids: logits quantised so that scores TIE (the
+    kernels' rule: score descending, position ascending = the reference's stable sort), nms_pre below and above the level
+    sizes, the min-size filter on and off, 1-2 images -- (level, anchor) indices must be identical"""
+    from hypothesis import given, settings, strategies as st
+    import torch_ops_mock as mock
+    from rsprompter_amd.anchor_heads import AnchorGenerator, DeltaXYWHBBoxCoder
+
+    @settings(max_examples=20, deadline=None, derandomize=True)
+    @given(st.integers(1, 2), st.integers(2, 12), st.integers(2, 12), st.sampled_from([5, 40, 300, 1000]), st.integers(1, 60),
+           st.sampled_from([-1, 0, 8]), st.integers(1, 12), st.integers(0, 2 ** 31 - 1))
+    def check(B, h0, w0, nms_pre, max_per_img, min_size, levels_q, seed):
+        g = torch.Generator().manual_seed(seed)
+        strides = [4, 8, 16]
+        gen = AnchorGenerator(strides=strides, ratios=[0.5, 1.0, 2.0], scales=[8])
+        base = torch.stack(gen.base_anchors, 0)
+        A, LD = 3, 32
+        sizes = [(h0 * 4, w0 * 4), (h0 * 2, w0 * 2), (h0, w0)]
+        heads = []
+        for (H, W) in sizes:
+            hd = torch.zeros(B * H * W, LD)
+            hd[:, :A] = (torch.randn(B * H * W, A, generator=g) * 2 * levels_q).round() / levels_q      # ties
+            hd[:, A:5 * A] = torch.randn(B * H * W, 4 * A, generator=g) * 0.4
+            heads.append(hd.contiguous())
+        img_hw = torch.tensor([[float(16 * h0), float(16 * w0)]] * B)
+        coder = DeltaXYWHBBoxCoder()
+        args = (base, strides, nms_pre, max_per_img, 0.7, min_size, coder, DEV)
+        got = emu.RpnSelector(*args)(heads, sizes, LD, img_hw)
+        ref = mock.RpnSelector(*args)(heads, sizes, LD, img_hw)
+        for b in range(B):
+            k = int(ref['count'][b])
+            assert int(got['count'][b]) == k
+            assert torch.equal(got['ids'][b, :k], ref['ids'][b, :k]) and torch.equal(got['src'][b, :k], ref['src'][b, :k])
+            assert float((got['boxes'][b, :k] - ref['boxes'][b, :k]).abs().max() if k else 0.0) < 1e-3
+    check()
