@@ -401,3 +401,54 @@ def test_emu_rpn_selection_property(emu):
             assert torch.equal(got['ids'][b, :k], ref['ids'][b, :k]) and torch.equal(got['src'][b, :k], ref['src'][b, :k])
             assert float((got['boxes'][b, :k] - ref['boxes'][b, :k]).abs().max() if k else 0.0) < 1e-3
     check()
+
+
+def test_emu_bbox_post_and_query_topk_property(emu):
+    """softmax + per-class decode + score threshold + multiclass NMS (rsp_bbox_post, rsp_batched_nms) and the fusion head's
+    top-k over (query, class) (rsp_query_topk) on random inputs with DUPLICATED rows (exact score ties: the rule is score
+    descending, flat index ascending) against the oracle's restatements of BBoxHead._predict_by_feat_single /
+    instance_postprocess: same detections (tie-aware matching, tests/_match.py), same flat indices"""
+    from hypothesis import given, settings, strategies as st
+    import torch_ops_mock as mock
+    from _match import match_detections
+    from rsprompter_amd.anchor_heads import DeltaXYWHBBoxCoder
+
+    @settings(max_examples=25, deadline=None, derandomize=True)
+    @given(st.integers(1, 120), st.integers(1, 12), st.sampled_from([0.02, 0.05, 0.3]), st.integers(1, 60), st.integers(0, 2 ** 31 - 1))
+    def bbox(n, nc, thr, max_out, seed):
+        g = torch.Generator().manual_seed(seed)
+        xy = torch.rand(n, 2, generator=g) * 300
+        roi = torch.cat([torch.zeros(n, 1), xy, xy + torch.rand(n, 2, generator=g) * 120 + 2], 1)
+        LD = (5 * nc + 1 + 3) // 4 * 4
+        head = torch.zeros(n, LD)
+        head[:, :nc + 1] = torch.randn(n, nc + 1, generator=g) * 2.5
+        head[:, nc + 1:5 * nc + 1] = torch.randn(n, 4 * nc, generator=g)
+        if n > 3:                                            # duplicated RoIs: identical boxes and scores
+            roi[n // 2] = roi[0]; head[n // 2] = head[0]
+        coder = DeltaXYWHBBoxCoder(target_stds=(0.1, 0.1, 0.2, 0.2))
+        args = (head, LD, roi, torch.tensor([0, n]), torch.tensor([[400., 420.]]), nc, thr, coder, 0.5, max_out)
+        got, ref = emu.bbox_post(*args), mock.bbox_post(*args)
+        k = int(ref['count'][0])
+        assert int(got['count'][0]) == k
+        pairs = match_detections(got['boxes'][0, :k], got['scores'][0, :k], got['ids'][0, :k].long(),
+                                 ref['boxes'][0, :k], ref['scores'][0, :k], ref['ids'][0, :k].long())
+        assert len(pairs) == k
+    bbox()
+
+    @settings(max_examples=25, deadline=None, derandomize=True)
+    @given(st.integers(1, 2), st.integers(1, 60), st.integers(1, 10), st.integers(1, 100), st.integers(0, 2 ** 31 - 1))
+    def topk(B, Nq, nc, k, seed):
+        g = torch.Generator().manual_seed(seed)
+        k = min(k, Nq * nc)
+        cls = torch.randn(B, Nq, nc + 1, generator=g) * 2
+        if Nq > 2:
+            cls[:, Nq - 1] = cls[:, 0]                        # an exact tie between the first and the last query
+        sc, fl = emu.query_topk(cls.contiguous(), k)
+        rs, rf = mock.query_topk(cls, k)
+        assert float((sc - rs).abs().max()) < 1e-6
+        for b in range(B):                                   # equal up to the order inside runs of (numerically) equal scores
+            bad = (fl[b] != rf[b]).nonzero()[:, 0].tolist()
+            for i in bad:
+                j = (rf[b] == fl[b, i]).nonzero()
+                assert j.numel() == 1 and abs(float(rs[b, int(j[0, 0])]) - float(sc[b, i])) < 2e-7, (b, i)
+    topk()
