@@ -452,3 +452,60 @@ def test_emu_bbox_post_and_query_topk_property(emu):
                 j = (rf[b] == fl[b, i]).nonzero()
                 assert j.numel() == 1 and abs(float(rs[b, int(j[0, 0])]) - float(sc[b, i])) < 2e-7, (b, i)
     topk()
+
+
+def test_emu_sampling_kernels_property(emu):
+    """the gather / resample kernels on random geometry against the oracle (the reference's torch calls and the C restatement
+    of mmcv RoIAlign): RoIAlign with RoIs that are tiny, huge, partly or wholly outside the image and on every pyramid level;
+    MSDeformAttn with 1-5 levels of random sizes and offsets that leave the maps; GroupNorm with add / ReLU; bilinear
+    resizing up and down; the query prompter's attention-mask rule incl. fully blocked rows"""
+    from hypothesis import given, settings, strategies as st
+    import torch_ops_mock as mock
+
+    @settings(max_examples=15, deadline=None, derandomize=True)
+    @given(st.integers(1, 40), st.sampled_from([7, 14]), st.integers(0, 2 ** 31 - 1))
+    def roi(K, P, seed):
+        g = torch.Generator().manual_seed(seed)
+        B, C = 2, 8
+        strides, sizes = [4, 8, 16, 32], [(32, 40), (16, 20), (8, 10), (4, 5)]
+        feats = [torch.randn(B, h, w, C, generator=g) for h, w in sizes]
+        pes = [torch.randn(h, w, C, generator=g) if i % 2 == 0 else None for i, (h, w) in enumerate(sizes)]
+        xy = torch.rand(K, 2, generator=g) * 200 - 30                     # some start outside the 128 x 160 image
+        wh = torch.exp(torch.rand(K, 2, generator=g) * 6)                 # 1 .. 400 pixels: every level
+        rois = torch.cat([torch.randint(0, B, (K, 1), generator=g).float(), xy, xy + wh], 1)
+        got, ref = emu.roi_align(feats, pes, rois, P, strides), mock.roi_align(feats, pes, rois, P, strides)
+        assert float((got - ref).abs().max()) < 2e-5
+    roi()
+
+    @settings(max_examples=15, deadline=None, derandomize=True)
+    @given(st.integers(1, 5), st.sampled_from([16, 32]), st.integers(0, 2 ** 31 - 1))
+    def msda(L, hd, seed):
+        g = torch.Generator().manual_seed(seed)
+        shapes = [(int(torch.randint(1, 9, (1,), generator=g)), int(torch.randint(1, 9, (1,), generator=g))) for _ in range(L)]
+        ntok, B, D = sum(h * w for h, w in shapes), 2, 8 * hd
+        value = torch.randn(B * ntok, D, generator=g)
+        ow = torch.cat([torch.randn(B * ntok, 8 * L * 4 * 2, generator=g) * 3, torch.randn(B * ntok, 8 * L * 4, generator=g)], 1).contiguous()
+        ref_pts = torch.rand(ntok, 2, generator=g)
+        got = emu.msdeform_attn(value, ow, ref_pts, B, ntok, shapes, head_dim=hd)
+        assert float((got - mock.msdeform_attn(value, ow, ref_pts, B, ntok, shapes, head_dim=hd)).abs().max()) < 2e-5
+    msda()
+
+    @settings(max_examples=15, deadline=None, derandomize=True)
+    @given(st.integers(1, 3), st.integers(1, 12), st.integers(1, 12), st.integers(1, 20), st.integers(1, 20), st.integers(0, 2 ** 31 - 1))
+    def resample(B, h, w, ho, wo, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = torch.randn(B, h, w, 128, generator=g)
+        assert float((emu.resize_bilinear(x, (ho, wo)) - mock.resize_bilinear(x, (ho, wo))).abs().max()) < 1e-5
+        gam, bet, add = torch.randn(128, generator=g), torch.randn(128, generator=g), torch.randn(B, h * w, 128, generator=g)
+        xs = x.view(B, h * w, 128)
+        assert float((emu.groupnorm(xs, gam, bet, 32, add=add) - mock.groupnorm(xs, gam, bet, 32, add=add)).abs().max()) < 5e-5
+        assert float((emu.groupnorm(xs, gam, bet, 32, relu=True) - mock.groupnorm(xs, gam, bet, 32, relu=True)).abs().max()) < 5e-5
+        mpp = torch.randn(B, 5, h, w, generator=g) * 3
+        mpp[:, 0] = -5.0                                                  # a fully blocked row: cleared (models.py:439-442)
+        a, b = emu.query_attn_mask(mpp.contiguous(), (ho, wo)), mock.query_attn_mask(mpp, (ho, wo))
+        diff = a != b
+        if bool(diff.any()):                                              # only where the resized logit ties with the threshold
+            import torch.nn.functional as F
+            z = F.interpolate(mpp, (ho, wo), mode='bilinear', align_corners=False).flatten(2)
+            assert float(z[diff].abs().max()) < 1e-5
+    resample()
