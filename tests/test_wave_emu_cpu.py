@@ -509,3 +509,34 @@ def test_emu_sampling_kernels_property(emu):
             z = F.interpolate(mpp, (ho, wo), mode='bilinear', align_corners=False).flatten(2)
             assert float(z[diff].abs().max()) < 1e-5
     resample()
+
+
+def test_emu_tiny_sam_encoder_end_to_end(emu, monkeypatch):
+    """The whole SAM ViT encoder path -- patch embedding, a WINDOWED layer (token -> window row maps in the qkv / proj
+    epilogues, bias rows of the padded tokens, window attention with rel-pos inside over 3 x 3 partly padded windows) and a
+    GLOBAL layer (rel-pos kernel, plane-fed attention, S = 32), LayerNorms emitting planes, GELU + plane MLP, the neck's
+    1x1 / 3x3 convolutions with LayerNorm2d -- on the emulator against the HuggingFace SamVisionEncoder: a 2-layer, 128-wide,
+    2-head model at 512 x 512 (the geometry of the *-peft-512 configs), every hidden state and the image embedding"""
+    from oracle import hf_sam
+    from rsprompter_amd import nnutil, sam_encoder
+    from rsprompter_amd.synth import synth_state_dict
+    tiny = dict(hidden=128, depth=2, heads=2, global_idx=(1,), mlp=256)
+    monkeypatch.setitem(nnutil.SAM_ARCH, 'tiny', tiny)
+    if getattr(sam_encoder, 'SAM_ARCH', nnutil.SAM_ARCH) is not nnutil.SAM_ARCH:
+        monkeypatch.setitem(sam_encoder.SAM_ARCH, 'tiny', tiny)
+    monkeypatch.setitem(hf_sam.ARCH, 'tiny', dict(hidden_size=128, num_hidden_layers=2, num_attention_heads=2,
+                                                  global_attn_indexes=[1]))
+    enc = sam_encoder.SamVisionEncoderHIP(arch='tiny', image_size=512, output_hidden_states=True)
+    sd = synth_state_dict(enc, seed=3)
+    enc.load_state_dict(sd)
+    o = hf_sam.build_vision_encoder('tiny', mlp_dim=256, image_size=512)
+    o.load_state_dict(sd, strict=True)
+    x = torch.randn(1, 3, 512, 512, generator=torch.Generator().manual_seed(4))
+    emb_ref, hs_ref = hf_sam.run_vision_encoder(o, x)
+    out = enc(x)
+    emb, hs = out[0], out[1]
+    assert emb.shape == emb_ref.shape and len(hs) == len(hs_ref) == 3
+    errs = [float((h - r).abs().max()) for h, r in zip(hs, hs_ref)]
+    e_emb = float((emb - emb_ref).abs().max())
+    print('tiny encoder on the emulator: hidden states', ['%.1e' % e for e in errs], 'embedding %.1e (range %.1f)' % (e_emb, float(emb_ref.abs().max())))
+    assert max(errs) < 1e-4 and e_emb < 1e-4
