@@ -31,7 +31,7 @@ N_MASK_TOKENS = 4  # num_multimask_outputs + 1
 # `decoder.t2i_fold = True`, or `bench.py --t2i-fold on`) until it has been tuned and the whole GPU suite has run with it.
 T2I_FOLD_DEFAULT = __import__('os').environ.get('RSP_T2I_FOLD', '0') == '1'
 # The upscaler tail as one kernel: emulator-verified, unmeasured -- `bench.py --upscale-fused on` for round 5.
-UPSCALE_FUSED_DEFAULT = False
+UPSCALE_FUSED_DEFAULT = __import__('os').environ.get('RSP_UPSCALE_FUSED', '0') == '1'
 
 
 def _upscale2_k_order():
