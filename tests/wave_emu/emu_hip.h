@@ -138,7 +138,6 @@ struct Wave {
   uint64_t release[WAVE];         // bumped when the lane's rendezvous has been computed
   alignas(64) unsigned char args[WAVE][ARG_BYTES];
   alignas(64) unsigned char res[WAVE][RES_BYTES];
-  uint64_t scalar_res = 0;
 };
 
 struct Block {
@@ -152,7 +151,6 @@ struct Block {
 struct Launch {
   dim3 grid, block;
   uint3_emu block_idx{0, 0, 0};
-  unsigned char* dyn_smem = nullptr;
   std::function<void()> body;
 };
 
@@ -490,7 +488,7 @@ inline int emu_amdgcn_cvt_pk_fp8_f32(float a, float b, int old, bool hi_word) {
 
 // ------------------------------------------------------------------------------------------------ wave collectives
 namespace emu {
-enum { OP_SHFL = 1, OP_BALLOT, OP_RFL, OP_MFMA_F16, OP_TR16, OP_DMA, OP_MFMA_OTHER, OP_LOCKSTEP };
+enum { OP_SHFL = 1, OP_BALLOT, OP_RFL, OP_MFMA_F16, OP_TR16, OP_DMA, OP_LOCKSTEP };
 
 template <class T>
 __attribute__((noinline)) T shfl_generic(T v, int src_lane_rel, int width, int mode) {
@@ -540,9 +538,10 @@ __attribute__((noinline)) inline unsigned long long __ballot(int pred) {
   emu::wave_rendezvous([](emu::Wave& W) {
     uint64_t m = 0;
     for (int l = 0; l < emu::WAVE; ++l) if (emu::lane_in(W, l) && emu::arg_at<int>(W, l)) m |= 1ull << l;
-    W.scalar_res = m;
+    // (per-lane result slots: another diverged group of the wave may be computed before these lanes run again)
+    for (int l = 0; l < emu::WAVE; ++l) if (emu::lane_in(W, l)) emu::res_at<uint64_t>(W, l) = m;
   }, emu::OP_BALLOT, __builtin_return_address(0));
-  return w.scalar_res;
+  return emu::res_at<uint64_t>(w, f.lane);
 }
 __forceinline__ unsigned long long emu_amdgcn_ballot_w64(bool p) { return __ballot(p ? 1 : 0); }
 
@@ -555,9 +554,10 @@ __attribute__((noinline)) T emu_amdgcn_readfirstlane(T v) {
   emu::arg_at<uint64_t>(w, f.lane) = raw;
   emu::wave_rendezvous([](emu::Wave& W) {
     const int first = __builtin_ctzll(W.arrived_mask);
-    W.scalar_res = emu::arg_at<uint64_t>(W, first);
+    const uint64_t v0 = emu::arg_at<uint64_t>(W, first);
+    for (int l = 0; l < emu::WAVE; ++l) if (emu::lane_in(W, l)) emu::res_at<uint64_t>(W, l) = v0;
   }, emu::OP_RFL, __builtin_return_address(0));
-  T out; memcpy(&out, &w.scalar_res, sizeof(T));
+  T out; memcpy(&out, &emu::res_at<uint64_t>(w, f.lane), sizeof(T));
   return out;
 }
 
