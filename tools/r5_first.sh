@@ -28,3 +28,4 @@ for cfg in "base:" "fold:--t2i-fold on" "up:--upscale-fused on" "both:--t2i-fold
 done
 bash tools/gpu_job.sh r5/first "p:both:--t2i-fold on --upscale-fused on"
 timeout 120 python tools/decoder_tail_micro.py 800 10 > $O/decoder_tail_micro.txt 2>&1; echo "[decoder tail micro] rc=$? $(( $(date +%s) - t0 )) s"; cat $O/decoder_tail_micro.txt
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/mfma16_probe tools/probes/mfma16_probe.hip && /tmp/mfma16_probe > $O/mfma16_probe.txt 2>&1; tail -n 2 $O/mfma16_probe.txt
