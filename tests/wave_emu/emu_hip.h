@@ -599,6 +599,42 @@ __attribute__((noinline)) inline emu_f32x16 emu_amdgcn_mfma_f32_32x32x16_f16(emu
   memcpy(&d, w.res[f.lane], 64);
   return d;
 }
+// ---- v_mfma_f32_16x16x32_f16, HYPOTHESISED layout (not yet compared with the device: tools/probes/mfma16_probe.hip is in
+// round 5's first GPU job; no kernel of the library uses this instruction yet):
+// A[m = l % 16][k = 8 (l / 16) + j], B[k = 8 (l / 16) + j][n = l % 16], C / D[m = 4 (l / 16) + r][n = l % 16], r = 0..3
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+__attribute__((noinline)) inline emu_f32x4 emu_amdgcn_mfma_f32_16x16x32_f16(emu_half8 a, emu_half8 b, emu_f32x4 c, int, int, int) {
+  emu::Fiber& f = emu::cur();
+  emu::Wave& w = *f.wave;
+  memcpy(w.args[f.lane], &a, 16);
+  memcpy(w.args[f.lane] + 16, &b, 16);
+  memcpy(w.args[f.lane] + 32, &c, 16);
+  emu::wave_rendezvous([](emu::Wave& W) {
+    if (W.arrived != emu::WAVE) emu::die("MFMA with inactive lanes");
+    static thread_local float A[16][32], B[32][16];
+    for (int l = 0; l < 64; ++l) {
+      const _Float16* pa = reinterpret_cast<const _Float16*>(W.args[l]);
+      const _Float16* pb = reinterpret_cast<const _Float16*>(W.args[l] + 16);
+      for (int j = 0; j < 8; ++j) {
+        A[l & 15][8 * (l >> 4) + j] = (float)pa[j];
+        B[8 * (l >> 4) + j][l & 15] = (float)pb[j];
+      }
+    }
+    for (int l = 0; l < 64; ++l) {
+      const float* pc = reinterpret_cast<const float*>(W.args[l] + 32);
+      float* pd = reinterpret_cast<float*>(W.res[l]);
+      for (int r = 0; r < 4; ++r) {
+        const int m = 4 * (l >> 4) + r, n = l & 15;
+        double s = 0.0;
+        for (int k = 0; k < 32; ++k) s += (double)A[m][k] * (double)B[k][n];
+        pd[r] = (float)((double)pc[r] + s);
+      }
+    }
+  }, emu::OP_MFMA_F16, __builtin_return_address(0));
+  emu_f32x4 d;
+  memcpy(&d, w.res[f.lane], 16);
+  return d;
+}
 #define emu_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(...) (emu::die("mfma_scale f8f6f4 is not emulated"), emu_f32x16{})
 
 // ---- ds_read_b64_tr_b16: inside a 16-lane group lane i supplies the address of four consecutive halves D_i[0..3];
