@@ -84,7 +84,7 @@ def build(sources=None, verbose=False):
     if os.path.exists(lib) and os.path.exists(stamp) and open(stamp).read() == h.hexdigest():
         return lib
     objs = []
-    flags = ['-std=c++17', '-O1', '-g', '-fPIC', '-ffp-contract=off', '-Wno-everything', '-fno-strict-aliasing',
+    flags = ['-std=c++17', '-O2', '-g', '-fPIC', '-ffp-contract=off', '-Wno-everything', '-fno-strict-aliasing',
              '-I', os.path.join(HERE, 'stub'), '-I', CSRC, '-I', os.path.join(ROOT, 'include')]
     for name in sources:
         text = prepass(open(os.path.join(CSRC, name)).read())
