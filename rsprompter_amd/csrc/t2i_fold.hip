@@ -76,7 +76,10 @@ struct T2iFoldP {
 };
 
 // NPE: heads whose PEK term a wave evaluates (its 32 columns h * T + t touch at most 5 heads when T >= 7, else all 8)
-template <int NPE, bool SPREAD>
+// ONEACC: every score product of a tile -- the 16 k-steps of keys . q' and the NPE PEK steps -- accumulates into ONE
+// register block (possible when both products carry the same power-of-two scale; two more blocks pushed the kernel's 256
+// VGPRs over the edge: 365 accumulator <-> vector register moves per tile in the ISA of the three-block form)
+template <int NPE, bool SPREAD, bool ONEACC>
 __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[FNBUF][FBUF_BYTES];
   __shared__ __attribute__((aligned(1024))) unsigned char sQl[FNW * 16 * 1024];      // q' lo fragments: [wave][k-step][lane] x 16 B
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
     // ---- S^T = keys q'^T (two accumulators: even / odd k-steps) and the PEK term, fragment reads one step ahead ----
     f32x16 s0, s1, sp;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; sp[e] = 0.f; }
+    for (int e = 0; e < 16; ++e) { s0[e] = 0.f; if constexpr (!ONEACC) { s1[e] = 0.f; sp[e] = 0.f; } }
     {
       half8_t kfh[2], kfl[2];
       auto kread = [&](int st, half8_t& h8, half8_t& l8) {
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
         } else if constexpr (i + 1 < 16 + NPE) pread(i + 1 - 16, kfh[cur ^ 1], kfl[cur ^ 1]);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (i < 16) {
-          if constexpr ((i & 1) == 0) {
+          if constexpr (ONEACC || (i & 1) == 0) {
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[cur], qh[i], s0, 0, 0, 0);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], qlf[cur], s0, 0, 0, 0);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], qh[i], s0, 0, 0, 0);
@@ -209,6 +212,10 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], qlf[cur], s1, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], qh[i], s1, 0, 0, 0);
           }
+        } else if constexpr (ONEACC) {
+          s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[cur], th[i - 16], s0, 0, 0, 0);
+          s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], tl[i - 16], s0, 0, 0, 0);
+          s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], th[i - 16], s0, 0, 0, 0);
         } else {
           sp = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[cur], th[i - 16], sp, 0, 0, 0);
           sp = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], tl[i - 16], sp, 0, 0, 0);
@@ -227,7 +234,8 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
     float tmax = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      sc[e] = fmaf(s0[e] + s1[e], p.c_main, sp[e] * p.c_pe);
+      if constexpr (ONEACC) sc[e] = s0[e] * p.c_main;
+      else sc[e] = fmaf(s0[e] + s1[e], p.c_main, sp[e] * p.c_pe);
       tmax = fmaxf(tmax, sc[e]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -310,7 +318,7 @@ extern "C" int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo
                                 int32_t variant, rsp_stream_t stream) {
   if (!keys_hi || !keys_lo || !pek_hi || !pek_lo || !qp_hi || !qp_lo || !tqx_hi || !tqx_lo || !u || R < 0 || N <= 0 ||
       (N % FKT) || ncols <= 0 || ncols > 96 || (ncols & 7) || k_rows < (int64_t)R * N || q_rows < (int64_t)R * 96 ||
-      k_rows * 512 > 0x7fffffffLL || (int64_t)N * 256 > 0x7fffffffLL || variant < 0 || variant > 1)
+      k_rows * 512 > 0x7fffffffLL || (int64_t)N * 256 > 0x7fffffffLL || variant < 0 || variant > 3)
     return RSP_EINVAL;
   if (R == 0) return RSP_OK;
   T2iFoldP p;
@@ -327,14 +335,17 @@ extern "C" int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo
   // variant 0: the DMA instructions of the next tile as a burst behind the barrier -- the form that ran on the MI355X in
   // round 4 (2.2 ms per call at R = 800); variant 1: one per k-step between the score MFMAs (verified on the emulator
   // only; a candidate for the next round's measurements)
+  // variants 2 / 3: as 0 / 1 with ONE score accumulator (needs equal scales of the two score products; emulator only)
   const bool five = ncols >= 56;
-  if (variant == 0) {
-    if (five) hipLaunchKernelGGL((sam_t2i_fold_kernel<5, false>), dim3(R), dim3(FNT), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((sam_t2i_fold_kernel<8, false>), dim3(R), dim3(FNT), 0, (hipStream_t)stream, p);
-  } else {
-    if (five) hipLaunchKernelGGL((sam_t2i_fold_kernel<5, true>), dim3(R), dim3(FNT), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((sam_t2i_fold_kernel<8, true>), dim3(R), dim3(FNT), 0, (hipStream_t)stream, p);
-  }
-  RSP_CHECK_LAUNCH();
-  return RSP_OK;
+  const bool one = variant >= 2;
+  if (one && keys_e + qp_e != pek_e + tqx_e) return RSP_EINVAL;
+  const dim3 g(R), b(FNT);
+  hipStream_t s = (hipStream_t)stream;
+#define T2I_CASE(V, NPE_, SP_, ONE_) if (variant == V && five == (NPE_ == 5)) { hipLaunchKernelGGL((sam_t2i_fold_kernel<NPE_, SP_, ONE_>), g, b, 0, s, p); RSP_CHECK_LAUNCH(); return RSP_OK; }
+  T2I_CASE(0, 5, false, false) T2I_CASE(0, 8, false, false)
+  T2I_CASE(1, 5, true, false) T2I_CASE(1, 8, true, false)
+  T2I_CASE(2, 5, false, true) T2I_CASE(2, 8, false, true)
+  T2I_CASE(3, 5, true, true) T2I_CASE(3, 8, true, true)
+#undef T2I_CASE
+  return RSP_EINVAL;
 }

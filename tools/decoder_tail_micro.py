@@ -1,7 +1,7 @@
 """The per-RoI passes of the SAM mask decoder at the bench shape (R = 800 prompt sets x 4096 keys x 256 channels): ms per call
-of the token -> image attention in its projected form (K | V GEMM + sam_t2i_kernel), folded (csrc/t2i_fold.hip, variants 0 /
-1), and of the upscaler tail as two kernels (ConvTranspose GEMM with its LayerNorm epilogue + sam_upscale2_kernel) and as one
-(sam_upscale_fused_kernel).  The folded variant 1 and the fused upscaler have been verified on the lane-level emulator only
+of the token -> image attention in its projected form (K | V GEMM + sam_t2i_kernel), folded (csrc/t2i_fold.hip, variants 0 -
+3), and of the upscaler tail as two kernels (ConvTranspose GEMM with its LayerNorm epilogue + sam_upscale2_kernel) and as one
+(sam_upscale_fused_kernel).  The folded variants 1 - 3 and the fused upscaler have been verified on the lane-level emulator only
 (tests/test_wave_emu_cpu.py): this tool is their first timing.
 
   python tools/decoder_tail_micro.py [R] [iters]        one line per form (R <= 1023: the folded kernel's 32-bit offsets)
@@ -67,6 +67,8 @@ def main(dev=None, R=800, iters=10, h=64, w=64, T=10):
     for name, fn in (('token -> image: K | V GEMM + sam_t2i_kernel', projected),
                      ('token -> image: folded, variant 0 (DMA burst; measured in round 4)', lambda: folded(0)),
                      ('token -> image: folded, variant 1 (DMA spread between the MFMAs)', lambda: folded(1)),
+                     ('token -> image: folded, variant 2 (burst, one score accumulator)', lambda: folded(2)),
+                     ('token -> image: folded, variant 3 (spread, one score accumulator)', lambda: folded(3)),
                      ('upscaler tail: ConvT GEMM + LN epilogue, then sam_upscale2_kernel', two_kernels),
                      ('upscaler tail: sam_upscale_fused_kernel', fused)):
         ms = timed(fn, iters, dev)
