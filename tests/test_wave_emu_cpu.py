@@ -511,6 +511,42 @@ def test_emu_sampling_kernels_property(emu):
     resample()
 
 
+def test_emu_decoder_tail_kernels_property(emu):
+    """the two opt-in kernels of the SAM decoder's per-RoI passes on random geometry: the folded token -> image attention
+    (every variant; 1-12 tokens = both head-count instantiations, key counts of 1-5 tiles) against fp64 and the unfolded
+    kernels, and the fused upscaler tail against the two-kernel form for h != w, RoI sizes that are no multiple of the
+    128-row tile, and a single RoI smaller than one tile"""
+    from hypothesis import given, settings, strategies as st
+    from rsprompter_amd import ops
+    from rsprompter_amd.sam_decoder import SamMaskDecoderHIP
+    from rsprompter_amd.synth import synth_state_dict
+    import test_gpu_kernels as tk
+
+    @settings(max_examples=16, deadline=None, derandomize=True)
+    @given(st.integers(1, 3), st.sampled_from([32, 64, 96, 160]), st.integers(1, 12))
+    def fold(R, N, T):
+        tk.test_sam_t2i_fold_matches_fp64_attention(DEV, R, N, T)
+    fold()
+
+    dec = SamMaskDecoderHIP()
+    dec.load_state_dict(synth_state_dict(dec, 3))
+    dec._pack()
+    P, ln = dec._packed, dec.upscale_layer_norm
+
+    @settings(max_examples=30, deadline=None, derandomize=True)
+    @given(st.integers(1, 3), st.integers(1, 13), st.integers(1, 13), st.integers(0, 2 ** 31 - 1))
+    def upscaler(R, h, w, seed):
+        g = torch.Generator().manual_seed(seed)
+        x = ops.to_planes(torch.randn(R * h * w, 256, generator=g) * 1.5)
+        hy = torch.randn(R, 32, generator=g)
+        up = ops.conv_transpose2x2(x.view(R, h, w, 256), *P['up1'], act=ops.ACT_GELU, ln=(ln.weight, ln.bias, 1e-6))
+        two = ops.conv_transpose2x2(up, *P['up2'], act=ops.ACT_GELU, hyper=hy)
+        one = ops.sam_upscale_fused(x, P['up1'][0], P['up1'][1], ln.weight, ln.bias, 1e-6, P['up2p'][0], P['up2p'][1], hy, h, w)
+        assert one.shape == two.shape == (R, 4 * h, 4 * w)
+        assert float((one - two).abs().max()) < 2e-5 * max(1.0, float(two.abs().max()))
+    upscaler()
+
+
 def test_emu_tiny_sam_encoder_end_to_end(emu, monkeypatch):
     """The whole SAM ViT encoder path -- patch embedding, a WINDOWED layer (token -> window row maps in the qkv / proj
     epilogues, bias rows of the padded tokens, window attention with rel-pos inside over 3 x 3 partly padded windows) and a
