@@ -326,6 +326,9 @@ def main():
                          '(csrc/t2i_fold.hip); default: the library default (rsprompter_amd.sam_decoder.T2I_FOLD_DEFAULT)')
     ap.add_argument('--upscale-fused', dest='upscale_fused', choices=['on', 'off'], default=None,
                     help='the SAM upscaler tail as one kernel (csrc/upscale.hip sam_upscale_fused_kernel, DESIGN 4.3c)')
+    ap.add_argument('--encoder-graph', dest='encoder_graph', choices=['on', 'off'], default=None,
+                    help="replay the SAM encoder's launch sequence as a captured hipGraph in the timed steps "
+                         '(rsprompter_amd.sam_encoder._EncoderGraph; the roofline leg stays eager: per-kernel events)')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -355,6 +358,9 @@ def main():
     if args.upscale_fused is not None:
         import rsprompter_amd.sam_decoder as _sd2
         _sd2.UPSCALE_FUSED_DEFAULT = args.upscale_fused == 'on'
+    if args.encoder_graph is not None:
+        import rsprompter_amd.sam_encoder as _se
+        _se.ENCODER_GRAPH_DEFAULT = args.encoder_graph == 'on'
     from rsprompter_amd.structures import DetDataSample
     from rsprompter_amd.synth import synth_images, synth_metas
     import torch.distributed as tdist
@@ -453,6 +459,9 @@ def main():
         relpos_ms = sum(v['ms'] for k, v in agg.items() if k.startswith('vit_relpos'))
         attn_tf_rel = sum(v['flops'] for v in attn) / (attn_ms + relpos_ms) / 1e9 if attn_ms else None
         value = world * B * args.steps / elapsed
+        # non-default code paths of this run (absent = the defaults of the library)
+        opt_in = {k: v for k, v in (('t2i_fold', args.t2i_fold), ('upscale_fused', args.upscale_fused),
+                                    ('encoder_graph', args.encoder_graph)) if v is not None}
         result = {
             'metric': 'images/sec (1024x1024 synthetic tiles, rsprompter_%s SAM-ViT-%s%s, full predict path)' % (
                 args.model, args.arch[0].upper(), ' + LoRA' if args.lora else ''),
@@ -465,7 +474,8 @@ def main():
             'config': {'workload': f'rsprompter_{args.model} SAM-ViT-{args.arch}' + (' + LoRA(qkv r16)' if args.lora else '') + f', batch {B}x1024x1024 per GPU, '
                                    f'{num_classes} classes, seeded synthetic weights' + _config_tag(args, B, world),
                        'images_per_gpu_per_step': B, 'detections_per_step_rank0': n_dets,
-                       'parallelism': f'dp{world} (images sharded by batch, result gather to rank 0 over RCCL)' if world > 1 else 'single GPU'},
+                       'parallelism': f'dp{world} (images sharded by batch, result gather to rank 0 over RCCL)' if world > 1 else 'single GPU',
+                       **({'opt_in': opt_in} if opt_in else {})},
             'roofline': {'bound': 'mfma', 'kernel': dom_name, 'launches_per_step': dom['calls'],
                          'ms_per_step': round(dom['ms'], 3), 'achieved': round(achieved, 2),
                          'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4),

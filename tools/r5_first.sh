@@ -1,7 +1,7 @@
 #!/bin/bash
 # First GPU call of round 5: the kernels round 4 finished on the lane-level emulator after its GPU budget was spent.
 #   1. their first run on an MI355X (tests that are skipped until RSP_UNMEASURED=1),
-#   2. the bench with each of them on / off on the same box (A/B),
+#   2. the bench with each of them on / off on the same box (A/B), incl. the encoder replayed as a hipGraph,
 #   3. rocprofv3 kernel statistics of the bench with all of them on.
 # Usage: gpurun --timeout 600 -- 'bash tools/r5_first.sh'; results in gpurun_out/r5/first/.
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
@@ -18,12 +18,18 @@ except Exception as e:
     print('no bench line:', e)
 PY
 }
-RSP_UNMEASURED=1 timeout 200 python -m pytest -m gpu -q -s tests/test_gpu_baseline_configs.py tests/test_gpu_kernels.py \
-  -k "unmeasured or t2i_fold or folded_token" > $O/unmeasured.log 2>&1
+RSP_UNMEASURED=1 timeout 300 python -m pytest -m gpu -q -s tests/test_gpu_baseline_configs.py tests/test_gpu_kernels.py \
+  tests/test_gpu_encoder.py -k "unmeasured or t2i_fold or folded_token or graph_replay" > $O/unmeasured.log 2>&1
 echo "[first GPU run of the emulator-verified kernels] rc=$? $(( $(date +%s) - t0 )) s: $(tail -n 1 $O/unmeasured.log)"
 for cfg in "base:" "fold:--t2i-fold on" "up:--upscale-fused on" "both:--t2i-fold on --upscale-fused on"; do
   name=${cfg%%:*}; flags=${cfg#*:}
   timeout 90 python bench.py --no-cpu-baseline $flags > $O/bench_$name.json 2> $O/bench_$name.err
+  echo "[bench $name] rc=$? $(( $(date +%s) - t0 )) s: $(line $O/bench_$name.json)"
+done
+# the encoder as a replayed hipGraph: ViT-H (GPU-bound: expect no change) and ViT-B at batch 8 (configs[1]: interpreter-bound)
+for cfg in "graph_h:--encoder-graph on" "b8:--arch base" "graph_b8:--arch base --encoder-graph on"; do
+  name=${cfg%%:*}; flags=${cfg#*:}
+  timeout 120 python bench.py --no-cpu-baseline $flags > $O/bench_$name.json 2> $O/bench_$name.err
   echo "[bench $name] rc=$? $(( $(date +%s) - t0 )) s: $(line $O/bench_$name.json)"
 done
 bash tools/gpu_job.sh r5/first "p:both:--t2i-fold on --upscale-fused on"
