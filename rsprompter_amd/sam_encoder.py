@@ -225,12 +225,16 @@ class SamVisionEncoderHIP(HIPModule):
         want_hidden = bool(self.output_hidden_states if output_hidden_states is None else output_hidden_states)
         # graph replay: only on a device, outside a capture of the caller's, and not under bench.py's per-kernel event
         # profiler (events recorded inside a capture carry no time)
-        if self.graph and pixel_values.is_cuda and ops._prof is None and not torch.cuda.is_current_stream_capturing():
+        if self.graph and self._graph_allowed(pixel_values):
             key = (B, want_hidden, str(pixel_values.device), pixel_values.dtype)
             if key not in self._graphs:
                 self._graphs[key] = _EncoderGraph(self, pixel_values, want_hidden)
             return self._graphs[key](pixel_values)
         return self._run(pixel_values, want_hidden)
+
+    @staticmethod
+    def _graph_allowed(pixel_values):
+        return pixel_values.is_cuda and ops._prof is None and not torch.cuda.is_current_stream_capturing()
 
     def _run(self, pixel_values, want_hidden):
         """the launch sequence: no host synchronisation, no host-side decision that depends on device data"""
