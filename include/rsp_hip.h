@@ -473,7 +473,7 @@ typedef struct RspMaskEmbedDesc {
   int32_t R, he, we, C;
   float eps;
 } RspMaskEmbedDesc;
-int rsp_sam_mask_embed(const RspMaskEmbedDesc* d, rsp_stream_t stream);
+int rsp_sam_mask_embed(const RspMaskEmbedDesc* d, rsp_stream_t stream);   /* C % 256 == 0, else RSP_EINVAL */
 /* maskformer_fusion_head.py:149-162: softmax(cls)[:, :-1], top-k over Nq*nc, (score desc, index asc)        */
 int rsp_query_topk(const float* cls, int32_t B, int32_t Nq, int32_t nc, int32_t k, float* out_score,
                    int32_t* out_flat, rsp_stream_t stream);

@@ -568,8 +568,8 @@ extern "C" int rsp_query_attn_mask(const float* mask_pred_plus, uint8_t* mask, i
 
 extern "C" int rsp_sam_mask_embed(const RspMaskEmbedDesc* d, rsp_stream_t stream) {
   if (!d || !d->mask_pred_plus || !d->image_embeddings || !d->roi_img || !d->out || d->R <= 0 || d->he <= 0 || d->we <= 0 ||
-      d->C <= 0 || (d->C & 3))
-    return RSP_EINVAL;
+      d->C <= 0 || (d->C & 255))      // a round of the output loop = 64 lanes x 4 channels, and its pixel broadcast is a wave
+    return RSP_EINVAL;                // shuffle: every lane has to take part in every round (SAM: C = 256)
   MaskEmbP p;
   p.mpp = d->mask_pred_plus; p.emb = d->image_embeddings; p.roi_img = d->roi_img;
   p.w1 = d->conv1_w; p.b1 = d->conv1_b; p.g1 = d->ln1_w; p.be1 = d->ln1_b;

@@ -112,8 +112,12 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _is_device(t):
+    return t.is_cuda
+
+
 def _chk_f32(t, name):
-    if t.dtype != torch.float32 or not t.is_cuda:
+    if t.dtype != torch.float32 or not _is_device(t):
         raise ValueError(f"{name}: expected a float32 CUDA/HIP tensor, got {t.dtype} on {t.device}")
 
 
@@ -615,7 +619,7 @@ def resize_pad(img_hwc, new_hw, pad_hw, pad_val=(0.0, 0.0, 0.0), out=None, norma
     fp32 [3, Hp, Wp] (see rsp_resize_pad).  normalise = (mean3, std3, swap_rb) fuses the DetDataPreprocessor step."""
     import ctypes
     lib = _lib.load()
-    if img_hwc.dim() != 3 or img_hwc.shape[2] != 3 or not img_hwc.is_cuda:
+    if img_hwc.dim() != 3 or img_hwc.shape[2] != 3 or not _is_device(img_hwc):
         raise ValueError('resize_pad expects an [H, W, 3] device tensor')
     im = img_hwc.contiguous()
     if im.dtype != torch.uint8:

@@ -84,7 +84,9 @@ class _EncoderGraph:
                 enc._run(self.inp, want_hidden)
         cur.wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads of the process (the RCCL watchdog polling its events, a data loader) keep working
+        # during the capture; calls that would break it from THIS thread still raise
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.out = enc._run(self.inp, want_hidden)
 
     def __call__(self, pixel_values):

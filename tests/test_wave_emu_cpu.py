@@ -123,6 +123,11 @@ SWEEP = [
     ('test_gpu_query', 'test_query_kernels_unit', ()),
     ('test_gpu_samdet', 'test_bbox_post_matches_real_bbox_head_with_and_without_rescale', ()),
     ('test_gpu_samdet', 'test_resnet_leaf_kernels', ()),
+    ('test_gpu_samdet', 'test_box_prompt_mask_post_and_scale_boxes', ()),     # box prompts' sin / cos, mask_post_logits
+    ('test_gpu_apis', 'test_resize_pad_kernel_matches_cv2_restatement', ()),
+    ('test_gpu_kernels', 'test_vit_attention', (14, 2, 80, 3)),               # the fp32-fed attention entry points
+    ('test_gpu_kernels', 'test_vit_attention', (32, 1, 80, 2)),               # ... global form (K | V split kernel + DMA ring)
+    ('test_gpu_query', 'test_fusion_head_rescale_paths', ()),
     ('test_gpu_samseg', 'test_paste_masks_kernel_matches_reference_vectors', ()),
     ('test_gpu_dist', 'test_pack_masks_matches_numpy', ()),
     ('test_gpu_dist', 'test_mask_rle_matches_coco_restatement', ()),          # byte-equal to the reference's COCO strings
@@ -545,6 +550,87 @@ def test_emu_decoder_tail_kernels_property(emu):
         assert one.shape == two.shape == (R, 4 * h, 4 * w)
         assert float((one - two).abs().max()) < 2e-5 * max(1.0, float(two.abs().max()))
     upscaler()
+
+
+def test_emu_query_prompt_kernels_property(emu):
+    """SamMaskEmbedding of the query prompter (mask_embed_kernel: two stride-2 convolutions with LayerNorm2d + GELU, a 1x1
+    convolution, + the image embedding of the prompt set's image; models.py:305, HF:569-601) and the row gather, on random
+    geometry against the reference's torch calls"""
+    from hypothesis import given, settings, strategies as st
+    import torch_ops_mock as mock
+
+    @settings(max_examples=12, deadline=None, derandomize=True)
+    @given(st.integers(1, 5), st.integers(1, 2), st.integers(1, 10), st.integers(1, 10), st.sampled_from([256, 512]),
+           st.integers(0, 2 ** 31 - 1))
+    def embed(R, B, he, we, C, seed):
+        g = torch.Generator().manual_seed(seed)
+        rn = lambda *sh: torch.randn(*sh, generator=g)
+        prm = dict(conv1_w=rn(4, 1, 2, 2), conv1_b=rn(4), ln1_w=rn(4), ln1_b=rn(4), conv2_w=rn(16, 4, 2, 2) * 0.5, conv2_b=rn(16),
+                   ln2_w=rn(16), ln2_b=rn(16), conv3_w=rn(C, 16) * 0.3, conv3_b=rn(C))
+        mpp = rn(R, 4 * he, 4 * we) * 4
+        emb = rn(B * he * we, C)
+        roi_img = torch.randint(0, B, (R,), generator=g).to(torch.int32)
+        got, ref = emu.sam_mask_embed(mpp, emb, roi_img, prm, he, we), mock.sam_mask_embed(mpp, emb, roi_img, prm, he, we)
+        assert got.shape == ref.shape and float((got - ref).abs().max()) < 5e-5 * max(1.0, float(ref.abs().max()))
+    embed()
+    # a channel count that would leave lanes out of the output loop's wave shuffle is refused (this test found that
+    # C = 32 gave wrong rows for every pixel beyond the 8th; the reference only has C = 256)
+    g = torch.Generator().manual_seed(0)
+    prm = dict(conv1_w=torch.randn(4, 1, 2, 2), conv1_b=torch.randn(4), ln1_w=torch.randn(4), ln1_b=torch.randn(4),
+               conv2_w=torch.randn(16, 4, 2, 2), conv2_b=torch.randn(16), ln2_w=torch.randn(16), ln2_b=torch.randn(16),
+               conv3_w=torch.randn(32, 16), conv3_b=torch.randn(32))
+    with pytest.raises(RuntimeError):
+        emu.sam_mask_embed(torch.randn(2, 12, 12), torch.randn(9, 32), torch.zeros(2, dtype=torch.int32), prm, 3, 3)
+
+    @settings(max_examples=20, deadline=None, derandomize=True)
+    @given(st.integers(1, 50), st.integers(0, 70), st.sampled_from([4, 32, 100, 256]), st.integers(0, 2 ** 31 - 1))
+    def gather(n_src, n_idx, C, seed):
+        g = torch.Generator().manual_seed(seed)
+        src = torch.randn(n_src, C, generator=g)
+        idx = torch.randint(0, n_src, (n_idx,), generator=g).to(torch.int32)
+        if n_idx == 0:
+            return
+        assert torch.equal(emu.gather_rows(src, idx), src[idx.long()])
+    gather()
+
+
+def test_emu_first_generation_entry_points(emu):
+    """the entry points include/rsp_hip.h keeps for ABI compatibility and rsprompter_amd/ no longer calls: the natural-layout
+    split (its own kernel) against its definition, and the forms that forward to their successors (rsp_vit_relpos ->
+    _q -> _rows, rsp_vit_attention -> _ex, rsp_msdeform_attn -> _ex) against the successor's result through the wrappers"""
+    from rsprompter_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(4)
+    x = torch.cat([torch.randn(1000, generator=g) * 3, torch.tensor([0.0, 1e-9, 7e4, -7e4, 65504.0 / 64])])
+    hi, lo = torch.empty(x.numel(), dtype=torch.float16), torch.empty(x.numel(), dtype=torch.float16)
+    _lib.check(lib.rsp_split_f16(x.data_ptr(), hi.data_ptr(), lo.data_ptr(), x.numel(), 6, 0), 'rsp_split_f16')
+    xs = x * 64.0
+    want_hi = xs.clamp(-65504.0, 65504.0).to(torch.float16)
+    want_lo = (xs - want_hi.float()).clamp(-65504.0, 65504.0).to(torch.float16)
+    assert torch.equal(hi, want_hi) and torch.equal(lo, want_lo)
+    Bp, S, nh, dh = 2, 14, 2, 64
+    qkv = torch.randn(Bp, S * S, 3, nh, dh, generator=g).contiguous()
+    rph, rpw = torch.randn(2 * S - 1, dh, generator=g) * 0.2, torch.randn(2 * S - 1, dh, generator=g) * 0.2
+    rel = emu.vit_relpos(qkv, rph, rpw, Bp, S, nh, dh)
+    rel1 = torch.empty_like(rel)
+    _lib.check(lib.rsp_vit_relpos(qkv.data_ptr(), rph.data_ptr(), rpw.data_ptr(), rel1.data_ptr(), Bp, S, nh, dh, 0), 'rsp_vit_relpos')
+    assert torch.equal(rel, rel1)
+    out = emu.vit_attention(qkv, rel, Bp, S, nh, dh, dh ** -0.5)
+    out1 = torch.empty_like(out)
+    _lib.check(lib.rsp_vit_attention(qkv.data_ptr(), rel.data_ptr(), out1.data_ptr(), Bp, S, nh, dh, dh ** -0.5, 0), 'rsp_vit_attention')
+    assert torch.equal(out, out1)
+    shapes = [(3, 4), (6, 5)]
+    ntok, B = sum(h * w for h, w in shapes), 2
+    value = torch.randn(B * ntok, 128, generator=g)
+    ow = torch.randn(B * ntok, 8 * 2 * 4 * 3, generator=g).contiguous()
+    ref_pts = torch.rand(ntok, 2, generator=g)
+    got = emu.msdeform_attn(value, ow, ref_pts, B, ntok, shapes)
+    got1 = torch.empty_like(got)
+    import ctypes
+    hw = (ctypes.c_int * (2 * len(shapes)))(*[v for s_ in shapes for v in s_])
+    _lib.check(lib.rsp_msdeform_attn(value.data_ptr(), ow.data_ptr(), ow.shape[1], ref_pts.data_ptr(), got1.data_ptr(), B, ntok,
+                                     len(shapes), hw, 0), 'rsp_msdeform_attn')
+    assert torch.equal(got, got1)
 
 
 def test_emu_tiny_sam_encoder_end_to_end(emu, monkeypatch):

@@ -24,8 +24,31 @@ def load_emu():
             fn = getattr(lib, name)        # every symbol of include/rsp_hip.h must exist in the emulated build too
             fn.restype, fn.argtypes = res, args
         lib.emu_set_lazy_dma.argtypes = [ctypes.c_int]
+        if os.environ.get('RSP_WAVE_EMU_COUNT'):
+            lib = _Counting(lib, os.environ['RSP_WAVE_EMU_COUNT'])
         _EMU = lib
     return _EMU
+
+
+class _Counting:
+    """RSP_WAVE_EMU_COUNT=<file>: calls per C entry point, appended to <file> as `pid name count` lines when the process
+    ends (which entry points of include/rsp_hip.h does the emulator suite execute: profiles/r4_emu_entry_point_coverage.txt)"""
+
+    def __init__(self, lib, path):
+        import atexit
+        self.__dict__['_lib'], self.__dict__['_n'] = lib, {}
+        atexit.register(lambda: open(path, 'a').writelines(f'{os.getpid()} {k} {v}\n' for k, v in sorted(self._n.items())))
+
+    def __getattr__(self, name):
+        fn = getattr(self._lib, name)
+        if not name.startswith('rsp_'):
+            return fn
+
+        def call(*a):
+            self._n[name] = self._n.get(name, 0) + 1
+            return fn(*a)
+        self.__dict__[name] = call
+        return call
 
 
 @contextlib.contextmanager
@@ -47,7 +70,7 @@ def emulated_ops():
     from rsprompter_amd import _lib, ops
     lib = load_emu()
     import torch
-    saved = (_lib._lib, ops._stream, ops._chk_f32, ops.require_device)
+    saved = (_lib._lib, ops._stream, ops._chk_f32, ops.require_device, ops._is_device)
     saved_sync = torch.cuda.synchronize
     _lib._lib = lib
     torch.cuda.synchronize = lambda *a, **k: None          # launches complete before they return
@@ -56,10 +79,10 @@ def emulated_ops():
         import torch
         if t.dtype != torch.float32:
             raise ValueError(f'{name}: expected float32')
-    ops._stream, ops._chk_f32, ops.require_device = (lambda: 0), chk, (lambda dev: None)
+    ops._stream, ops._chk_f32, ops.require_device, ops._is_device = (lambda: 0), chk, (lambda dev: None), (lambda t: True)
     lib.emu_set_lazy_dma(1 if os.environ.get('RSP_WAVE_EMU_LAZY') == '1' else 0)     # audit mode: see lazy_dma()
     try:
         yield ops
     finally:
-        _lib._lib, ops._stream, ops._chk_f32, ops.require_device = saved
+        _lib._lib, ops._stream, ops._chk_f32, ops.require_device, ops._is_device = saved
         torch.cuda.synchronize = saved_sync
