@@ -162,6 +162,7 @@ def test_emu_dma_kernels_with_latest_possible_completion(emu):
         tk.test_plane_gemm_tile_variants(DEV, 1)
         tk.test_vit_window_attention_fused_relpos(DEV, 3, 4, 2, 80, 1, 1)
         tk.test_vit_attention_planes(DEV, 32, 2, 64, 2)
+        tk.test_vit_attention(DEV, 32, 1, 80, 2)                      # attn_global_kernel's K | V^T ring (fp32-fed entry point)
         tk.test_sam_t2i_fold_matches_fp64_attention(DEV, 3, 64, 10)
 
 
