@@ -181,7 +181,10 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) { s0[e] = 0.f; if constexpr (!ONEACC) { s1[e] = 0.f; sp[e] = 0.f; } }
     {
-      half8_t kfh[2], kfl[2];
+      // fragment reads run LA k-steps ahead of their MFMAs through a ring of LA + 1 register sets: one step (= 3 MFMAs, ~100
+      // cycles) in the measured form, two in the one-accumulator form (the 32 registers it frees pay for the third set)
+      constexpr int LA = ONEACC ? 2 : 1, NB = LA + 1;
+      half8_t kfh[NB], kfl[NB];
       auto kread = [&](int st, half8_t& h8, half8_t& l8) {
         const int off = k_row_off + (((2 * st + hh) ^ k_swz) << 4);
         h8 = *reinterpret_cast<const half8_t*>(sK0 + off);
@@ -192,15 +195,18 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
         h8 = *reinterpret_cast<const half8_t*>(sP0 + off);
         l8 = *reinterpret_cast<const half8_t*>(sP1 + off);
       };
-      half8_t qlf[2];
-      kread(0, kfh[0], kfl[0]);
-      qlf[0] = *reinterpret_cast<const half8_t*>(my_ql);
+      half8_t qlf[NB];
+      auto fetch = [&](auto jc) {                       // the operands of k-step j into ring slot j % NB
+        constexpr int j = decltype(jc)::value, sl = j % NB;
+        if constexpr (j < 16) {
+          kread(j, kfh[sl], kfl[sl]);
+          qlf[sl] = *reinterpret_cast<const half8_t*>(my_ql + j * 1024);
+        } else if constexpr (j < 16 + NPE) pread(j - 16, kfh[sl], kfl[sl]);
+      };
+      static_for_f<0, LA>([&](auto jc) { fetch(jc); });
       static_for_f<0, 16 + NPE>([&](auto ic) {
-        constexpr int i = decltype(ic)::value, cur = i & 1;
-        if constexpr (i + 1 < 16) {
-          kread(i + 1, kfh[cur ^ 1], kfl[cur ^ 1]);
-          qlf[cur ^ 1] = *reinterpret_cast<const half8_t*>(my_ql + (i + 1) * 1024);
-        } else if constexpr (i + 1 < 16 + NPE) pread(i + 1 - 16, kfh[cur ^ 1], kfl[cur ^ 1]);
+        constexpr int i = decltype(ic)::value, cur = i % NB;
+        fetch(std::integral_constant<int, i + LA>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (i < 16) {
           if constexpr (ONEACC || (i & 1) == 0) {
@@ -335,7 +341,8 @@ extern "C" int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo
   // variant 0: the DMA instructions of the next tile as a burst behind the barrier -- the form that ran on the MI355X in
   // round 4 (2.2 ms per call at R = 800); variant 1: one per k-step between the score MFMAs (verified on the emulator
   // only; a candidate for the next round's measurements)
-  // variants 2 / 3: as 0 / 1 with ONE score accumulator (needs equal scales of the two score products; emulator only)
+  // variants 2 / 3: as 0 / 1 with ONE score accumulator (needs equal scales of the two score products) and the fragment
+  // reads TWO k-steps ahead of their MFMAs instead of one (emulator only)
   const bool five = ncols >= 56;
   const bool one = variant >= 2;
   if (one && keys_e + qp_e != pek_e + tqx_e) return RSP_EINVAL;

@@ -67,8 +67,8 @@ def main(dev=None, R=800, iters=10, h=64, w=64, T=10):
     for name, fn in (('token -> image: K | V GEMM + sam_t2i_kernel', projected),
                      ('token -> image: folded, variant 0 (DMA burst; measured in round 4)', lambda: folded(0)),
                      ('token -> image: folded, variant 1 (DMA spread between the MFMAs)', lambda: folded(1)),
-                     ('token -> image: folded, variant 2 (burst, one score accumulator)', lambda: folded(2)),
-                     ('token -> image: folded, variant 3 (spread, one score accumulator)', lambda: folded(3)),
+                     ('token -> image: folded, variant 2 (burst, one score accumulator, reads 2 steps ahead)', lambda: folded(2)),
+                     ('token -> image: folded, variant 3 (spread, one score accumulator, reads 2 steps ahead)', lambda: folded(3)),
                      ('upscaler tail: ConvT GEMM + LN epilogue, then sam_upscale2_kernel', two_kernels),
                      ('upscaler tail: sam_upscale_fused_kernel', fused)):
         ms = timed(fn, iters, dev)
