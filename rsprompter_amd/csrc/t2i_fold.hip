@@ -77,8 +77,9 @@ struct T2iFoldP {
 
 // NPE: heads whose PEK term a wave evaluates (its 32 columns h * T + t touch at most 5 heads when T >= 7, else all 8)
 // ONEACC: every score product of a tile -- the 16 k-steps of keys . q' and the NPE PEK steps -- accumulates into ONE
-// register block (possible when both products carry the same power-of-two scale; two more blocks pushed the kernel's 256
-// VGPRs over the edge: 365 accumulator <-> vector register moves per tile in the ISA of the three-block form)
+// register block (possible when both products carry the same power-of-two scale): 32 registers less, 32 VALU instructions
+// and 32 accumulator <-> vector moves less per tile, no scratch in any instantiation; the freed registers hold a third set
+// of score fragments, so that the LDS reads run two k-steps ahead of their MFMAs (LA below)
 template <int NPE, bool SPREAD, bool ONEACC>
 __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[FNBUF][FBUF_BYTES];
