@@ -367,7 +367,7 @@ int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo, int64_t k
                      const uint16_t* qp_lo, int32_t qp_e, const uint16_t* tqx_hi, const uint16_t* tqx_lo,
                      int32_t tqx_e, int64_t q_rows, float* u, int32_t R, int32_t N, int32_t ncols,
                      int32_t variant /* 0 = the form measured in round 4; 1 = DMA issue spread between the MFMAs; 2 / 3 = 0 / 1 with one
-                                        score accumulator and LDS reads two k-steps ahead (need keys_e + qp_e == pek_e +
+                                        score accumulator, LDS reads two k-steps ahead, value-side reads in front of the softmax (need keys_e + qp_e == pek_e +
                                         tqx_e, else RSP_EINVAL); 1-3 unmeasured */,
                      rsp_stream_t stream);
 

@@ -236,6 +236,27 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
       });
     }
 
+    // keys^T fragments for U^T += keys^T P^T come through the transposing read of the SAME image, VLA steps ahead of their
+    // MFMAs; in the one-accumulator form the first VLA sets are requested HERE, in front of the softmax (~600 cycles of
+    // VALU work with nothing else to hide behind on a single-wave SIMD), in the measured form after it
+    typedef __attribute__((address_space(3))) v4s_f* lv4;
+    constexpr int VLA = (ONEACC && NPE == 5) ? 2 : 1, VNB = VLA + 1;      // (NPE = 8 has no registers left for a third set)
+    v4s_f va[VNB][4];
+    auto vread = [&](int s_, int db, v4s_f* f) {
+      const int row0 = 16 * s_ + v_row;
+      const int c = 4 * db + v_c;
+      const int a0 = row0 * (FKCPR * 16) + ((c ^ hh) << 4) + v_b;                     // (row >> 2) & 3 == hh
+      const int a1 = (row0 + 8) * (FKCPR * 16) + ((c ^ ((hh + 2) & 3)) << 4) + v_b;   // ... == (hh + 2) & 3
+      f[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sK0 + a0));
+      f[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sK0 + a1));
+      f[2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sK1 + a0));
+      f[3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sK1 + a1));
+    };
+    if constexpr (ONEACC) {
+      static_for_f<0, VLA>([&](auto jc) { constexpr int j = decltype(jc)::value; vread(j / 8, j % 8, va[j % VNB]); });
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
     // ---- online softmax in the log2 domain: this lane's query column, 16 of the tile's 32 keys per half wave ----
     float sc[16];
     float tmax = -INFINITY;
@@ -264,26 +285,14 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
         for (int e = 0; e < 16; ++e) acc_o[db][e] *= alpha;
     }
 
-    // ---- U^T += keys^T P^T: keys^T fragments through the transposing read of the SAME image ----
+    // ---- U^T += keys^T P^T ----
     {
-      typedef __attribute__((address_space(3))) v4s_f* lv4;
-      v4s_f va[2][4];
-      auto vread = [&](int s_, int db, v4s_f* f) {
-        const int row0 = 16 * s_ + v_row;
-        const int c = 4 * db + v_c;
-        const int a0 = row0 * (FKCPR * 16) + ((c ^ hh) << 4) + v_b;                     // (row >> 2) & 3 == hh
-        const int a1 = (row0 + 8) * (FKCPR * 16) + ((c ^ ((hh + 2) & 3)) << 4) + v_b;   // ... == (hh + 2) & 3
-        f[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sK0 + a0));
-        f[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sK0 + a1));
-        f[2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sK1 + a0));
-        f[3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sK1 + a1));
-      };
-      vread(0, 0, va[0]);
+      if constexpr (!ONEACC) vread(0, 0, va[0]);
       half8_t ph, pl;
       static_for_f<0, 16>([&](auto ic) {
-        constexpr int i = decltype(ic)::value, s_ = i / 8, db = i % 8, cur = i & 1;
+        constexpr int i = decltype(ic)::value, s_ = i / 8, db = i % 8, cur = i % VNB;
         if constexpr (db == 0) split8_fast_f(sc + 8 * s_, ph, pl);
-        if constexpr (i + 1 < 16) vread((i + 1) / 8, (i + 1) % 8, va[cur ^ 1]);
+        if constexpr (i + VLA < 16) vread((i + VLA) / 8, (i + VLA) % 8, va[(i + VLA) % VNB]);
         __builtin_amdgcn_sched_barrier(0);
         union { v4s_f s4[2]; half8_t h8; } uh, ul;
         uh.s4[0] = va[cur][0]; uh.s4[1] = va[cur][1]; ul.s4[0] = va[cur][2]; ul.s4[1] = va[cur][3];
