@@ -168,7 +168,7 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
     // the score MFMAs below (SPREAD), not as a burst here: a `buffer_load ... lds` occupies the issue port for 60+ cycles,
     // with one wave per SIMD nothing else would run meanwhile
     const bool has_next = kt + 1 < nt;
-    if constexpr (!SPREAD) {
+    if constexpr (!SPREAD && !ONEACC) {
       if (has_next) static_for_f<0, FNDMA>([&](auto ic) { issue_slot(ic, kt + 1, buf ^ 1); });
     }
     const unsigned char* sb = &smem[buf][0];
@@ -205,6 +205,11 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
         } else if constexpr (j < 16 + NPE) pread(j - 16, kfh[sl], kfl[sl]);
       };
       static_for_f<0, LA>([&](auto jc) { fetch(jc); });
+      if constexpr (!SPREAD && ONEACC) {                // the burst BEHIND the first fragment requests: their LDS latency
+        __builtin_amdgcn_sched_barrier(0);              // passes under the 18 DMA issues instead of after them
+        if (has_next) static_for_f<0, FNDMA>([&](auto ic) { issue_slot(ic, kt + 1, buf ^ 1); });
+        __builtin_amdgcn_sched_barrier(0);
+      }
       static_for_f<0, 16 + NPE>([&](auto ic) {
         constexpr int i = decltype(ic)::value, cur = i % NB;
         fetch(std::integral_constant<int, i + LA>{});
