@@ -324,6 +324,8 @@ def main():
     ap.add_argument('--t2i-fold', dest='t2i_fold', choices=['on', 'off'], default=None,
                     help='token -> image attention of the SAM decoder with the K | V projections folded in '
                          '(csrc/t2i_fold.hip); default: the library default (rsprompter_amd.sam_decoder.T2I_FOLD_DEFAULT)')
+    ap.add_argument('--t2i-fold-variant', dest='t2i_fold_variant', type=int, choices=[0, 1, 2, 3], default=None,
+                    help='issue schedule of the folded kernel (rsp_sam_t2i_fold `variant`; 0 = the form measured in round 4)')
     ap.add_argument('--upscale-fused', dest='upscale_fused', choices=['on', 'off'], default=None,
                     help='the SAM upscaler tail as one kernel (csrc/upscale.hip sam_upscale_fused_kernel, DESIGN 4.3c)')
     ap.add_argument('--encoder-graph', dest='encoder_graph', choices=['on', 'off'], default=None,
@@ -355,6 +357,9 @@ def main():
     if args.t2i_fold is not None:
         import rsprompter_amd.sam_decoder as _sd
         _sd.T2I_FOLD_DEFAULT = args.t2i_fold == 'on'
+    if args.t2i_fold_variant is not None:
+        import rsprompter_amd.sam_decoder as _sd3
+        _sd3.T2I_FOLD_VARIANT_DEFAULT = args.t2i_fold_variant
     if args.upscale_fused is not None:
         import rsprompter_amd.sam_decoder as _sd2
         _sd2.UPSCALE_FUSED_DEFAULT = args.upscale_fused == 'on'
@@ -460,7 +465,8 @@ def main():
         attn_tf_rel = sum(v['flops'] for v in attn) / (attn_ms + relpos_ms) / 1e9 if attn_ms else None
         value = world * B * args.steps / elapsed
         # non-default code paths of this run (absent = the defaults of the library)
-        opt_in = {k: v for k, v in (('t2i_fold', args.t2i_fold), ('upscale_fused', args.upscale_fused),
+        opt_in = {k: v for k, v in (('t2i_fold', args.t2i_fold), ('t2i_fold_variant', args.t2i_fold_variant),
+                                    ('upscale_fused', args.upscale_fused),
                                     ('encoder_graph', args.encoder_graph)) if v is not None}
         result = {
             'metric': 'images/sec (1024x1024 synthetic tiles, rsprompter_%s SAM-ViT-%s%s, full predict path)' % (

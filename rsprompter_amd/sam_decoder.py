@@ -30,6 +30,7 @@ N_MASK_TOKENS = 4  # num_multimask_outputs + 1
 # the kernel itself needs 2.2 ms per call where its matrix work would allow ~1: it stays OPT-IN (this flag, or
 # `decoder.t2i_fold = True`, or `bench.py --t2i-fold on`) until it has been tuned and the whole GPU suite has run with it.
 T2I_FOLD_DEFAULT = __import__('os').environ.get('RSP_T2I_FOLD', '0') == '1'
+T2I_FOLD_VARIANT_DEFAULT = int(__import__('os').environ.get('RSP_T2I_FOLD_VARIANT', '0'))    # rsp_sam_t2i_fold `variant` (0: measured)
 # The upscaler tail as one kernel: emulator-verified, unmeasured -- `bench.py --upscale-fused on` for round 5.
 UPSCALE_FUSED_DEFAULT = __import__('os').environ.get('RSP_UPSCALE_FUSED', '0') == '1'
 
@@ -96,7 +97,7 @@ class SamMaskDecoderHIP(HIPModule):
         self._pe_cache = {}
         # token -> image attention of layer 1 / final with the K | V projections folded in (csrc/t2i_fold.hip)
         self.t2i_fold = T2I_FOLD_DEFAULT
-        self.t2i_fold_variant = 0          # rsp_sam_t2i_fold `variant`
+        self.t2i_fold_variant = T2I_FOLD_VARIANT_DEFAULT
         # the upscaler tail in one kernel (csrc/upscale.hip, sam_upscale_fused_kernel): verified on the emulator only
         self.upscale_fused = UPSCALE_FUSED_DEFAULT
 

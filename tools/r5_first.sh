@@ -3,7 +3,8 @@
 #   1. their first run on an MI355X (tests that are skipped until RSP_UNMEASURED=1),
 #   2. the bench with each of them on / off on the same box (A/B), incl. the encoder replayed as a hipGraph,
 #   3. rocprofv3 kernel statistics of the bench with all of them on.
-# Usage: gpurun --timeout 600 -- 'bash tools/r5_first.sh'; results in gpurun_out/r5/first/.
+# Usage: gpurun --timeout 1200 -- 'bash tools/r5_first.sh' (about 15 minutes of box time: 10 bench runs of 50-70 s, one of them
+# under rocprofv3, two short pytest selections, two micro tools); results in gpurun_out/r5/first/.
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 O=gpurun_out/r5/first
 mkdir -p $O
@@ -21,7 +22,8 @@ PY
 RSP_UNMEASURED=1 timeout 300 python -m pytest -m gpu -q -s tests/test_gpu_baseline_configs.py tests/test_gpu_kernels.py \
   tests/test_gpu_encoder.py -k "unmeasured or t2i_fold or folded_token or graph_replay" > $O/unmeasured.log 2>&1
 echo "[first GPU run of the emulator-verified kernels] rc=$? $(( $(date +%s) - t0 )) s: $(tail -n 1 $O/unmeasured.log)"
-for cfg in "base:" "fold:--t2i-fold on" "up:--upscale-fused on" "both:--t2i-fold on --upscale-fused on"; do
+for cfg in "base:" "fold:--t2i-fold on" "fold2:--t2i-fold on --t2i-fold-variant 2" "fold3:--t2i-fold on --t2i-fold-variant 3" \
+           "up:--upscale-fused on" "both:--t2i-fold on --upscale-fused on"; do
   name=${cfg%%:*}; flags=${cfg#*:}
   timeout 90 python bench.py --no-cpu-baseline $flags > $O/bench_$name.json 2> $O/bench_$name.err
   echo "[bench $name] rc=$? $(( $(date +%s) - t0 )) s: $(line $O/bench_$name.json)"
