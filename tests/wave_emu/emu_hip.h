@@ -599,8 +599,11 @@ __attribute__((noinline)) inline emu_f32x16 emu_amdgcn_mfma_f32_32x32x16_f16(emu
   memcpy(&d, w.res[f.lane], 64);
   return d;
 }
-// ---- v_mfma_f32_16x16x32_f16, HYPOTHESISED layout (not yet compared with the device: tools/probes/mfma16_probe.hip is in
-// round 5's first GPU job; no kernel of the library uses this instruction yet):
+// ---- v_mfma_f32_16x16x32_f16 (no kernel of the library uses it yet).  The C / D map is the one the CDNA4 guide states
+// (col = lane & 15, row = 4 (lane >> 4) + register); the A / B map -- 8 consecutive k per lane, k block = lane >> 4 -- is the
+// 32x32x16 rule carried over and NOT yet compared with the device (tools/probes/mfma16_probe.hip, round 5's first GPU job).
+// A kernel only depends on it through the pairing of A's and B's k sets per lane group: any k permutation common to both
+// operands gives the same sums.
 // A[m = l % 16][k = 8 (l / 16) + j], B[k = 8 (l / 16) + j][n = l % 16], C / D[m = 4 (l / 16) + r][n = l % 16], r = 0..3
 typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
 __attribute__((noinline)) inline emu_f32x4 emu_amdgcn_mfma_f32_16x16x32_f16(emu_half8 a, emu_half8 b, emu_f32x4 c, int, int, int) {
