@@ -74,7 +74,7 @@ namespace emu {
 
 constexpr int WAVE = 64;
 constexpr size_t STACK_BYTES = 256 * 1024;
-constexpr int ARG_BYTES = 128, RES_BYTES = 64;
+constexpr int ARG_BYTES = 192, RES_BYTES = 64;
 
 [[noreturn]] inline void die(const char* msg) {
   fprintf(stderr, "wave_emu: %s\n", msg);
@@ -638,7 +638,63 @@ __attribute__((noinline)) inline emu_f32x4 emu_amdgcn_mfma_f32_16x16x32_f16(emu_
   memcpy(&d, w.res[f.lane], 16);
   return d;
 }
-#define emu_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(...) (emu::die("mfma_scale f8f6f4 is not emulated"), emu_f32x16{})
+// ---- v_mfma_scale_f32_32x32x64_f8f6f4 with both operands OCP e4m3 (cbsz = blgp = 0; the other formats are refused):
+// lane l holds A[m = l % 32][k = 32 (l / 32) + j] and B[k = 32 (l / 32) + j][n = l % 32], j = 0..31 (one byte each, 8
+// registers), C / D as the 32x32 forms above.  Each lane's 32-element K block carries an E8M0 scale 2^(e - 127): byte
+// opsel_a of its scale_a register for A, byte opsel_b of scale_b for B (the use csrc/gemm_dma.hip documents; the order of
+// the bytes INSIDE a block cannot matter to a kernel that feeds A and B the same way).  Products are exact in double.
+typedef int emu_i32x8 __attribute__((ext_vector_type(8)));
+inline float emu_e4m3_to_f(unsigned v) {
+  const int e = (v >> 3) & 15, m = v & 7;
+  float x;
+  if (e == 15 && m == 7) x = __builtin_nanf("");
+  else if (e == 0) x = ldexpf((float)m, -9);                  // subnormal: m / 8 * 2^-6
+  else x = ldexpf(1.0f + (float)m * 0.125f, e - 7);
+  return (v & 0x80) ? -x : x;
+}
+__attribute__((noinline)) inline emu_f32x16 emu_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(emu_i32x8 a, emu_i32x8 b, emu_f32x16 c, int cbsz,
+                                                                                    int blgp, int opsel_a, int scale_a,
+                                                                                    int opsel_b, int scale_b) {
+  if (cbsz != 0 || blgp != 0) emu::die("mfma_scale f8f6f4: only e4m3 x e4m3 (cbsz = blgp = 0) is emulated");
+  emu::Fiber& f = emu::cur();
+  emu::Wave& w = *f.wave;
+  memcpy(w.args[f.lane], &a, 32);
+  memcpy(w.args[f.lane] + 32, &b, 32);
+  memcpy(w.args[f.lane] + 64, &c, 64);
+  const int ea = (scale_a >> (8 * (opsel_a & 3))) & 255, eb = (scale_b >> (8 * (opsel_b & 3))) & 255;
+  memcpy(w.args[f.lane] + 128, &ea, 4);
+  memcpy(w.args[f.lane] + 132, &eb, 4);
+  emu::wave_rendezvous([](emu::Wave& W) {
+    if (W.arrived != emu::WAVE) emu::die("MFMA with inactive lanes");
+    static thread_local double A[32][64], B[64][32];
+    for (int l = 0; l < 64; ++l) {
+      const unsigned char* pa = W.args[l];
+      const unsigned char* pb = W.args[l] + 32;
+      int ea, eb;
+      memcpy(&ea, W.args[l] + 128, 4);
+      memcpy(&eb, W.args[l] + 132, 4);
+      const double sa = ldexp(1.0, ea - 127), sb = ldexp(1.0, eb - 127);
+      for (int j = 0; j < 32; ++j) {
+        A[l & 31][32 * (l >> 5) + j] = (double)emu_e4m3_to_f(pa[j]) * sa;
+        B[32 * (l >> 5) + j][l & 31] = (double)emu_e4m3_to_f(pb[j]) * sb;
+      }
+    }
+    for (int l = 0; l < 64; ++l) {
+      const float* pc = reinterpret_cast<const float*>(W.args[l] + 64);
+      float* pd = reinterpret_cast<float*>(W.res[l]);
+      const int n = l & 31;
+      for (int r = 0; r < 16; ++r) {
+        const int m = 8 * (r >> 2) + 4 * (l >> 5) + (r & 3);
+        double s = 0.0;
+        for (int k = 0; k < 64; ++k) s += A[m][k] * B[k][n];
+        pd[r] = (float)((double)pc[r] + s);
+      }
+    }
+  }, emu::OP_MFMA_F16, __builtin_return_address(0));
+  emu_f32x16 d;
+  memcpy(&d, w.res[f.lane], 64);
+  return d;
+}
 
 // ---- ds_read_b64_tr_b16: inside a 16-lane group lane i supplies the address of four consecutive halves D_i[0..3];
 // lane l of the group receives D_{4 j + l / 4}[l % 4], j = 0..3
