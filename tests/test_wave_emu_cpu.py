@@ -664,3 +664,12 @@ def test_emu_tiny_sam_encoder_end_to_end(emu, monkeypatch):
     e_emb = float((emb - emb_ref).abs().max())
     print('tiny encoder on the emulator: hidden states', ['%.1e' % e for e in errs], 'embedding %.1e (range %.1f)' % (e_emb, float(emb_ref.abs().max())))
     assert max(errs) < 1e-4 and e_emb < 1e-4
+    # the opt-in fp8-corrected product (LayerNorm / GELU / attention epilogues emit cat8 planes, the four block
+    # GEMMs run fp16 hi.hi + one scaled fp8 MFMA): 16-bit-class arithmetic, so only closeness to the fp16x3 run is asked
+    from rsprompter_amd import ops
+    monkeypatch.setattr(ops, 'F8_CORR', True)
+    enc._packed = None
+    out8 = enc(x)
+    e8 = [float((h - r).abs().max()) / float(r.abs().max()) for h, r in zip(out8[1], hs)] + [float((out8[0] - emb).abs().max()) / float(emb.abs().max())]
+    print('... with the fp8-corrected product: relative distance to the fp16x3 run', ['%.1e' % e for e in e8])
+    assert 0 < max(e8) < 2e-3
