@@ -489,7 +489,7 @@ def test_rpn_topk_ties_and_small_levels(dev):
     sel_score = torch.zeros((Bn, L, k), device=dev)
     sel_cnt = torch.zeros((Bn, L), dtype=torch.int32, device=dev)
     _lib.check(lib.rsp_rpn_topk(d, Bn, sel_idx.data_ptr(), sel_score.data_ptr(), sel_cnt.data_ptr(),
-                                torch.cuda.current_stream().cuda_stream), 'topk')
+                                ops._stream()), 'topk')
     for b in range(Bn):
         for li, (H, W) in enumerate(sizes):
             n = H * W * A

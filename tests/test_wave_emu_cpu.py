@@ -121,6 +121,7 @@ SWEEP = [
     ('test_gpu_kernels', 'test_mask_post_matches_reference_formula', ()),
     ('test_gpu_kernels', 'test_hyper_mask', ()),
     ('test_gpu_kernels', 'test_batched_nms_matches_oracle', (5000, 5, 0.7, 1000)),
+    ('test_gpu_kernels', 'test_rpn_topk_ties_and_small_levels', ()),
     ('test_gpu_query', 'test_query_kernels_unit', ()),
     ('test_gpu_samdet', 'test_bbox_post_matches_real_bbox_head_with_and_without_rescale', ()),
     ('test_gpu_samdet', 'test_resnet_leaf_kernels', ()),
