@@ -321,16 +321,6 @@ def main():
     ap.add_argument('--f8corr', action='store_true',
                     help='opt-in fast mode: encoder GEMMs as fp16 hi.hi + one fp8 correction MFMA (DESIGN.md section 3); '
                          'NOT the headline configuration -- parity margins are 8x smaller')
-    ap.add_argument('--t2i-fold', dest='t2i_fold', choices=['on', 'off'], default=None,
-                    help='token -> image attention of the SAM decoder with the K | V projections folded in '
-                         '(csrc/t2i_fold.hip); default: the library default (rsprompter_amd.sam_decoder.T2I_FOLD_DEFAULT)')
-    ap.add_argument('--t2i-fold-variant', dest='t2i_fold_variant', type=int, choices=[0, 1, 2, 3], default=None,
-                    help='issue schedule of the folded kernel (rsp_sam_t2i_fold `variant`; 0 = the form measured in round 4)')
-    ap.add_argument('--upscale-fused', dest='upscale_fused', choices=['on', 'off'], default=None,
-                    help='the SAM upscaler tail as one kernel (csrc/upscale.hip sam_upscale_fused_kernel, DESIGN 4.3c)')
-    ap.add_argument('--encoder-graph', dest='encoder_graph', choices=['on', 'off'], default=None,
-                    help="replay the SAM encoder's launch sequence as a captured hipGraph in the timed steps "
-                         '(rsprompter_amd.sam_encoder._EncoderGraph; the roofline leg stays eager: per-kernel events)')
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -354,18 +344,6 @@ def main():
     from rsprompter_amd import ops
     if args.f8corr:
         ops.F8_CORR = True
-    if args.t2i_fold is not None:
-        import rsprompter_amd.sam_decoder as _sd
-        _sd.T2I_FOLD_DEFAULT = args.t2i_fold == 'on'
-    if args.t2i_fold_variant is not None:
-        import rsprompter_amd.sam_decoder as _sd3
-        _sd3.T2I_FOLD_VARIANT_DEFAULT = args.t2i_fold_variant
-    if args.upscale_fused is not None:
-        import rsprompter_amd.sam_decoder as _sd2
-        _sd2.UPSCALE_FUSED_DEFAULT = args.upscale_fused == 'on'
-    if args.encoder_graph is not None:
-        import rsprompter_amd.sam_encoder as _se
-        _se.ENCODER_GRAPH_DEFAULT = args.encoder_graph == 'on'
     from rsprompter_amd.structures import DetDataSample
     from rsprompter_amd.synth import synth_images, synth_metas
     import torch.distributed as tdist
@@ -464,10 +442,6 @@ def main():
         relpos_ms = sum(v['ms'] for k, v in agg.items() if k.startswith('vit_relpos'))
         attn_tf_rel = sum(v['flops'] for v in attn) / (attn_ms + relpos_ms) / 1e9 if attn_ms else None
         value = world * B * args.steps / elapsed
-        # non-default code paths of this run (absent = the defaults of the library)
-        opt_in = {k: v for k, v in (('t2i_fold', args.t2i_fold), ('t2i_fold_variant', args.t2i_fold_variant),
-                                    ('upscale_fused', args.upscale_fused),
-                                    ('encoder_graph', args.encoder_graph)) if v is not None}
         result = {
             'metric': 'images/sec (1024x1024 synthetic tiles, rsprompter_%s SAM-ViT-%s%s, full predict path)' % (
                 args.model, args.arch[0].upper(), ' + LoRA' if args.lora else ''),
@@ -481,7 +455,7 @@ def main():
                                    f'{num_classes} classes, seeded synthetic weights' + _config_tag(args, B, world),
                        'images_per_gpu_per_step': B, 'detections_per_step_rank0': n_dets,
                        'parallelism': f'dp{world} (images sharded by batch, result gather to rank 0 over RCCL)' if world > 1 else 'single GPU',
-                       **({'opt_in': opt_in} if opt_in else {})},
+                       },
             'roofline': {'bound': 'mfma', 'kernel': dom_name, 'launches_per_step': dom['calls'],
                          'ms_per_step': round(dom['ms'], 3), 'achieved': round(achieved, 2),
                          'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4),

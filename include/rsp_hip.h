@@ -157,6 +157,10 @@ int rsp_gemm_uses_s2(const RspGemmDesc* desc);
 /* residual, 2 = GELU, 4 = fp32 output, 8 = plane output, 16 = output row map; 64 = the run-time form that serves every    */
 /* other mode (tests assert which compile-time specialisation they exercise; no device work)                               */
 int rsp_gemm_s2_epilogue(const RspGemmDesc* desc);
+/* 1 when rsp_gemm serves this descriptor with the ping-pong kernel (csrc/gemm_pp.hip: one 512-thread block per CU, tile  */
+/* 256 x 256, the two waves of a SIMD alternating matrix and load phases; tile_hint 200 forces it for every descriptor it */
+/* implements = those with a compile-time epilogue form above and K >= 128)                                              */
+int rsp_gemm_uses_pp(const RspGemmDesc* desc);
 
 /* ------------------------------------------------------------------------ */
 /* LayerNorm over the last dim of a [rows, C] matrix (C % 4 == 0, C <= 2048). */
@@ -366,9 +370,6 @@ int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo, int64_t k
                      const uint16_t* pek_hi, const uint16_t* pek_lo, int32_t pek_e, const uint16_t* qp_hi,
                      const uint16_t* qp_lo, int32_t qp_e, const uint16_t* tqx_hi, const uint16_t* tqx_lo,
                      int32_t tqx_e, int64_t q_rows, float* u, int32_t R, int32_t N, int32_t ncols,
-                     int32_t variant /* 0 = the form measured in round 4; 1 = DMA issue spread between the MFMAs; 2 / 3 = 0 / 1 with one
-                                        score accumulator, LDS reads two k-steps ahead, value-side reads in front of the softmax (need keys_e + qp_e == pek_e +
-                                        tqx_e, else RSP_EINVAL); 1-3 unmeasured */,
                      rsp_stream_t stream);
 
 /* The upscaler tail of the SAM mask decoder in one pass over the per-RoI keys (HF:513-531; csrc/upscale.hip,          */

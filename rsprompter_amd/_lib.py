@@ -142,7 +142,7 @@ PROTOTYPES = {
                               ctypes.POINTER(RspBoxCoder), c_int, c_void_p, c_void_p, c_void_p, c_void_p,
                               c_void_p, c_void_p]),
     "rsp_sam_t2i_fold": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
-                                 c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+                                 c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p]),
     "rsp_sam_upscale_fused": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                       c_void_p]),
@@ -175,6 +175,7 @@ PROTOTYPES = {
     "rsp_gather_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "rsp_gemm_uses_s2": (c_int, [ctypes.POINTER(RspGemmDesc)]),
     "rsp_gemm_s2_epilogue": (c_int, [ctypes.POINTER(RspGemmDesc)]),
+    "rsp_gemm_uses_pp": (c_int, [ctypes.POINTER(RspGemmDesc)]),
     "rsp_rle_to_string": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "rsp_mask_post_logits": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float,
                                      c_void_p, c_void_p, c_void_p]),

@@ -676,6 +676,9 @@ int launch_dma(const RspGemmDesc& d, hipStream_t s) {
 bool rsp_gemm_s2_eligible(const RspGemmDesc& d);                       // gemm_s2.hip
 int rsp_gemm_s2_auto(const RspGemmDesc& d);
 int rsp_gemm_s2_dispatch(const RspGemmDesc& d, int var, hipStream_t s);
+bool rsp_gemm_pp_eligible(const RspGemmDesc& d);                       // gemm_pp.hip
+int rsp_gemm_pp_auto(const RspGemmDesc& d);
+int rsp_gemm_pp_dispatch(const RspGemmDesc& d, int var, hipStream_t s);
 
 // called from rsp_gemm (gemm.hip) when the descriptor carries A planes
 int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
@@ -685,6 +688,10 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
     if (!rsp_gemm_s2_eligible(d)) return RSP_EINVAL;
     return rsp_gemm_s2_dispatch(d, (d.tile_hint & 0xff) - 40, s);
   }
+  // tile hint 200: the ping-pong kernel (gemm_pp.hip), forced; product rule (round 5): wherever its 256 x 256 tiles fill
+  // the CUs for several rounds
+  if ((d.tile_hint & 0xff) >= 200) return rsp_gemm_pp_dispatch(d, (d.tile_hint & 0xff) - 200, s);   // 200 + v: experiment variant v
+  if ((d.tile_hint & 0xff) == 0 && rsp_gemm_pp_auto(d)) return rsp_gemm_pp_dispatch(d, 0, s);
   // product rule (round 3): the two-blocks-per-CU persistent kernel wherever it has a specialised epilogue -- 7-20 %
   // faster than the kernels below on the ViT-H encoder shapes (tools/gemm_s2_exp.py).  Tile hint 1 = "the round-2 rule".
   if ((d.tile_hint & 0xff) == 0 && rsp_gemm_s2_auto(d)) return rsp_gemm_s2_dispatch(d, 0, s);
@@ -794,5 +801,12 @@ extern "C" int rsp_gemm_uses_s2(const RspGemmDesc* d) {
   if (!d || !(d->Ahi && d->Alo)) return 0;
   const int h = d->tile_hint & 0xff;
   if (h >= 40 && h < 168) return 1;
-  return h == 0 && rsp_gemm_s2_auto(*d);
+  return h == 0 && !rsp_gemm_pp_auto(*d) && rsp_gemm_s2_auto(*d);
+}
+
+extern "C" int rsp_gemm_uses_pp(const RspGemmDesc* d) {
+  if (!d || !(d->Ahi && d->Alo)) return 0;
+  const int h = d->tile_hint & 0xff;
+  if (h >= 200) return rsp_gemm_pp_eligible(*d);
+  return h == 0 && rsp_gemm_pp_auto(*d);
 }

@@ -76,11 +76,10 @@ struct T2iFoldP {
 };
 
 // NPE: heads whose PEK term a wave evaluates (its 32 columns h * T + t touch at most 5 heads when T >= 7, else all 8)
-// ONEACC: every score product of a tile -- the 16 k-steps of keys . q' and the NPE PEK steps -- accumulates into ONE
-// register block (possible when both products carry the same power-of-two scale): 32 registers less, 32 VALU instructions
-// and 32 accumulator <-> vector moves less per tile, no scratch in any instantiation; the freed registers hold a third set
-// of score fragments, so that the LDS reads run two k-steps ahead of their MFMAs (LA below)
-template <int NPE, bool SPREAD, bool ONEACC>
+// (Round 5, first GPU run of the three other issue schedules written on the emulator -- the next tile's DMA spread between
+// the score MFMAs: 11.3 instead of 4.5 ms per step; one score accumulator with deeper LDS lookahead: 4.48 vs 4.51 --
+// gpurun_out/r5/job1, profiles/r5_decoder_paths_ab.txt: removed.)
+template <int NPE>
 __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[FNBUF][FBUF_BYTES];
   __shared__ __attribute__((aligned(1024))) unsigned char sQl[FNW * 16 * 1024];      // q' lo fragments: [wave][k-step][lane] x 16 B
@@ -164,13 +163,9 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
     const int buf = kt & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of tile kt has landed
     __builtin_amdgcn_s_barrier();                         // ... everybody's; the other buffer has been read
-    // the 18 DMA instructions of tile kt + 1 (into the buffer everybody has just left) are issued one per k-step BETWEEN
-    // the score MFMAs below (SPREAD), not as a burst here: a `buffer_load ... lds` occupies the issue port for 60+ cycles,
-    // with one wave per SIMD nothing else would run meanwhile
+    // the 18 DMA instructions of tile kt + 1 (into the buffer everybody has just left), as a burst
     const bool has_next = kt + 1 < nt;
-    if constexpr (!SPREAD && !ONEACC) {
-      if (has_next) static_for_f<0, FNDMA>([&](auto ic) { issue_slot(ic, kt + 1, buf ^ 1); });
-    }
+    if (has_next) static_for_f<0, FNDMA>([&](auto ic) { issue_slot(ic, kt + 1, buf ^ 1); });
     const unsigned char* sb = &smem[buf][0];
     const unsigned char* sK0 = sb;
     const unsigned char* sK1 = sb + FK_UNITS * 16;
@@ -180,11 +175,10 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
     // ---- S^T = keys q'^T (two accumulators: even / odd k-steps) and the PEK term, fragment reads one step ahead ----
     f32x16 s0, s1, sp;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) { s0[e] = 0.f; if constexpr (!ONEACC) { s1[e] = 0.f; sp[e] = 0.f; } }
+    for (int e = 0; e < 16; ++e) { s0[e] = 0.f; s1[e] = 0.f; sp[e] = 0.f; }
     {
-      // fragment reads run LA k-steps ahead of their MFMAs through a ring of LA + 1 register sets: one step (= 3 MFMAs, ~100
-      // cycles) in the measured form, two in the one-accumulator form (the 32 registers it frees pay for the third set)
-      constexpr int LA = ONEACC ? 2 : 1, NB = LA + 1;
+      // fragment reads run LA k-steps ahead of their MFMAs through a ring of LA + 1 register sets (one step = 3 MFMAs)
+      constexpr int LA = 1, NB = LA + 1;
       half8_t kfh[NB], kfl[NB];
       auto kread = [&](int st, half8_t& h8, half8_t& l8) {
         const int off = k_row_off + (((2 * st + hh) ^ k_swz) << 4);
@@ -205,17 +199,12 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
         } else if constexpr (j < 16 + NPE) pread(j - 16, kfh[sl], kfl[sl]);
       };
       static_for_f<0, LA>([&](auto jc) { fetch(jc); });
-      if constexpr (!SPREAD && ONEACC) {                // the burst BEHIND the first fragment requests: their LDS latency
-        __builtin_amdgcn_sched_barrier(0);              // passes under the 18 DMA issues instead of after them
-        if (has_next) static_for_f<0, FNDMA>([&](auto ic) { issue_slot(ic, kt + 1, buf ^ 1); });
-        __builtin_amdgcn_sched_barrier(0);
-      }
       static_for_f<0, 16 + NPE>([&](auto ic) {
         constexpr int i = decltype(ic)::value, cur = i % NB;
         fetch(std::integral_constant<int, i + LA>{});
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (i < 16) {
-          if constexpr (ONEACC || (i & 1) == 0) {
+          if constexpr ((i & 1) == 0) {
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[cur], qh[i], s0, 0, 0, 0);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], qlf[cur], s0, 0, 0, 0);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], qh[i], s0, 0, 0, 0);
@@ -224,28 +213,19 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], qlf[cur], s1, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], qh[i], s1, 0, 0, 0);
           }
-        } else if constexpr (ONEACC) {
-          s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[cur], th[i - 16], s0, 0, 0, 0);
-          s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], tl[i - 16], s0, 0, 0, 0);
-          s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], th[i - 16], s0, 0, 0, 0);
         } else {
           sp = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[cur], th[i - 16], sp, 0, 0, 0);
           sp = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], tl[i - 16], sp, 0, 0, 0);
           sp = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[cur], th[i - 16], sp, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (SPREAD && i < FNDMA) {
-          if (has_next) issue_slot(ic, kt + 1, buf ^ 1);
-          __builtin_amdgcn_sched_barrier(0);
-        }
       });
     }
 
     // keys^T fragments for U^T += keys^T P^T come through the transposing read of the SAME image, VLA steps ahead of their
-    // MFMAs; in the one-accumulator form the first VLA sets are requested HERE, in front of the softmax (~600 cycles of
-    // VALU work with nothing else to hide behind on a single-wave SIMD), in the measured form after it
+    // MFMAs
     typedef __attribute__((address_space(3))) v4s_f* lv4;
-    constexpr int VLA = (ONEACC && NPE == 5) ? 2 : 1, VNB = VLA + 1;      // (NPE = 8 has no registers left for a third set)
+    constexpr int VLA = 1, VNB = VLA + 1;
     v4s_f va[VNB][4];
     auto vread = [&](int s_, int db, v4s_f* f) {
       const int row0 = 16 * s_ + v_row;
@@ -257,18 +237,13 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
       f[2] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sK1 + a0));
       f[3] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lv4)(sK1 + a1));
     };
-    if constexpr (ONEACC) {
-      static_for_f<0, VLA>([&](auto jc) { constexpr int j = decltype(jc)::value; vread(j / 8, j % 8, va[j % VNB]); });
-      __builtin_amdgcn_sched_barrier(0);
-    }
 
     // ---- online softmax in the log2 domain: this lane's query column, 16 of the tile's 32 keys per half wave ----
     float sc[16];
     float tmax = -INFINITY;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      if constexpr (ONEACC) sc[e] = s0[e] * p.c_main;
-      else sc[e] = fmaf(s0[e] + s1[e], p.c_main, sp[e] * p.c_pe);
+      sc[e] = fmaf(s0[e] + s1[e], p.c_main, sp[e] * p.c_pe);
       tmax = fmaxf(tmax, sc[e]);
     }
     tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
@@ -292,7 +267,7 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
 
     // ---- U^T += keys^T P^T ----
     {
-      if constexpr (!ONEACC) vread(0, 0, va[0]);
+      vread(0, 0, va[0]);
       half8_t ph, pl;
       static_for_f<0, 16>([&](auto ic) {
         constexpr int i = decltype(ic)::value, s_ = i / 8, db = i % 8, cur = i % VNB;
@@ -336,10 +311,10 @@ extern "C" int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo
                                 const uint16_t* pek_hi, const uint16_t* pek_lo, int32_t pek_e, const uint16_t* qp_hi,
                                 const uint16_t* qp_lo, int32_t qp_e, const uint16_t* tqx_hi, const uint16_t* tqx_lo,
                                 int32_t tqx_e, int64_t q_rows, float* u, int32_t R, int32_t N, int32_t ncols,
-                                int32_t variant, rsp_stream_t stream) {
+                                rsp_stream_t stream) {
   if (!keys_hi || !keys_lo || !pek_hi || !pek_lo || !qp_hi || !qp_lo || !tqx_hi || !tqx_lo || !u || R < 0 || N <= 0 ||
       (N % FKT) || ncols <= 0 || ncols > 96 || (ncols & 7) || k_rows < (int64_t)R * N || q_rows < (int64_t)R * 96 ||
-      k_rows * 512 > 0x7fffffffLL || (int64_t)N * 256 > 0x7fffffffLL || variant < 0 || variant > 3)
+      k_rows * 512 > 0x7fffffffLL || (int64_t)N * 256 > 0x7fffffffLL)
     return RSP_EINVAL;
   if (R == 0) return RSP_OK;
   T2iFoldP p;
@@ -353,21 +328,11 @@ extern "C" int rsp_sam_t2i_fold(const uint16_t* keys_hi, const uint16_t* keys_lo
   p.c_pe = ldexpf(1.0f, -(pek_e + tqx_e)) * LOG2E_F;
   p.u_unscale = ldexpf(1.0f, -keys_e);                   // (the 2^14 of the probabilities cancels against their sum)
   // columns are ordered h * T + t: 32 consecutive ones touch at most 5 heads when T >= 7
-  // variant 0: the DMA instructions of the next tile as a burst behind the barrier -- the form that ran on the MI355X in
-  // round 4 (2.2 ms per call at R = 800); variant 1: one per k-step between the score MFMAs (verified on the emulator
-  // only; a candidate for the next round's measurements)
-  // variants 2 / 3: as 0 / 1 with ONE score accumulator (needs equal scales of the two score products) and the fragment
-  // reads TWO k-steps ahead of their MFMAs instead of one (emulator only)
   const bool five = ncols >= 56;
-  const bool one = variant >= 2;
-  if (one && keys_e + qp_e != pek_e + tqx_e) return RSP_EINVAL;
   const dim3 g(R), b(FNT);
   hipStream_t s = (hipStream_t)stream;
-#define T2I_CASE(V, NPE_, SP_, ONE_) if (variant == V && five == (NPE_ == 5)) { hipLaunchKernelGGL((sam_t2i_fold_kernel<NPE_, SP_, ONE_>), g, b, 0, s, p); RSP_CHECK_LAUNCH(); return RSP_OK; }
-  T2I_CASE(0, 5, false, false) T2I_CASE(0, 8, false, false)
-  T2I_CASE(1, 5, true, false) T2I_CASE(1, 8, true, false)
-  T2I_CASE(2, 5, false, true) T2I_CASE(2, 8, false, true)
-  T2I_CASE(3, 5, true, true) T2I_CASE(3, 8, true, true)
-#undef T2I_CASE
-  return RSP_EINVAL;
+  if (five) hipLaunchKernelGGL((sam_t2i_fold_kernel<5>), g, b, 0, s, p);
+  else hipLaunchKernelGGL((sam_t2i_fold_kernel<8>), g, b, 0, s, p);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
 }

@@ -275,6 +275,9 @@ def _dma_tile_name(m, n, hint=0, conv=False, k=1 << 30, f8=False):
     return name
 
 
+PP_AUTO = True      # False: rsp_gemm's choice of the ping-pong kernel (csrc/gemm_pp.hip) is overridden by gemm_s2 (A/B runs)
+
+
 def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, c_rowmap=None,
          M=None, out_rows=None, res_mod=0, a_scale_log2=DEFAULT_A_SCALE_LOG2, conv=None,
          res_bmap=None, res_brows=0, out_planes=False, out_f32=True, dma="auto", tile_hint=0, c_ncols=0, pl_col0=0,
@@ -366,12 +369,18 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.act = act
     d.a_scale_log2 = plane_word(a_scale_log2, w_f8)
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
+    if not PP_AUTO and is_planes and tile_hint == 0 and _lib_real.load().rsp_gemm_uses_pp(d):
+        d.tile_hint = 40        # A/B switch (tools/ab_bench.py "ops.PP_AUTO=False"): the round-3 kernel for these shapes
+    if plan_only == 'pp':       # 1: gemm_f16x3_pp_kernel (csrc/gemm_pp.hip) serves the call
+        return int(_lib_real.load().rsp_gemm_uses_pp(d)) if is_planes else 0
     if plan_only:
         return int(_lib_real.load().rsp_gemm_s2_epilogue(d)) if is_planes else -1
     tile = _dma_tile_name(m, n, tile_hint, conv is not None, w.K, w_f8) if is_planes else ('128x128' if n > 64 else ('128x64' if n > 32 else '128x32'))
     kname = ('gemm_f16f8_dma_kernel' if w_f8 else 'gemm_f16x3_dma_kernel') if is_planes else 'gemm_f16x3_kernel'
     if is_planes and _prof is not None and _lib_real.load().rsp_gemm_uses_s2(d):
         kname, tile = 'gemm_f16x3_s2_kernel', '256x128'         # the kernel rsp_gemm really launches (profiler label)
+    elif is_planes and _prof is not None and _lib_real.load().rsp_gemm_uses_pp(d):
+        kname, tile = 'gemm_f16x3_pp_kernel', '256x256'
     _timed(f'{kname}<{tile}>', 2.0 * m * n * w.K, 4.0 * (m * w.K + m * n) + 4.0 * n * w.K,
            lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm"),
            detail=f'M={m} N={n} K={w.K}' + (' conv' if conv is not None else ''))
@@ -794,7 +803,7 @@ def sam_upscale_fused(x, w1, bias1, gamma, beta, eps, w2p, bias2, hyper, h, w):
 SAM_T2I_FOLD_MAX_TOKENS = 12    # 8 heads x T query columns fit the kernel's 96
 
 
-def sam_t2i_fold(keys, pek, qp, tqx, *, R, N, ncols, variant=0):
+def sam_t2i_fold(keys, pek, qp, tqx, *, R, N, ncols):
     """token -> image attention over the per-RoI key planes with the K | V projections folded in (csrc/t2i_fold.hip):
     keys Planes [R*N, 256]; pek Planes [N, 128] = k_proj(pe) + bias; qp Planes [R*96, 256] and tqx Planes [R*96, 128] (see
     rsp_sam_t2i_fold).  Returns u fp32 [R*96, 256] = sum_n softmax[n] keys[n] per (RoI, column); the rows of the columns
@@ -806,12 +815,12 @@ def sam_t2i_fold(keys, pek, qp, tqx, *, R, N, ncols, variant=0):
     if qp.rows != tqx.rows or qp.rows < R * 96 or keys.rows < R * N or pek.rows != N:
         raise ValueError('sam_t2i_fold: row counts')
     u = torch.zeros((R * 96, 256), dtype=torch.float32, device=keys.device)
-    _timed('sam_t2i_fold_kernel' + ('<spread>' if variant else ''), 2.0 * R * N * 96 * (256 + 128 + 256), 4.0 * R * N * 256,
+    _timed('sam_t2i_fold_kernel', 2.0 * R * N * 96 * (256 + 128 + 256), 4.0 * R * N * 256,
            lambda: _lib.check(lib.rsp_sam_t2i_fold(keys.hi.data_ptr(), keys.lo.data_ptr(), keys.rows, keys.scale_log2,
                                                    pek.hi.data_ptr(), pek.lo.data_ptr(), pek.scale_log2,
                                                    qp.hi.data_ptr(), qp.lo.data_ptr(), qp.scale_log2,
                                                    tqx.hi.data_ptr(), tqx.lo.data_ptr(), tqx.scale_log2, qp.rows,
-                                                   u.data_ptr(), R, N, ncols, variant, _stream()), "rsp_sam_t2i_fold"))
+                                                   u.data_ptr(), R, N, ncols, _stream()), "rsp_sam_t2i_fold"))
     return u
 
 

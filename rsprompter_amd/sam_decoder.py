@@ -25,14 +25,11 @@ HID = 256          # SamMaskDecoderConfig.hidden_size
 HEADS = 8
 MLP_DIM = 2048
 N_MASK_TOKENS = 4  # num_multimask_outputs + 1
-# The folded form of the layer-1 / final token -> image attention (csrc/t2i_fold.hip).  Round 4 measured it on the bench
-# fixture (ViT-H, 800 RoIs): 167.1 ms per step folded vs 168.1 projected on the same box, mask logits / detections equal;
-# the kernel itself needs 2.2 ms per call where its matrix work would allow ~1: it stays OPT-IN (this flag, or
-# `decoder.t2i_fold = True`, or `bench.py --t2i-fold on`) until it has been tuned and the whole GPU suite has run with it.
-T2I_FOLD_DEFAULT = __import__('os').environ.get('RSP_T2I_FOLD', '0') == '1'
-T2I_FOLD_VARIANT_DEFAULT = int(__import__('os').environ.get('RSP_T2I_FOLD_VARIANT', '0'))    # rsp_sam_t2i_fold `variant` (0: measured)
-# The upscaler tail as one kernel: emulator-verified, unmeasured -- `bench.py --upscale-fused on` for round 5.
-UPSCALE_FUSED_DEFAULT = __import__('os').environ.get('RSP_UPSCALE_FUSED', '0') == '1'
+# Both product paths since round 5 (first GPU run + A/B on one box: profiles/r5_decoder_paths_ab.txt, -0.9 ms per ViT-H
+# step together): the layer-1 / final token -> image attention with the K | V projections folded in (csrc/t2i_fold.hip)
+# and the upscaler tail as one kernel (csrc/upscale.hip, sam_upscale_fused_kernel).  The instance attributes `t2i_fold` /
+# `upscale_fused` remain so that the parity tests can hold the fused forms against the kernel chains they replace (those
+# chains also serve the shapes the fused kernels do not take: more than 12 tokens, N % 32 != 0, R * N * 512 >= 2^31).
 
 
 def _upscale2_k_order():
@@ -96,10 +93,9 @@ class SamMaskDecoderHIP(HIPModule):
         _add_linear(self, 'iou_prediction_head.proj_out', N_MASK_TOKENS, HID)
         self._pe_cache = {}
         # token -> image attention of layer 1 / final with the K | V projections folded in (csrc/t2i_fold.hip)
-        self.t2i_fold = T2I_FOLD_DEFAULT
-        self.t2i_fold_variant = T2I_FOLD_VARIANT_DEFAULT
-        # the upscaler tail in one kernel (csrc/upscale.hip, sam_upscale_fused_kernel): verified on the emulator only
-        self.upscale_fused = UPSCALE_FUSED_DEFAULT
+        self.t2i_fold = True
+        # the upscaler tail in one kernel (csrc/upscale.hip, sam_upscale_fused_kernel)
+        self.upscale_fused = True
 
     # ------------------------------------------------------------------ packing
     def _pw(self, name, with_bias=True):
@@ -192,8 +188,7 @@ class SamMaskDecoderHIP(HIPModule):
         exp[:, cols, head] = tqs                                    # block diagonal: own head's 16 columns, zeros elsewhere
         tqx = ops.to_planes(exp.view(R * 96, d2))
         qp = ops.gemm(tqx, P[pre + '.k_projT'], bias=None, out_planes=True, out_f32=False)      # [R*96, 256] planes
-        u = ops.sam_t2i_fold(keys_pl, pe_t[pre + '.pek_planes'], qp, tqx, R=R, N=N, ncols=HEADS * T,
-                             variant=self.t2i_fold_variant)
+        u = ops.sam_t2i_fold(keys_pl, pe_t[pre + '.pek_planes'], qp, tqx, R=R, N=N, ncols=HEADS * T)
         full = ops.gemm(u, P[pre + '.v_proj'])                      # [R*96, 128]: every head's Wv on every column
         ao = full.view(R, 96, HEADS, dh2)[:, cols, head]            # keep the column's own head: [R, 8 T, 16]
         return ao.view(R, HEADS, T, dh2).permute(0, 2, 1, 3).reshape(R * T, d2).contiguous()

@@ -62,39 +62,6 @@ def _get(root, dotted):
     return root
 
 
-# Opt-in (RSP_ENCODER_GRAPH=1 or `encoder.graph = True`): the encoder's launches -- about ten per layer, static shapes, no
-# host decision in between -- are captured ONCE per (batch, device) into a hipGraph and replayed, so that a step costs the
-# interpreter one copy and one graph launch instead of 130-340 C-ABI calls.  Off by default: written at the end of round 4
-# and not yet run on a GPU (tests/test_gpu_encoder.py::test_encoder_graph_replay_matches_eager behind RSP_UNMEASURED=1).
-ENCODER_GRAPH_DEFAULT = os.environ.get('RSP_ENCODER_GRAPH') == '1'
-
-
-class _EncoderGraph:
-    """The captured launch sequence of `SamVisionEncoderHIP._run` for one input signature.  Capture follows the PyTorch
-    recipe: two eager runs on a side stream first (the library's one-time function attributes, the cached row maps and
-    attention workspace, the allocator's pools), then one run under `torch.cuda.graph` on static input / output tensors."""
-
-    def __init__(self, enc, pixel_values, want_hidden):
-        self.inp = pixel_values.detach().clone()
-        cur = torch.cuda.current_stream()
-        side = torch.cuda.Stream(device=pixel_values.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                enc._run(self.inp, want_hidden)
-        cur.wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        # thread_local: other threads of the process (the RCCL watchdog polling its events, a data loader) keep working
-        # during the capture; calls that would break it from THIS thread still raise
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
-            self.out = enc._run(self.inp, want_hidden)
-
-    def __call__(self, pixel_values):
-        self.inp.copy_(pixel_values)               # (dtype / layout conversion included)
-        self.graph.replay()
-        return self.out
-
-
 class SamVisionEncoderHIP(HIPModule):
     def __init__(self, arch='base', image_size=1024, patch_size=16, window_size=14,
                  out_channels=256, output_hidden_states=False, layer_norm_eps=1e-6, naming='hf'):
@@ -140,8 +107,6 @@ class SamVisionEncoderHIP(HIPModule):
         add_param(self, nm['nln2'] + '.bias', (out_channels,))
         self.lora = None  # optional dict name -> (A [r,D], B [3D,r], scale), merged at pack time
         self._maps = {}
-        self.graph = ENCODER_GRAPH_DEFAULT     # replay a captured hipGraph (see _EncoderGraph); outputs are then reused
-        self._graphs = {}                      # by the next call with the same signature
 
     # ------------------------------------------------------------------ packing
     def _pack(self):
@@ -189,7 +154,6 @@ class SamVisionEncoderHIP(HIPModule):
         P['nln2'] = (n2.weight.detach(), n2.bias.detach())
         self._packed = P
         self._maps = {}
-        self._graphs = {}
 
     def _window_map(self, B, device):
         """row map of window_partition (HF:900-922): GEMM row (b, wy, wx, iy, ix) -> token row or -1 (pad)."""
@@ -225,18 +189,7 @@ class SamVisionEncoderHIP(HIPModule):
         if self._packed is None:
             self._pack()
         want_hidden = bool(self.output_hidden_states if output_hidden_states is None else output_hidden_states)
-        # graph replay: only on a device, outside a capture of the caller's, and not under bench.py's per-kernel event
-        # profiler (events recorded inside a capture carry no time)
-        if self.graph and self._graph_allowed(pixel_values):
-            key = (B, want_hidden, str(pixel_values.device), pixel_values.dtype)
-            if key not in self._graphs:
-                self._graphs[key] = _EncoderGraph(self, pixel_values, want_hidden)
-            return self._graphs[key](pixel_values)
         return self._run(pixel_values, want_hidden)
-
-    @staticmethod
-    def _graph_allowed(pixel_values):
-        return pixel_values.is_cuda and ops._prof is None and not torch.cuda.is_current_stream_capturing()
 
     def _run(self, pixel_values, want_hidden):
         """the launch sequence: no host synchronisation, no host-side decision that depends on device data"""

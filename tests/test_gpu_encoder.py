@@ -67,43 +67,3 @@ def test_encoder_huge_with_lora_matches_merged_oracle(dev):
     # the adapter tensors travel under peft's names
     keys = m.state_dict().keys()
     assert any('base_model.model' in k and 'lora_A.default' in k for k in keys)
-
-
-@pytest.mark.skipif(__import__('os').environ.get('RSP_UNMEASURED') != '1', reason='written at the end of round 4 without a GPU: '
-                    'set RSP_UNMEASURED=1 for its first run on an MI355X')
-@pytest.mark.parametrize('hidden', [True, False])
-def test_encoder_graph_replay_matches_eager(dev, hidden):
-    """Opt-in hipGraph replay of the encoder's launch sequence (sam_encoder._EncoderGraph): the captured graph must give
-    the eager path's bits -- on the input it was captured with, on later inputs (the static input is refilled, the
-    persistent GEMM's ticket words are re-armed by every launch), for a second batch size (its own graph), with eager calls
-    in between, and after a weight reload (the graphs are dropped with the packed weights)."""
-    from rsprompter_amd.sam_encoder import RSSamVisionEncoder
-    from rsprompter_amd.synth import synth_state_dict
-    if dev.type != 'cuda':
-        pytest.skip('graph capture needs a device')
-    m = RSSamVisionEncoder('sam_vit_base', extra_config=dict(output_hidden_states=hidden))
-    enc = m.vision_encoder
-    enc.load_state_dict(synth_state_dict(enc, seed=0))
-    m = m.to(dev)
-    g = torch.Generator().manual_seed(3)
-    xs = [torch.randn(b, 3, 1024, 1024, generator=g).to(dev) for b in (2, 2, 1, 2)]
-
-    def run(x):
-        out = m(x)
-        return [out[0].clone()] + ([h.clone() for h in out[1]] if hidden else [])
-    enc.graph = False
-    ref = [run(x) for x in xs]
-    enc.graph = True
-    for rep in range(2):
-        for x, r in zip(xs, ref):
-            got = run(x)
-            assert len(got) == len(r) and all(torch.equal(a, b) for a, b in zip(got, r))
-        enc.graph = False
-        assert all(torch.equal(a, b) for a, b in zip(run(xs[0]), ref[0]))      # eager launches between replays
-        enc.graph = True
-    assert len(enc._graphs) == 2                                               # one per batch size
-    enc.load_state_dict(synth_state_dict(enc, seed=1))
-    enc.graph = False
-    ref2 = run(xs[0])
-    enc.graph = True
-    assert all(torch.equal(a, b) for a, b in zip(run(xs[0]), ref2)) and not torch.equal(ref2[0], ref[0][0])

@@ -466,90 +466,3 @@ def test_samdet_end_to_end_host_logic(mocked):
     assert pi.bboxes.shape == (0, 4) and pi.masks.dtype == torch.bool and tuple(pi.masks.shape) == (0, 512, 512)
 
 
-def test_encoder_graph_mode_gating_and_cache(monkeypatch):
-    """host logic of the opt-in hipGraph replay of the encoder (sam_encoder._EncoderGraph; the capture itself needs a
-    device: tests/test_gpu_encoder.py): off by default, one graph per (batch, hidden-states, device, dtype) signature,
-    eager when the gate says no (CPU tensors, bench.py's event profiler, a capture of the caller's), graphs dropped when
-    the weights are re-packed"""
-    import rsprompter_amd.sam_encoder as se
-    made = []
-
-    class FakeGraph:
-        def __init__(self, enc, x, want_hidden):
-            made.append((x.shape[0], want_hidden))
-            self.enc, self.want = enc, want_hidden
-
-        def __call__(self, x):
-            return ('replayed',) + self.enc._run(x, self.want)
-
-    monkeypatch.setattr(se, '_EncoderGraph', FakeGraph)
-    enc = se.SamVisionEncoderHIP('base', image_size=64, window_size=2)
-    assert enc.graph is False                                        # opt-in
-
-    def fake_pack():
-        enc._packed, enc._maps, enc._graphs = {}, {}, {}
-    monkeypatch.setattr(enc, '_pack', fake_pack)
-    monkeypatch.setattr(enc, '_run', lambda x, want: (x.shape[0], want))
-    x2, x3 = torch.zeros(2, 3, 64, 64), torch.zeros(3, 3, 64, 64)
-    assert enc(x2) == (2, False) and not made                        # graph mode off: eager
-    enc.graph = True
-    assert enc(x2) == (2, False) and not made                        # CPU tensor: the real gate says no
-    assert se.SamVisionEncoderHIP._graph_allowed(x2) is False
-    monkeypatch.setattr(se.SamVisionEncoderHIP, '_graph_allowed', staticmethod(lambda x: True))
-    assert enc(x2) == ('replayed', 2, False) and enc(x2)[0] == 'replayed' and made == [(2, False)]
-    assert enc(x3, output_hidden_states=True) == ('replayed', 3, True) and made == [(2, False), (3, True)]
-    assert enc(x2, output_hidden_states=True)[0] == 'replayed' and len(made) == 3 and len(enc._graphs) == 3
-    enc.load_state_dict(enc.state_dict())                            # weights reloaded: re-pack, graphs dropped
-    assert enc._packed is None
-    assert enc(x2) == ('replayed', 2, False) and len(made) == 4 and len(enc._graphs) == 1
-    with pytest.raises(ValueError):
-        enc(torch.zeros(2, 3, 32, 32))                               # validation comes before the graph lookup
-
-
-def test_encoder_graph_capture_recipe_with_stand_in_streams(monkeypatch):
-    """_EncoderGraph's own lines executed on the CPU with stand-ins for the torch.cuda stream / graph objects (signatures
-    checked against the real ones): warm-up runs on a side stream that waits for the current one and is waited for, ONE
-    run inside the capture, replay = refill of the static input + graph launch, the static output handed back."""
-    import contextlib
-    import inspect
-    import rsprompter_amd.sam_encoder as se
-    log = []
-
-    class Stream:
-        def __init__(self, device=None):
-            log.append('side stream')
-
-        def wait_stream(self, other):
-            log.append('wait')
-
-    class Graph:
-        def replay(self):
-            log.append('replay')
-
-    @contextlib.contextmanager
-    def graph_ctx(g, pool=None, stream=None, capture_error_mode='global'):
-        assert isinstance(g, Graph) and capture_error_mode == 'thread_local'
-        log.append('capture begin')
-        yield
-        log.append('capture end')
-    real = inspect.signature(torch.cuda.graph.__init__).parameters
-    assert 'capture_error_mode' in real and list(real)[1] == 'cuda_graph'
-    assert 'device' in inspect.signature(torch.cuda.Stream.__new__).parameters
-    monkeypatch.setattr(torch.cuda, 'current_stream', lambda *a: Stream.__new__(Stream))
-    monkeypatch.setattr(torch.cuda, 'Stream', Stream)
-    monkeypatch.setattr(torch.cuda, 'stream', lambda s: contextlib.nullcontext())
-    monkeypatch.setattr(torch.cuda, 'CUDAGraph', Graph)
-    monkeypatch.setattr(torch.cuda, 'graph', graph_ctx)
-
-    class Enc:
-        def _run(self, x, want_hidden):
-            log.append('run')
-            return (x, want_hidden)                        # the "static output" aliases the static input
-    x = torch.arange(6.0).view(1, 6)
-    g = se._EncoderGraph(Enc(), x, True)
-    assert log == ['side stream', 'wait', 'run', 'run', 'wait', 'capture begin', 'run', 'capture end']
-    assert g.inp is not x and torch.equal(g.inp, x)
-    y = torch.ones(1, 6, dtype=torch.float64)
-    out = g(y)                                             # dtype conversion happens in the refill
-    assert log[-1] == 'replay' and out is g.out and out[1] is True
-    assert out[0] is g.inp and g.inp.dtype == torch.float32 and torch.equal(g.inp, torch.ones(1, 6))

@@ -500,3 +500,30 @@ def paste_masks(logits_nhwc, labels, boxes, img_hw, thr=0.5):
         lg = lg[range(k), labels.long()][:, None]
     meta = dict(ori_shape=(int(img_hw[0]), int(img_hw[1])), scale_factor=(1.0, 1.0))
     return samseg.fcn_predict_single(lg, boxes, None, meta, thr, rescale=True, class_agnostic=True)[0]
+
+
+# ----------------------------------------------------------------------------- the fused decoder forms (product since round 5)
+SAM_T2I_FOLD_MAX_TOKENS = 12
+
+
+def sam_t2i_fold(keys, pek, qp, tqx, *, R, N, ncols):
+    """u[r * 96 + c] = sum_n softmax_n(keys[r, n] . qp[r * 96 + c] + pek[n] . tqx[r * 96 + c]) keys[r, n] (rsp_sam_t2i_fold; the
+    softmax scale travels inside tqx / qp); rows of the columns >= ncols stay zero"""
+    k = keys[:R * N].view(R, N, 256)
+    s = torch.einsum('rnd,rcd->rcn', k, qp[:R * 96].view(R, 96, 256)) + torch.einsum('nd,rcd->rcn', pek, tqx[:R * 96].view(R, 96, 128))
+    u = torch.einsum('rcn,rnd->rcd', s.softmax(-1), k)
+    u[:, ncols:] = 0
+    return u.reshape(R * 96, 256)
+
+
+def sam_upscale_fused(x, w1, bias1, gamma, beta, eps, w2p, bias2, hyper, h, w):
+    """ConvT(256 -> 64) + LN2d + GELU + ConvT(64 -> 32) + GELU + <., hyper> (rsp_sam_upscale_fused); w2p's K columns are in
+    sam_decoder._upscale2_k_order()"""
+    from rsprompter_amd.sam_decoder import _upscale2_k_order
+    rows = x.shape[0]
+    R = rows // (h * w)
+    y = (x @ w1.w.t() + bias1).view(rows, 4, 64)                              # [(dy, dx), co]
+    y = F.gelu(F.layer_norm(y, (64,), gamma, beta, eps))
+    z = F.gelu(y[..., _upscale2_k_order()] @ w2p.w.t() + bias2).view(rows, 2, 2, 2, 2, 32)     # [dy, dx, dy2, dx2, c2]
+    m = torch.einsum('nabcdk,nk->nabcd', z, hyper.repeat_interleave(h * w, 0))
+    return m.view(R, h, w, 2, 2, 2, 2).permute(0, 1, 3, 5, 2, 4, 6).reshape(R, 4 * h, 4 * w)
