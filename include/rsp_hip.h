@@ -157,9 +157,10 @@ int rsp_gemm_uses_s2(const RspGemmDesc* desc);
 /* residual, 2 = GELU, 4 = fp32 output, 8 = plane output, 16 = output row map; 64 = the run-time form that serves every    */
 /* other mode (tests assert which compile-time specialisation they exercise; no device work)                               */
 int rsp_gemm_s2_epilogue(const RspGemmDesc* desc);
-/* 1 when rsp_gemm serves this descriptor with the ping-pong kernel (csrc/gemm_pp.hip: one 512-thread block per CU, tile  */
-/* 256 x 256, the two waves of a SIMD alternating matrix and load phases; tile_hint 200 forces it for every descriptor it */
-/* implements = those with a compile-time epilogue form above and K >= 128)                                              */
+/* 256 / 128 when rsp_gemm serves this descriptor with the ping-pong kernel (csrc/gemm_pp.hip: one 512-thread block per   */
+/* CU, block tile 256 x 256 or 128 x 256, the two waves of a SIMD alternating matrix and load phases) = the tile's rows;   */
+/* 0 otherwise.  tile_hint 200 / 201 force the two tiles for every descriptor the kernel implements (those with one of the */
+/* compile-time epilogue forms above and K >= 128).                                                                       */
 int rsp_gemm_uses_pp(const RspGemmDesc* desc);
 
 /* ------------------------------------------------------------------------ */

@@ -690,8 +690,15 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   }
   // tile hint 200: the ping-pong kernel (gemm_pp.hip), forced; product rule (round 5): wherever its 256 x 256 tiles fill
   // the CUs for several rounds
-  if ((d.tile_hint & 0xff) >= 200) return rsp_gemm_pp_dispatch(d, (d.tile_hint & 0xff) - 200, s);   // 200 + v: experiment variant v
-  if ((d.tile_hint & 0xff) == 0 && rsp_gemm_pp_auto(d)) return rsp_gemm_pp_dispatch(d, 0, s);
+  // 200 + v: gemm_pp.hip, variant v: bit 0 = the 128 x 256 tile; development builds: 4 / 8 / 12 ablations, 16 = time stamps
+  if ((d.tile_hint & 0xff) >= 200) {
+    const int v = (d.tile_hint & 0xff) - 200;
+    return rsp_gemm_pp_dispatch(d, (v & 16) ? 32 | (v & 1) : v, s);
+  }
+  if ((d.tile_hint & 0xff) == 0) {
+    const int bm = rsp_gemm_pp_auto(d);
+    if (bm) return rsp_gemm_pp_dispatch(d, bm == 128 ? 1 : 0, s);
+  }
   // product rule (round 3): the two-blocks-per-CU persistent kernel wherever it has a specialised epilogue -- 7-20 %
   // faster than the kernels below on the ViT-H encoder shapes (tools/gemm_s2_exp.py).  Tile hint 1 = "the round-2 rule".
   if ((d.tile_hint & 0xff) == 0 && rsp_gemm_s2_auto(d)) return rsp_gemm_s2_dispatch(d, 0, s);
@@ -807,6 +814,7 @@ extern "C" int rsp_gemm_uses_s2(const RspGemmDesc* d) {
 extern "C" int rsp_gemm_uses_pp(const RspGemmDesc* d) {
   if (!d || !(d->Ahi && d->Alo)) return 0;
   const int h = d->tile_hint & 0xff;
-  if (h >= 200) return rsp_gemm_pp_eligible(*d);
-  return h == 0 && rsp_gemm_pp_auto(*d);
+  if (h >= 200) return rsp_gemm_pp_eligible(*d) ? (((h - 200) & 1) ? 128 : 256) : 0;
+  if (h != 0) return 0;
+  return rsp_gemm_pp_auto(*d);
 }

@@ -371,7 +371,7 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     d.alpha = math.ldexp(1.0, -(a_scale_log2 + w.scale_log2))
     if not PP_AUTO and is_planes and tile_hint == 0 and _lib_real.load().rsp_gemm_uses_pp(d):
         d.tile_hint = 40        # A/B switch (tools/ab_bench.py "ops.PP_AUTO=False"): the round-3 kernel for these shapes
-    if plan_only == 'pp':       # 1: gemm_f16x3_pp_kernel (csrc/gemm_pp.hip) serves the call
+    if plan_only == 'pp':       # 256 / 128: gemm_f16x3_pp_kernel (csrc/gemm_pp.hip) with that tile serves the call, else 0
         return int(_lib_real.load().rsp_gemm_uses_pp(d)) if is_planes else 0
     if plan_only:
         return int(_lib_real.load().rsp_gemm_s2_epilogue(d)) if is_planes else -1
@@ -380,7 +380,7 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     if is_planes and _prof is not None and _lib_real.load().rsp_gemm_uses_s2(d):
         kname, tile = 'gemm_f16x3_s2_kernel', '256x128'         # the kernel rsp_gemm really launches (profiler label)
     elif is_planes and _prof is not None and _lib_real.load().rsp_gemm_uses_pp(d):
-        kname, tile = 'gemm_f16x3_pp_kernel', '256x256'
+        kname, tile = 'gemm_f16x3_pp_kernel', f'{_lib_real.load().rsp_gemm_uses_pp(d)}x256'
     _timed(f'{kname}<{tile}>', 2.0 * m * n * w.K, 4.0 * (m * w.K + m * n) + 4.0 * n * w.K,
            lambda: _lib.check(lib.rsp_gemm(d, _stream()), "rsp_gemm"),
            detail=f'M={m} N={n} K={w.K}' + (' conv' if conv is not None else ''))

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-S2, S2_GENERIC, R2, PP = 40, 104, 1, 200
+S2, S2_GENERIC, R2, PP, PP128 = 40, 104, 1, 200, 201
 E_RES, E_GELU, E_C, E_PL, E_RMAP, E_GENERIC = 1, 2, 4, 8, 16, 64
 
 
@@ -64,11 +64,13 @@ def _check(fn, refs, want_epi, rows=None, tol=2e-6):
     assert fn(R2, plan_only=True) == -1
     for o, r in zip(base if isinstance(base, tuple) else (base,), refs):
         assert _rel(o, r, rows) < tol
-    for hint in (S2, S2_GENERIC, PP):     # PP: gemm_f16x3_pp_kernel (csrc/gemm_pp.hip), needs K >= 128
+    # PP / PP128: gemm_f16x3_pp_kernel (csrc/gemm_pp.hip, K >= 128) with its 256 x 256 and 128 x 256 tiles, also with one
+    # block per XCD (several tiles per block)
+    for hint in (S2, S2_GENERIC, PP, PP128, PP | (1 << 16), PP128 | (1 << 16)):
         try:
             got = fn(hint)
         except RuntimeError:
-            assert hint == PP and fn(PP, plan_only='pp') == 0   # not a descriptor that kernel implements (K < 128)
+            assert (hint & 0xff) in (PP, PP128) and fn(hint, plan_only='pp') == 0   # not a descriptor that kernel implements
             continue
         torch.cuda.synchronize()
         for o, r in zip(got if isinstance(got, tuple) else (got,), refs):
@@ -194,8 +196,9 @@ def test_s2_generic_epilogue_modes(dev):
 
 
 def test_s2_is_the_product_choice_for_the_encoder_shapes(dev):
-    """rsp_gemm's own choice (tile hint 0) for the ViT shapes at one image: the s2 kernel with the specialisation the
-    layer needs -- and the result is the same bits as with the hint"""
+    """rsp_gemm's own choice (tile hint 0) for the ViT shapes at two images: the s2 kernel with the specialisation the
+    layer needs, or (round 5) the ping-pong kernel where its tiles fill the CUs -- and the result is the same bits as with
+    the round-2 kernel"""
     from rsprompter_amd import ops
     g = torch.Generator().manual_seed(5)
     T, D = 8192, 1280                   # two 1024-px images of ViT-H: every encoder Linear has >= 256 tiles of 256 x 128
@@ -206,12 +209,13 @@ def test_s2_is_the_product_choice_for_the_encoder_shapes(dev):
     w, b, wq = _mk(g, 3 * D, D, dev)
     assert ops.gemm(xp, wq, out_planes=True, c_ncols=D, pl_col0=D, plan_only=True) == E_C | E_PL
     w1, b1, pw1 = _mk(g, 4 * D, D, dev)
-    assert ops.gemm(xp, pw1, act=ops.ACT_GELU, out_planes=True, out_f32=False, plan_only=True) == E_PL | E_GELU
+    assert (ops.gemm(xp, pw1, act=ops.ACT_GELU, out_planes=True, out_f32=False, plan_only=True) == E_PL | E_GELU or
+            ops.gemm(xp, pw1, act=ops.ACT_GELU, out_planes=True, out_f32=False, plan_only='pp') in (128, 256))
     h0 = ops.gemm(xp, pw1, act=ops.ACT_GELU, out_planes=True, out_f32=False)
     assert _same(h0, ops.gemm(xp, pw1, act=ops.ACT_GELU, out_planes=True, out_f32=False, tile_hint=R2))
     assert _rel(h0, F.gelu(x[sub].double() @ w1.double().t() + b1.double()), rows=sub) < 2e-6
     w2, b2, pw2 = _mk(g, D, 4 * D, dev)
-    assert ops.gemm(h0, pw2, res=xd, plan_only=True) == E_C | E_RES
+    assert ops.gemm(h0, pw2, res=xd, plan_only=True) == E_C | E_RES or ops.gemm(h0, pw2, res=xd, plan_only='pp') in (128, 256)
     y = ops.gemm(h0, pw2, res=xd)
     assert _same(y, ops.gemm(h0, pw2, res=xd, tile_hint=R2))
     assert _rel(y, _pl64(h0)[sub] @ w2.double().t() + b2.double() + x[sub].double(), rows=sub) < 2e-6

@@ -247,6 +247,41 @@ def test_emu_rle_codec_round_trip_property(emu):
     check()
 
 
+def test_emu_pingpong_gemm_several_tiles_per_block(emu):
+    """gemm_f16x3_pp_kernel (csrc/gemm_pp.hip, round 5: one 512-thread block per CU, the two waves of a SIMD alternating
+    matrix and load phases): both tiles (256 x 256: hint 200, 128 x 256: hint 201) with ONE and TWO blocks per XCD, so that a
+    block walks several tiles -- the next tile's first ring stages are queued from inside the epilogue, whose LDS
+    transposition lives in the wave's own DMA slots.  Bit-equal to gemm_f16x3_dma_kernel; also with the DMA completing as late
+    as the kernel's s_waitcnt immediates allow."""
+    import harness
+    import test_gpu_gemm_s2 as t
+    ops = emu
+    g = torch.Generator().manual_seed(6)
+
+    def run():
+        for (M, N, K, kw, name) in [(1100, 768, 256, dict(), 'plain'),
+                                    (1100, 768, 128, dict(act=ops.ACT_GELU, out_planes=True, out_f32=False), 'lin1-like'),
+                                    (1100, 768, 192, 'res', 'residual'), (900, 768, 128, 'qkv', 'qkv scatter')]:
+            a = torch.randn(M, K, generator=g)
+            w = torch.randn(N, K, generator=g) / K ** 0.5
+            b = torch.randn(N, generator=g)
+            pw = ops.PackedWeight(w, b, device=DEV)
+            ap = ops.to_planes(a)
+            if kw == 'res':
+                kw = dict(res=torch.randn(M, N, generator=g))
+            if kw == 'qkv':
+                perm = torch.randperm(M + 50, generator=g)[:M].to(torch.int32)
+                kw = dict(c_rowmap=perm, out_rows=M + 50, out_planes=True, c_ncols=256, pl_col0=256)
+            rows = kw['c_rowmap'].long() if 'c_rowmap' in kw else None
+            ref = t._flat(ops.gemm(ap, pw, tile_hint=1, **kw))
+            for hint in (200 | (1 << 16), 200 | (2 << 16) | (2 << 8), 201 | (1 << 16), 201 | (2 << 16) | (2 << 8)):
+                assert ops.gemm(ap, pw, tile_hint=hint, plan_only='pp', **kw) == (128 if hint & 1 else 256)
+                assert t._same(ref, t._flat(ops.gemm(ap, pw, tile_hint=hint, **kw)), rows), (name, hint)
+    run()
+    with harness.lazy_dma():
+        run()
+
+
 def test_emu_gemm_ragged_shapes_property(emu):
     """C = act(A W^T + b) + res for random ragged shapes through whatever kernel the dispatcher picks (fp32 A: the
     register-staged kernel; planes: gemm_f16x3_dma_kernel; hint 40: the persistent kernel) against the fp64 product"""

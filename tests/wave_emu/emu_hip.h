@@ -748,11 +748,28 @@ inline emu_u32x4 emu_amdgcn_raw_buffer_load_b128(emu_rsrc r, int voff, int soff,
 inline unsigned emu_amdgcn_raw_buffer_load_b32(emu_rsrc r, int voff, int soff, int) {
   unsigned v; emu_buf_read(r, (int64_t)(unsigned)voff + (unsigned)soff, &v, 4); return v;
 }
+// A buffer STORE takes a place in the wave's vmcnt order (vmcnt retires in order and counts stores): gemm_pp2.hip issues
+// epilogue stores between its DMA instructions and counts them in its s_waitcnt immediates.  One marker per wave
+// instruction (pushed by the wave's first live lane; lanes run one after the other up to the next rendezvous, so the marker
+// sits in front of every DMA instruction that follows it in program order).
+namespace emu {
+inline void vmem_store_marker() {
+  if (!g.lazy_dma) return;
+  Fiber& f = cur();
+  Wave& w = *f.wave;
+  if (f.lane != __builtin_ctzll(w.live_mask)) return;
+  DmaOp op;
+  op.mask = 0; op.base = nullptr; op.size = 0;
+  w.dmaq.push_back(op);
+}
+}  // namespace emu
 inline void emu_amdgcn_raw_buffer_store_b128(emu_u32x4 v, emu_rsrc r, int voff, int soff, int) {
   emu_buf_write(r, (int64_t)(unsigned)voff + (unsigned)soff, &v, 16);
+  emu::vmem_store_marker();
 }
 inline void emu_amdgcn_raw_buffer_store_b64(emu_u32x2 v, emu_rsrc r, int voff, int soff, int) {
   emu_buf_write(r, (int64_t)(unsigned)voff + (unsigned)soff, &v, 8);
+  emu::vmem_store_marker();
 }
 
 // ---- DMA to LDS: every lane fetches `size` bytes from its own global address; the LDS address is wave-uniform

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round 5, GPU call 4: the deferred-epilogue ping-pong GEMM (gemm_pp2.hip): parity tests, micro-benchmark, step A/B, then
+# (development build) its tile time stamps
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+O=gpurun_out/r5/job4
+mkdir -p $O
+t0=$(date +%s)
+timeout 300 python -m pytest -m gpu -q -x tests/test_gpu_gemm_s2.py > $O/gemm_tests.log 2>&1
+echo "[gemm tests] rc=$? $(( $(date +%s) - t0 )) s: $(tail -n 1 $O/gemm_tests.log)"; grep -E "Error|assert|FAILED" $O/gemm_tests.log | head -n 10
+timeout 300 python tools/gemm_pp_exp.py huge 8 > $O/pp_huge.txt 2>&1; echo "[pp huge] rc=$? $(( $(date +%s) - t0 )) s"; cat $O/pp_huge.txt | cut -c1-400
+timeout 300 python tools/gemm_pp_exp.py base 8 > $O/pp_base.txt 2>&1; echo "[pp base] rc=$? $(( $(date +%s) - t0 )) s"; cat $O/pp_base.txt | cut -c1-400
+timeout 300 python tools/gemm_pp_exp.py large 16 > $O/pp_large.txt 2>&1; echo "[pp large] rc=$? $(( $(date +%s) - t0 )) s"; cat $O/pp_large.txt | cut -c1-400
+timeout 400 python tools/ab_bench.py --kernels --steps 4 --rounds 3 "s2:ops.PP_AUTO=False" "pp:ops.PP_AUTO=True" > $O/ab_huge.txt 2> $O/ab_huge.err
+echo "[ab huge] rc=$? $(( $(date +%s) - t0 )) s"; cat $O/ab_huge.txt | cut -c1-220; tail -n 3 $O/ab_huge.err
+export RSP_DEV_BUILD=1
+timeout 600 python -m rsprompter_amd.build > $O/dev_build.log 2>&1; echo "[dev build] rc=$? $(( $(date +%s) - t0 )) s"
+timeout 300 python tools/gemm_pp_exp.py trace2 huge > $O/pp2_trace.txt 2>&1; echo "[trace2] rc=$? $(( $(date +%s) - t0 )) s"; cat $O/pp2_trace.txt | cut -c1-700
+bash tools/gpu_job.sh r5/job4 "m:pp2:python tools/gemm_pp_exp.py huge 8"
+echo "[done] $(( $(date +%s) - t0 )) s"
