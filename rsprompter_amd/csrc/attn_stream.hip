@@ -26,6 +26,13 @@
 //     register-pipelined LDS fragment reads (kept), a software-pipelined tile loop with QK^T of tile t + 1 interleaved
 //     into the softmax of tile t by sched_group_barrier (ISA showed the interleave; 3.26 vs 3.13 ms, removed), and
 //     de-phasing the two waves of a SIMD (no change).  The remaining lever is fewer VALU instructions per score.
+//     Round 5 (after the compute / load alternation took the GEMM's K loop to the matrix pipe's own pace, gemm_pp.hip): the
+//     same alternation here -- waves 0-3 / 4-7 of a block pairwise on the SIMDs, one in a pure matrix phase (PV of tile
+//     t - 1, then QK^T of tile t) while its partner runs softmax, P split and DMA issue, s_barrier between phases, separate
+//     two-deep K and V rings -- was built, verified on the emulator and measured on the MI355X: bit-equal, 2.04 vs 2.09 ms
+//     (ViT-H, 4096 tokens), and with the step's MFMAs issued pass-major over independent accumulators 2.22 vs 2.19 ms.
+//     At 313-337 TFLOP/s the kernel keeps the matrix pipe ~60 % busy -- the class of the GEMM (73 %) -- so neither wave
+//     ordering nor dependent-MFMA spacing is what is left here; removed (gpurun_out/r5).
 #include <stdlib.h>
 #include <type_traits>
 #include "rsp_common.h"

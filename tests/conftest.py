@@ -13,6 +13,31 @@ def pytest_configure(config):
     # the parity tests read intermediate tensors the predict path only keeps on request (rsprompter_amd/debug.py)
     import rsprompter_amd.debug as dbg
     dbg.KEEP_TRACES = True
+    _memoise_synth_tensors()
+
+
+def _memoise_synth_tensors(cap_bytes=12 << 30):
+    """The seeded synthetic weights are pure functions of (seed, key, shape, dtype) (rsprompter_amd/synth.py); the suite
+    builds the same ViT-H / ViT-L state dicts many times (oracle and product side of every end-to-end test: ~4 s of
+    torch.randn per ViT-H tree).  Memoised for the session; load_state_dict copies, nobody writes into the cached tensors."""
+    import rsprompter_amd.synth as synth
+    if getattr(synth, '_memo_installed', False):
+        return
+    cache, used = {}, [0]
+    plain = synth.synth_tensor
+
+    def cached(name, ref, seed=0):
+        key = (seed, name, tuple(ref.shape), str(ref.dtype))
+        t = cache.get(key)
+        if t is None:
+            t = plain(name, ref, seed)
+            nb = t.numel() * t.element_size()
+            if used[0] + nb <= cap_bytes:
+                cache[key] = t
+                used[0] += nb
+        return t
+    synth.synth_tensor = cached
+    synth._memo_installed = True
 
 
 @pytest.fixture(scope='session')

@@ -220,20 +220,35 @@ def test_query_nwpu_peft512_config(dev):
     _check_query(model, oracle, imgs, metas, dev, 'query peft-512')
 
 
+_SHARED = {}
+
+
+def _vith_anchor_shared(dev):
+    """configs[3] fixture of the two ViT-H anchor tests: ONE model, ONE oracle run (tiles 0, 1, 7 of the bench batch) -- the CPU
+    oracle's ViT-H forward costs ~25 s per tile, and the suite runs against a wall-clock limit"""
+    if 'vith_anchor' not in _SHARED:
+        from oracle import glue
+        from oracle.anchor import AnchorOracle
+        from rsprompter_amd.default_configs import rsprompter_anchor
+        from rsprompter_amd.synth import synth_images, synth_metas
+        oracle = AnchorOracle('huge', 10)
+        model = _build(rsprompter_anchor('huge', 10), oracle, dev)
+        imgs, metas = synth_images(8, seed=1234), synth_metas(8)
+        pick = [0, 1, 7]
+        x = glue.data_preprocess([imgs[b] for b in pick], MEAN, STD, True, 32)
+        ref, tr = oracle.predict(x, [metas[b] for b in pick])
+        _SHARED['vith_anchor'] = dict(oracle=oracle, model=model, imgs=imgs, metas=metas, pick=pick, ref=ref, tr=tr)
+    return _SHARED['vith_anchor']
+
+
 def test_config3_anchor_vith_batch2(dev):
     """BASELINE.json configs[3] per-GPU slice (rsprompter_anchor, SAM ViT-H; `_base_/rsprompter_anchor.py` defaults are
     huge): 2 tiles free-running; detections matched to the oracle's, then the LOW-RES MASK LOGITS of the matched
     instances compared (the anchor path's logits depend on which boxes were detected, hence the matching)."""
-    from oracle import glue
-    from oracle.anchor import AnchorOracle
-    from rsprompter_amd.default_configs import rsprompter_anchor
-    from rsprompter_amd.synth import synth_images, synth_metas
     B = 2
-    oracle = AnchorOracle('huge', 10)
-    model = _build(rsprompter_anchor('huge', 10), oracle, dev)
-    imgs, metas = synth_images(B), synth_metas(B)
-    x = glue.data_preprocess(imgs, MEAN, STD, True, 32)
-    ref, tr = oracle.predict(x, metas)
+    sh = _vith_anchor_shared(dev)
+    model, imgs, metas = sh['model'], sh['imgs'][:B], sh['metas'][:B]
+    ref, tr = sh['ref'], sh['tr']                         # oracle run on tiles 0, 1, 7: the first two are this test's
     out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
     low = model.roi_head._last_mask_trace['mask_preds'].cpu()                # [sum k, 1, 256, 256], image-major
     assert low.shape[0] == sum(o.pred_instances.labels.shape[0] for o in out)
@@ -253,31 +268,25 @@ def test_config3_anchor_vith_batch2(dev):
         worst = max(worst, e_low)
         ours0 += pi.labels.shape[0]
         ref0 += k
-    e_emb = _maxerr(model._last_embeddings, tr['image_embeddings'])
+    e_emb = _maxerr(model._last_embeddings, tr['image_embeddings'][:B])
     print(f'configs[3]: image embedding err {e_emb:.2e}, worst matched mask-logit err {worst:.2e}')
     assert e_emb < LOGIT_TOL
 
 
 def test_config3_anchor_vith_bench_batch8(dev):
     """The bench's own batch (bench.py default: rsprompter_anchor SAM ViT-H, 8 tiles per step, 800 prompt sets through
-    the SAM decoder): images 0, 3 and 7 of the free-running batch-8 step against the oracle run on those three tiles
-    (images are independent; the oracle cost is 3 tiles).  Round 1's ViT-H bench ran on NaN neck rows unnoticed because
+    the SAM decoder): images 0, 1 and 7 of the free-running batch-8 step against the oracle run on those three tiles
+    (images are independent; the oracle run -- 3 tiles -- is shared with test_config3_anchor_vith_batch2).  Round 1's ViT-H bench ran on NaN neck rows unnoticed because
     no test looked at this configuration at this batch."""
-    from oracle import glue
-    from oracle.anchor import AnchorOracle
-    from rsprompter_amd.default_configs import rsprompter_anchor
-    from rsprompter_amd.synth import synth_images, synth_metas
-    B, pick = 8, [0, 3, 7]
-    oracle = AnchorOracle('huge', 10)
-    model = _build(rsprompter_anchor('huge', 10), oracle, dev)
-    imgs, metas = synth_images(B, seed=1234), synth_metas(B)
+    sh = _vith_anchor_shared(dev)
+    B, pick = 8, sh['pick']
+    model, imgs, metas = sh['model'], sh['imgs'], sh['metas']
     out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
     low = model.roi_head._last_mask_trace['mask_preds'].cpu()                # [sum k, 1, 256, 256], image-major
     emb = model._last_embeddings.cpu()
     ks = [int(o.pred_instances.labels.shape[0]) for o in out]
     assert low.shape[0] == sum(ks) and bool(torch.isfinite(low).all()) and bool(torch.isfinite(emb).all())
-    x = glue.data_preprocess([imgs[b] for b in pick], MEAN, STD, True, 32)
-    ref, tr = oracle.predict(x, [metas[b] for b in pick])
+    ref, tr = sh['ref'], sh['tr']
     ref0 = 0
     for n, b in enumerate(pick):
         pi, r = out[b].pred_instances, ref[n]
