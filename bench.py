@@ -321,6 +321,9 @@ def main():
     ap.add_argument('--f8corr', action='store_true',
                     help='opt-in fast mode: encoder GEMMs as fp16 hi.hi + one fp8 correction MFMA (DESIGN.md section 3); '
                          'NOT the headline configuration -- parity margins are 8x smaller')
+    ap.add_argument('--exchange', choices=['gather', 'allgather'], default='gather',
+                    help="N > 1: where the per-image results of a step go -- 'gather': rank 0 only (mmengine collect_results, "
+                         "what tools/dist_test.sh evaluates); 'allgather': every rank (BASELINE.json north_star's wording)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -377,7 +380,7 @@ def main():
         if world > 1:
             if pending[0] is not None:
                 pending[0].collect()
-            pending[0] = rdist.gather_results(res, dataset_size=world * B, stream=side, dst=0)
+            pending[0] = rdist.gather_results(res, dataset_size=world * B, stream=side, dst=0 if args.exchange == 'gather' else None)
         return res
 
     def sync():
@@ -454,7 +457,7 @@ def main():
             'config': {'workload': f'rsprompter_{args.model} SAM-ViT-{args.arch}' + (' + LoRA(qkv r16)' if args.lora else '') + f', batch {B}x1024x1024 per GPU, '
                                    f'{num_classes} classes, seeded synthetic weights' + _config_tag(args, B, world),
                        'images_per_gpu_per_step': B, 'detections_per_step_rank0': n_dets,
-                       'parallelism': f'dp{world} (images sharded by batch, result gather to rank 0 over RCCL)' if world > 1 else 'single GPU',
+                       'parallelism': (f'dp{world} (images sharded by batch, result ' + ('gather to rank 0' if args.exchange == 'gather' else 'all-gather') + ' over RCCL)') if world > 1 else 'single GPU',
                        },
             'roofline': {'bound': 'mfma', 'kernel': dom_name, 'launches_per_step': dom['calls'],
                          'ms_per_step': round(dom['ms'], 3), 'achieved': round(achieved, 2),

@@ -32,6 +32,11 @@
 // phases -- was built and measured: bit-exact, and 5-15 % SLOWER than BM = 256 everywhere: its 3 x 48 KB ring leaves ~2
 // phases of DMA slack, VALU beside the partner's MFMA stream runs at a quarter of its rate, and untransposed stores cost
 // the texture path 32 lines per instruction; profiles/r5_gemm_pp2_negative/.)
+// (Also measured and dropped: splitting the tiles of an XCD's ragged last round in K among its idle blocks -- partial sums
+// through a workspace tile, release / acquire flags -- for the 2.5-round shapes (ViT-H lin2 / proj: 640 tiles).  Correct
+// (1e-6 of the unsplit sums, emulator + GPU), but worth +3 % on lin2 and -14 % on proj: the chip runs these kernels at
+// its POWER limit, and a half-empty last round simply clocks higher -- the idle CUs are not the loss they look like.
+// profiles/r5_gemm_pp_split_tail_negative/.)
 // Scope: what gemm_s2.hip's specialised epilogues cover (plain plane-path GEMMs); chosen by rsp_gemm for shapes with
 // enough tiles to fill the 256 CUs several times (rsp_gemm_pp_auto).
 #include <type_traits>

@@ -332,7 +332,12 @@ def gemm(a, w, *, out=None, bias="auto", res=None, act=ACT_NONE, a_rowmap=None, 
     if (c_ncols or pl_col0) and not (is_planes and out_planes):
         raise ValueError('column-range outputs (c_ncols / pl_col0) belong to the plane path with out_planes=True')
     if out_planes:
-        pl = empty_planes((rows, n - pl_col0), a.device, f8=out_f8)
+        if isinstance(out_planes, Planes):         # a caller-owned plane tensor (rows the GEMM does not map keep their contents)
+            pl = out_planes
+            if tuple(pl.shape) != (rows, n - pl_col0) or pl.f8 != bool(out_f8):
+                raise ValueError('out_planes: a Planes tensor of the output\'s shape and format')
+        else:
+            pl = empty_planes((rows, n - pl_col0), a.device, f8=out_f8)
         d.Chi, d.Clo, d.c_scale_log2, d.c_rows = pl.hi.data_ptr(), pl.lo.data_ptr(), pl.word, rows
     d.c_ncols, d.pl_col0 = c_ncols, pl_col0
     if out is None and out_f32:

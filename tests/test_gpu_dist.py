@@ -139,7 +139,7 @@ def test_gather_results_device_codec_side_stream(dev):
                 assert np.array_equal(dec, r.masks[j].cpu().numpy())
 
 
-def _worker_rle(rank, world, port, ret):
+def _worker_rle(rank, world, port, ret, dst=0):
     os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))
     import torch.distributed as dist
@@ -148,7 +148,7 @@ def _worker_rle(rank, world, port, ret):
     try:
         rdist.init_from_env(backend='gloo')
         side = torch.cuda.Stream(device=dev)
-        got = rdist.gather_results(_blob_results(rank, 2, dev), dataset_size=4, stream=side).collect()
+        got = rdist.gather_results(_blob_results(rank, 2, dev), dataset_size=4, stream=side, dst=dst).collect()
         ret[rank] = None if got is None else list(got)
         dist.barrier()
         dist.destroy_process_group()
@@ -156,27 +156,31 @@ def _worker_rle(rank, world, port, ret):
         ret[rank] = repr(e)
 
 
-def test_gather_results_two_ranks_on_one_device():
-    """two processes sharing cuda:0 over gloo (the calls bench.py issues over RCCL): results reach rank 0 only, in
-    dataset order (item j = image j // 2 of rank j % 2)."""
+@pytest.mark.parametrize('dst', [0, None])
+def test_gather_results_two_ranks_on_one_device(dst):
+    """two processes sharing cuda:0 over gloo (the calls bench.py issues over RCCL): results reach rank 0 only (dst = 0:
+    mmengine collect_results, `bench.py --exchange gather`) or EVERY rank (dst = None: the north star's all-gather,
+    `--exchange allgather`), in dataset order (item j = image j // 2 of rank j % 2)."""
     from oracle import rle as orle
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_worker_rle, args=(2, port, ret), nprocs=2, join=True)
+    mp.spawn(_worker_rle, args=(2, port, ret, dst), nprocs=2, join=True)
     if isinstance(ret[0], str) or isinstance(ret[1], str):
         msg = f'{ret[0]} / {ret[1]}'
         if 'gloo' in msg.lower() or 'not supported' in msg.lower() or 'not implemented' in msg.lower():
             pytest.skip(f'gloo cannot run this collective on device tensors here: {msg[:200]}')
         raise AssertionError(msg)
-    assert ret[1] is None and len(ret[0]) == 4
+    assert (ret[1] is None) == (dst == 0) and len(ret[0]) == 4
     cpu = torch.device('cpu')
-    for j, g in enumerate(ret[0]):
-        r = _blob_results(j % 2, 2, cpu)[j // 2]
-        assert torch.equal(g['bboxes'], r.bboxes) and len(g['masks']) == len(r.bboxes)
-        for t, rle in enumerate(g['masks']):
-            dec = orle.rle_decode(orle.rle_from_string(rle['counts']), *rle['size'])
-            assert np.array_equal(dec, r.masks[t].numpy())
+    for rank in ((0,) if dst == 0 else (0, 1)):
+        assert len(ret[rank]) == 4
+        for j, g in enumerate(ret[rank]):
+            r = _blob_results(j % 2, 2, cpu)[j // 2]
+            assert torch.equal(g['bboxes'], r.bboxes) and len(g['masks']) == len(r.bboxes)
+            for t, rle in enumerate(g['masks']):
+                dec = orle.rle_decode(orle.rle_from_string(rle['counts']), *rle['size'])
+                assert np.array_equal(dec, r.masks[t].numpy())
 
 
 def _step_loop(model, imgs, metas, dev, world, n_steps, group_kw, stats=None):

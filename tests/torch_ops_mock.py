@@ -66,6 +66,9 @@ def gemm(a, w, *, out=None, bias='auto', res=None, act=0, a_rowmap=None, c_rowma
     if act == ACT_RELU_POST:
         y = F.relu(y)
     out[crow[keep]] = y[keep]
+    if isinstance(out_planes, torch.Tensor):      # caller-owned plane tensor: rows nobody maps keep their contents
+        out_planes[crow[keep]] = y[keep][:, pl_col0:]
+        return out[:, :c_ncols].contiguous() if c_ncols else out, out_planes
     if c_ncols or pl_col0:       # column-range outputs: fp32 = first c_ncols columns, "planes" = columns from pl_col0 on
         return out[:, :c_ncols].contiguous(), out[:, pl_col0:].contiguous()
     return (out, out) if (out_planes and out_f32) else out
