@@ -124,6 +124,70 @@ __global__ __launch_bounds__(256) void layernorm_rows4_kernel(const float* __res
   }
 }
 
+// ... and with EIGHT consecutive columns per lane (C % 128 == 0, fp16 planes): a lane's plane stores are 16 bytes instead of 8
+// (8-byte accesses run at 0.54-0.70 of the 16-byte rate, MI355X_MICROARCH.md), a store instruction writes four runs of 256
+// contiguous bytes, and the kernel issues half as many of them (round 5).
+template <int NC8>  // 8-column chunks per lane: C = 128 * NC8
+__global__ __launch_bounds__(256) void layernorm_rows4x8_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ y,
+                                                                int64_t rows, float eps, int act, half_t* __restrict__ yhi,
+                                                                half_t* __restrict__ ylo, float pscale) {
+  constexpr int C = 128 * NC8;
+  const int lane = threadIdx.x & 63, c16 = lane & 15;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const bool rv = row < rows;
+  const float* xr = x + (rv ? row : 0) * C;
+  f32x4 v[NC8][2];
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC8; ++i) {
+    v[i][0] = *reinterpret_cast<const f32x4*>(xr + (c16 + 16 * i) * 8);
+    v[i][1] = *reinterpret_cast<const f32x4*>(xr + (c16 + 16 * i) * 8 + 4);
+    sum += ((v[i][0][0] + v[i][0][1]) + (v[i][0][2] + v[i][0][3])) + ((v[i][1][0] + v[i][1][1]) + (v[i][1][2] + v[i][1][3]));
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum / (float)C;
+  float sq = 0.f;
+#pragma unroll
+  for (int i = 0; i < NC8; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float dlt = v[i][h][j] - mean;
+        sq += dlt * dlt;
+      }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = 1.0f / sqrtf(sq / (float)C + eps);
+  if (!rv) return;
+#pragma unroll
+  for (int i = 0; i < NC8; ++i) {
+    const int c = (c16 + 16 * i) * 8;
+    half8_t h8, l8;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c + 4 * h);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(beta + c + 4 * h);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t = (v[i][h][j] - mean) * rstd * g[j] + b[j];
+        if (act == RSP_ACT_GELU) t = rsp_gelu(t);
+        o[j] = t;
+        half_t a, bb;
+        rsp_split1(t * pscale, a, bb);
+        h8[4 * h + j] = a; l8[4 * h + j] = bb;
+      }
+      if (y) *reinterpret_cast<f32x4*>(y + row * C + c + 4 * h) = o;
+    }
+    const int64_t po = ((int64_t)(c >> 5) * rows + row) * 32 + (c & 31);   // KB32 layout
+    *reinterpret_cast<half8_t*>(yhi + po) = h8;
+    *reinterpret_cast<half8_t*>(ylo + po) = l8;
+  }
+}
+
 // C <= 64: a 16-lane group per row (4 rows per wave) so that no lane idles
 __global__ __launch_bounds__(256) void layernorm_small_kernel(const float* __restrict__ x,
                                                               const float* __restrict__ gamma,
@@ -198,6 +262,19 @@ extern "C" int rsp_layernorm_ex(const float* x, const float* gamma, const float*
   if (yhi && (C & 63) == 0 && C >= 256 && C <= 1280) {          // the encoder's plane-producing LayerNorms
     const int64_t blocks16 = (rows + 15) / 16;
     if (blocks16 > 0x7fffffffLL) return RSP_EINVAL;
+    if (!f8 && (C & 127) == 0) {      // (ViT-H rows: 4.07 -> 4.36 TB/s; profiles/r5_layernorm_x8_vs_x4.txt)
+#define RSP_LN8_LAUNCH(NC) hipLaunchKernelGGL((layernorm_rows4x8_kernel<NC>), dim3((unsigned)blocks16), dim3(256), 0, s, x, gamma, beta, y, rows, eps, act, hi, lo, ps)
+      switch (C / 128) {
+        case 2: RSP_LN8_LAUNCH(2); break;
+        case 4: RSP_LN8_LAUNCH(4); break;
+        case 6: RSP_LN8_LAUNCH(6); break;
+        case 8: RSP_LN8_LAUNCH(8); break;
+        default: RSP_LN8_LAUNCH(10); break;
+      }
+#undef RSP_LN8_LAUNCH
+      RSP_CHECK_LAUNCH();
+      return RSP_OK;
+    }
 #define RSP_LN4_LAUNCH(NC) hipLaunchKernelGGL((layernorm_rows4_kernel<NC>), dim3((unsigned)blocks16), dim3(256), 0, s, x, gamma, beta, y, rows, eps, act, hi, lo, ps, f8)
     switch (C / 64) {
       case 4: RSP_LN4_LAUNCH(4); break;
