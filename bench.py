@@ -275,7 +275,7 @@ def _pmc_traffic(arch):
     process, so the number is the one measured with tools/pmc_round2.sh on the kernel's most expensive shape of this
     architecture; None when no pass exists for it."""
     root = os.path.dirname(os.path.abspath(__file__))
-    for rel in (f'profiles/r4_pmc/gemm_traffic_{arch}.json', f'profiles/r3_pmc/gemm_traffic_{arch}.json', f'profiles/r2_pmc/gemm_traffic_{arch}.json', 'profiles/r1_pmc/gemm_lin1_traffic.json'):
+    for rel in (f'profiles/r5_pmc/gemm_traffic_{arch}.json', f'profiles/r4_pmc/gemm_traffic_{arch}.json', f'profiles/r3_pmc/gemm_traffic_{arch}.json', f'profiles/r2_pmc/gemm_traffic_{arch}.json', 'profiles/r1_pmc/gemm_lin1_traffic.json'):
         try:
             with open(os.path.join(root, rel)) as fh:
                 t = json.load(fh)

@@ -10,6 +10,7 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'quick: kernel-level GPU tests (-m "gpu and quick": the tier run between performance experiments)')
     # the parity tests read intermediate tensors the predict path only keeps on request (rsprompter_amd/debug.py)
     import rsprompter_amd.debug as dbg
     dbg.KEEP_TRACES = True

@@ -10,7 +10,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.quick]      # quick: the kernel-level tier (`-m "gpu and quick"`, < 2 min)
 
 S2, S2_GENERIC, R2, PP, PP128 = 40, 104, 1, 200, 201
 E_RES, E_GELU, E_C, E_PL, E_RMAP, E_GENERIC = 1, 2, 4, 8, 16, 64

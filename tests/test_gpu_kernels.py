@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.quick]      # quick: the kernel-level tier (`-m "gpu and quick"`, < 2 min)
 
 
 def _rel_err(got, ref):

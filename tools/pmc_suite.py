@@ -78,7 +78,7 @@ def main():
             if only and name not in only:
                 continue
             ms = timed(fn, args.iters)
-            print(json.dumps(dict(group=name, kernel='gemm_f16x3_s2_kernel', tile='256x128', M=m, N=n, K=k, ms=round(ms, 4),
+            print(json.dumps(dict(group=name, kernel='rsp_gemm (gemm_f16x3_pp_kernel where its tiles fill the CUs, else gemm_f16x3_s2_kernel)', M=m, N=n, K=k, ms=round(ms, 4),
                                   tflops=round(2.0 * m * n * k / ms / 1e9, 1), launches=args.iters + 1)), flush=True)
     if 'attn' in what:
         for name, Bp, S in (('attn_global', B, 64), ('attn_window', B * 25, 14)):

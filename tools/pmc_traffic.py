@@ -1,21 +1,25 @@
-"""profiles/<dir>/report.json (tools/pmc_report.py) -> the `roofline.traffic` record bench.py reads:
-memory-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md) of the most expensive GEMM shape.
-  python tools/pmc_traffic.py profiles/r2_pmc_final/report.json huge > profiles/r2_pmc/gemm_traffic_huge.json"""
+"""profiles/r5_pmc/gemm_traffic_<arch>.json from a pmc_report.py JSON: memory-side bytes per launch of the most expensive
+GEMM shape (lin1) for bench.py's `roofline.traffic`.   python tools/pmc_traffic.py <report.json> <arch> <batch> <out.json>"""
 import json
 import sys
 
-rep = json.load(open(sys.argv[1]))
-arch = sys.argv[2] if len(sys.argv) > 2 else 'huge'
-SHAPES = {'huge': dict(M=32768, N=5120, K=1280, tile=(256, 256)), 'base': dict(M=32768, N=3072, K=768, tile=(256, 256))}
-sh = SHAPES[arch]
-grid = -(-sh['M'] // sh['tile'][0]) * -(-sh['N'] // sh['tile'][1]) * 512          # threads: blocks x 512
-rows = [r for r in rep if r['kernel'].startswith('gemm_f16x3_dma_kernel<256, 256') and r['grid'] == grid]
-if not rows:
-    raise SystemExit(f'no 256x256 GEMM dispatch with grid {grid} in {sys.argv[1]}')
-d = rows[0]['derived']
-alg = 4 * (sh['M'] * sh['K'] + sh['N'] * sh['K'] + sh['M'] * sh['N'])
-print(json.dumps(dict(shape=f"lin1 M={sh['M']} N={sh['N']} K={sh['K']} (GELU, plane output), tile 256x256",
-                      traffic_bytes_per_launch=int(d['read_bytes'] + d['write_bytes']), read_bytes=int(d['read_bytes']),
-                      write_bytes=int(d['write_bytes']), algorithmic_bytes_per_launch=alg,
-                      l2_hit_pct=round(d.get('l2_hit_pct', 0), 1), mfma_busy_pct=round(d.get('mfma_busy_pct', 0), 1),
-                      source=sys.argv[1]), indent=1))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+from rsprompter_amd.nnutil import SAM_ARCH  # noqa: E402
+
+rep, arch, batch, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+a = SAM_ARCH[arch]
+M, N, K = batch * 4096, a['mlp'], a['hidden']
+rows = [r for r in json.load(open(rep)) if 'gemm' in r['kernel'] and 'read_bytes' in r['derived'] and 'write_bytes' in r['derived']]
+r = max(rows, key=lambda r: r['counters'].get('SQ_WAVE_CYCLES', 0))
+d = r['derived']
+json.dump({
+    'shape': f'lin1 M={M} N={N} K={K} (GELU, plane output), {r["kernel"]}',
+    'traffic_bytes_per_launch': int(d['read_bytes'] + d['write_bytes']),
+    'read_bytes': int(d['read_bytes']), 'write_bytes': int(d['write_bytes']),
+    'algorithmic_bytes_per_launch': 4 * (M * K + N * K + M * N),
+    'l2_hit_pct': round(d.get('l2_hit_pct', 0.0), 1), 'mfma_busy_pct': round(d.get('mfma_busy_pct', 0.0), 1),
+    'note': 'FETCH_SIZE x 2 KiB + WRITE_SIZE KiB (MI355X_MICROARCH.md, gfx950 correction), separate --pmc passes; FETCH_SIZE counts '
+            'L2 -> fabric reads, i.e. it includes requests the 256 MB Infinity Cache answers',
+    'source': f'{rep} (tools/r5_final.sh, rocprofv3 --pmc, one counter group per pass)',
+}, open(out, 'w'), indent=1)
+print(open(out).read())
