@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, GPU call 6: staggered block starts of the ping-pong GEMM (epilogue bursts against HBM write bandwidth), tile time stamps
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
-O=gpurun_out/r5/job6
+O=gpurun_out/r5/gemm_pp_alone
 mkdir -p $O
 export RSP_DEV_BUILD=1
 t0=$(date +%s)

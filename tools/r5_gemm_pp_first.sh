@@ -2,7 +2,7 @@
 # Round 5, GPU call 2: the ping-pong GEMM's first run on an MI355X: parity tests, micro-benchmark against gemm_s2 on the
 # encoder shapes, A/B of the whole step.
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
-O=gpurun_out/r5/job2
+O=gpurun_out/r5/gemm_pp_first
 mkdir -p $O
 t0=$(date +%s)
 timeout 300 python -m pytest -m gpu -q -x tests/test_gpu_gemm_s2.py > $O/gemm_tests.log 2>&1
