@@ -66,12 +66,17 @@ __device__ __forceinline__ void split8s(const float* x, half8_t& hi, half8_t& lo
 // Split of values known to be inside the fp16 range (probabilities * 2^14, scaled q): no saturation needed, and the hi
 // part may be TRUNCATED -- the remainder is then non-negative and lo = rtz(x - hi) still carries the next 11 bits, so
 // hi + lo holds ~21 bits, the same class as the round-to-nearest pair.  v_cvt_pkrtz_f16_f32 converts two values per
-// instruction: 3 VALU ops per element instead of 7 (the attention kernels are VALU-issue bound, PMC r2).
+// instruction: 2 VALU ops per element (round 5; 3 with the back conversion of rounds 2-4) instead of 7 (the attention
+// kernels are VALU-issue bound, PMC r2).
 __device__ __forceinline__ void split8_fast(const float* x, half8_t& hi, half8_t& lo) {
+  float m1 = -1.0f;
+  asm volatile("" : "+v"(m1));
 #pragma unroll
   for (int i = 0; i < 8; i += 2) {
     const half2_t h2 = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(x[i], x[i + 1]));
-    const float r0 = x[i] - (float)h2[0], r1 = x[i + 1] - (float)h2[1];
+    // x - hi, exact, as ONE v_fma_mix_f32 each (the fp16 half is a source of the fp32 fma: no v_cvt_f32_f16 in front)
+    // (the multiplier sits in a register the optimiser cannot see through: written as x - (float)h the compiler converts first)
+    const float r0 = __builtin_fmaf((float)h2[0], m1, x[i]), r1 = __builtin_fmaf((float)h2[1], m1, x[i + 1]);
     const half2_t l2 = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
     hi[i] = h2[0]; hi[i + 1] = h2[1]; lo[i] = l2[0]; lo[i + 1] = l2[1];
   }
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   }
   // ---- rel-pos bias in the log2 domain ----
   // rel_w of this lane's key columns (tile invariant) + one rel_h per key row
-  float bw[2][16];                                    // rel_w of key columns 0..31 and 32..63 (mod S) for this lane
+  f32x16 bw[2];                                       // rel_w of key columns 0..31 and 32..63 (mod S) for this lane
   const float* rq = rel_b + (int64_t)(qv ? q : 0) * (2 * S);
 #pragma unroll
   for (int blk = 0; blk < 2; ++blk)
@@ -231,6 +236,9 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
     for (int r = 0; r < 16; ++r) acc_o[db][r] = 0.f;
   float m_run = -INFINITY, l_run = 0.f;
   const float s_unscale2 = ldexpf(1.0f, -(EQ + p.kv_e)) * LOG2E_C;
+  f32x16 s_unscale16;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s_unscale16[r] = s_unscale2;
 
   // per-lane byte offsets of the transposing V reads (see header): row = 4 hh + (i >> 2), d = 16 g16 + 4 (i & 3)
   const int li = lane & 15, g16 = (lane >> 4) & 1;
@@ -294,11 +302,9 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
 #pragma unroll
       for (int blk = 0; blk < NBLK; ++blk) {
         float tm = -INFINITY;
+        sc[blk] = __builtin_elementwise_fma(sc[blk], s_unscale16, bw[blk]);      // 8 v_pk_fma_f32
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          sc[blk][r] = fmaf(sc[blk][r], s_unscale2, bw[blk][r]);
-          tm = fmaxf(tm, sc[blk][r]);
-        }
+        for (int r = 0; r < 16; ++r) tm = fmaxf(tm, sc[blk][r]);
         k0s[blk] = blk == 0 ? bh0 : bh1;                 // the key row's rel_h enters as one scalar per block
         tmax = fmaxf(tmax, tm + k0s[blk]);
       }
@@ -310,9 +316,10 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
 #pragma unroll
     for (int blk = 0; blk < NBLK; ++blk) {
       const float kk = k0s[blk] - m_new + P_SCALE_LOG2;
+      sc[blk] = sc[blk] + kk;                                                    // 8 v_pk_add_f32
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(sc[blk][r] + kk);
+        const float pv = __builtin_amdgcn_exp2f(sc[blk][r]);
         sc[blk][r] = pv;
         if constexpr (!LSUM_MFMA) psum += pv;
       }

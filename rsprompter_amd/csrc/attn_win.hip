@@ -70,12 +70,14 @@ __device__ __forceinline__ void split8w(const float* x, half8_t& hi, half8_t& lo
   }
 }
 
-// values inside the fp16 range: truncating split, 3 VALU per 2 elements more than nothing (attn_stream.hip split8_fast)
+// values inside the fp16 range: truncating split, 2 VALU per element (attn_stream.hip split8_fast)
 __device__ __forceinline__ void split8w_fast(const float* x, half8_t& hi, half8_t& lo) {
+  float m1 = -1.0f;                               // opaque multiplier: x - hi as ONE v_fma_mix_f32 (attn_stream.hip)
+  asm volatile("" : "+v"(m1));
 #pragma unroll
   for (int i = 0; i < 8; i += 2) {
     const half2_t h2 = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(x[i], x[i + 1]));
-    const float r0 = x[i] - (float)h2[0], r1 = x[i + 1] - (float)h2[1];
+    const float r0 = __builtin_fmaf((float)h2[0], m1, x[i]), r1 = __builtin_fmaf((float)h2[1], m1, x[i + 1]);
     const half2_t l2 = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
     hi[i] = h2[0]; hi[i + 1] = h2[1]; lo[i] = l2[0]; lo[i + 1] = l2[1];
   }
@@ -417,9 +419,15 @@ __global__ __launch_bounds__(448) void attn_win_kernel(const AttnWP p, const int
       const float m_new = upd ? tmax : m_run;
       const float kk = fmaf(-m_new, c2, P_SCALE_LOG2);
       float psum = 0.f;
+      {
+        f32x16 c2v, kkv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { c2v[r] = c2; kkv[r] = kk; }
+        sc = __builtin_elementwise_fma(sc, c2v, kkv);       // 8 v_pk_fma_f32
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        sc[r] = __builtin_amdgcn_exp2f(fmaf(sc[r], c2, kk));
+        sc[r] = __builtin_amdgcn_exp2f(sc[r]);
         if constexpr (!LSUM_MFMA) psum += sc[r];
       }
       if constexpr (kt > 0) {

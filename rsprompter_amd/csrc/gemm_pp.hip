@@ -364,11 +364,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_pp_kernel(const PPP p) {
       // (3) value = act(acc * alpha + bias) + residual
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float t = x[g][e] * alpha + bias4[e];
-          x[g][e] = (EPI & E_GELU) ? rsp_gelu(t) : t;
-        }
+        x[g] = x[g] * alpha + bias4;
+        if constexpr (EPI & E_GELU) x[g] = rsp_gelu4(x[g]);
         if constexpr (EPI & E_RES) x[g] += rv[i & 1][g];
       }
       if constexpr (i + 1 < TM) {
@@ -384,13 +381,8 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_f16x3_pp_kernel(const PPP p) {
         }
         if constexpr (EPI & E_PL) {
           half4_t h4, l4;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float y = x[g][e] * cs;
-            const float yh = __builtin_fminf(__builtin_fmaxf(y, -RSP_F16_MAX), RSP_F16_MAX);
-            h4[e] = (half_t)yh;
-            l4[e] = (half_t)__builtin_fminf(__builtin_fmaxf(y - (float)h4[e], -RSP_F16_MAX), RSP_F16_MAX);
-          }
+          f32x4 rem;
+          rsp_split4(x[g] * cs, h4, l4, rem);
           const unsigned po = cr < 0 ? OOB : (unsigned)(cr * 64 + pl_lane);
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, h4), rH, po, 0, 0);
           __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, l4), rL, po, 0, 0);

@@ -1,3 +1,4 @@
+// hipcc-flags: -ffp-contract=fast
 // SAM two-way-transformer cross attentions (HF:243-288 SamAttention inside HF:306-348, 396-404), the two shapes
 // that matter in the RSPrompter decoders:
 //   token -> image : T <= 12 prompt tokens attend over the N = h*w image positions   (many keys, few queries)
@@ -491,13 +492,15 @@ __global__ __launch_bounds__(F2_THREADS) void sam_i2t_fused_mfma_kernel(const I2
 #pragma unroll
           for (int tt = 0; tt < NKS; ++tt) {
             const float* kr = sK + (2 * tt + hh) * W + h * DH;
-            float a = 0.f;
+            // 16 products as 8 packed fmas on an (even, odd) pair of partial sums (v_pk_fma_f32) + one add
+            f32x2 a2 = {0.f, 0.f};
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const f32x4 kk = *reinterpret_cast<const f32x4*>(kr + 4 * u);
-              a += qv[u][0] * kk[0] + qv[u][1] * kk[1] + qv[u][2] * kk[2] + qv[u][3] * kk[3];
+              a2 = __builtin_elementwise_fma(f32x2{qv[u][0], qv[u][1]}, f32x2{kk[0], kk[1]}, a2);
+              a2 = __builtin_elementwise_fma(f32x2{qv[u][2], qv[u][3]}, f32x2{kk[2], kk[3]}, a2);
             }
-            sc[tt][h] = (2 * tt + hh < T) ? a : -INFINITY;
+            sc[tt][h] = (2 * tt + hh < T) ? a2[0] + a2[1] : -INFINITY;
           }
           __builtin_amdgcn_sched_barrier(0);                // one head's K reads in flight at a time (register pressure)
         }
@@ -520,13 +523,8 @@ __global__ __launch_bounds__(F2_THREADS) void sam_i2t_fused_mfma_kernel(const I2
       }
 #pragma unroll
       for (int tt = 0; tt < NKS; ++tt) {
-        half8_t ph, pl;
-#pragma unroll
-        for (int h = 0; h < 8; ++h) {
-          half_t a, b;
-          rsp_split1(sc[tt][h], a, b);
-          ph[h] = a; pl[h] = b;
-        }
+        half8_t ph, pl;                                   // probabilities * 2^14 in [0, 16384]: the truncating split
+        rsp_split8_trunc(sc[tt], ph, pl);
         *reinterpret_cast<half8_t*>(piece + (tt * 2 + 0) * 1024 + lane * 16) = ph;
         *reinterpret_cast<half8_t*>(piece + (tt * 2 + 1) * 1024 + lane * 16) = pl;
       }

@@ -55,10 +55,12 @@ __device__ __forceinline__ void static_for_f(F&& f) {
 }
 
 __device__ __forceinline__ void split8_fast_f(const float* x, half8_t& hi, half8_t& lo) {
+  float m1 = -1.0f;                               // opaque multiplier: x - hi as ONE v_fma_mix_f32 (attn_stream.hip)
+  asm volatile("" : "+v"(m1));
 #pragma unroll
   for (int i = 0; i < 8; i += 2) {
     const half2_t h2 = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(x[i], x[i + 1]));
-    const float r0 = x[i] - (float)h2[0], r1 = x[i + 1] - (float)h2[1];
+    const float r0 = __builtin_fmaf((float)h2[0], m1, x[i]), r1 = __builtin_fmaf((float)h2[1], m1, x[i + 1]);
     const half2_t l2 = __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(r0, r1));
     hi[i] = h2[0]; hi[i + 1] = h2[1]; lo[i] = l2[0]; lo[i + 1] = l2[1];
   }

@@ -85,8 +85,12 @@ __global__ __launch_bounds__(256) void sam_upscale2_kernel(const Up2P p) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + j * 32 + 8 * g + 4 * hh);
+        f32x4 t4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sum += rsp_gelu(acc[4 * g + e] * p.alpha + b4[e]) * hy[g][e];
+        for (int e = 0; e < 4; ++e) t4[e] = acc[4 * g + e] * p.alpha + b4[e];
+        t4 = rsp_gelu4(t4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sum += t4[e] * hy[g][e];
       }
       sum += __shfl_xor(sum, 32, 64);
       res[j] = sum;
@@ -252,18 +256,26 @@ __global__ __launch_bounds__(256) void sam_upscale_fused_kernel(const UpFP p) {
           const int ch = jj * 32 + 8 * g + 4 * hh;
           const f32x4 g4 = *reinterpret_cast<const f32x4*>(p.gamma + ch);
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.beta + ch);
+          f32x4 t4;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[jj][4 * g + e] = rsp_gelu((v[jj][4 * g + e] - mean) * rstd * g4[e] + b4[e]) * ys;
+          for (int e = 0; e < 4; ++e) t4[e] = (v[jj][4 * g + e] - mean) * rstd * g4[e] + b4[e];
+          t4 = rsp_gelu4(t4) * ys;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[jj][4 * g + e] = t4[e];
         }
       // B fragments of the second product: k-step s = registers [8 (s & 1), +8) of channel block s >> 1
       half8_t yh[4], yl[4];
 #pragma unroll
       for (int s_ = 0; s_ < 4; ++s_) {
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-          half_t a, b;
-          rsp_split1(v[s_ >> 1][8 * (s_ & 1) + t], a, b);
-          yh[s_][t] = a; yl[s_][t] = b;
+        for (int t4i = 0; t4i < 2; ++t4i) {
+          f32x4 in4, rem;
+          half4_t a4, b4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) in4[e] = v[s_ >> 1][8 * (s_ & 1) + 4 * t4i + e];
+          rsp_split4(in4, a4, b4, rem);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { yh[s_][4 * t4i + e] = a4[e]; yl[s_][4 * t4i + e] = b4[e]; }
         }
       }
 #pragma unroll
@@ -285,8 +297,12 @@ __global__ __launch_bounds__(256) void sam_upscale_fused_kernel(const UpFP p) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias2 + jb * 32 + 8 * g + 4 * hh);
+          f32x4 t4;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dot += rsp_gelu(acc2[4 * g + e] * p.alpha2 + b4[e]) * hy[g][e];
+          for (int e = 0; e < 4; ++e) t4[e] = acc2[4 * g + e] * p.alpha2 + b4[e];
+          t4 = rsp_gelu4(t4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dot += t4[e] * hy[g][e];
         }
         dot += __shfl_xor(dot, 32, 64);
         res[pos][jb] = dot;
