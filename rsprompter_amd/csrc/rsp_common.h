@@ -105,7 +105,7 @@ __device__ __forceinline__ void rsp_store_planes4(half_t* hi, half_t* lo, int64_
 // exact-erf GELU (nn.GELU default, HF "gelu"):  gelu(x) = x Phi(x) = max(x, 0) - 0.5 |x| erfc(|x| / sqrt 2), and
 //   erfc(u / sqrt 2) = 2^-P(u),  P(u) = u Q(u), Q a degree-7 polynomial fitted (weighted minimax on [0, 13.5], weight =
 //   the GELU's sensitivity 0.5 u erfc ln 2) to -log2 erfc: monotone on the interval, P(13.5) = 163 so that the tail
-//   underflows to exactly 0.  Branch-free: 1 transcendental + 12 VALU operations per element (round 5; rounds 1-4 used
+//   underflows to exactly 0 (so the clamped u can stand in for |x| in the last product).  Branch-free: 1 transcendental + 11 VALU operations per element (round 5; rounds 1-4 used
 //   Abramowitz-Stegun 7.1.26: 2 transcendentals + 15 operations), and every operation but min / max / exp2 exists as a
 //   packed fp32 instruction (v_pk_fma_f32, v_pk_mul_f32), which the four-wide form below compiles to.  Measured in fp32
 //   against the fp64 definition on 5 M points of [-16, 16] (tests/test_f32_gelu_cpu.py restates it in numpy): max
@@ -122,8 +122,7 @@ __device__ __forceinline__ void rsp_store_planes4(half_t* hi, half_t* lo, int64_
 #define RSP_GELU_C7 -1.0968042093e-05f
 #define RSP_GELU_C8 5.2522374980e-07f
 __device__ __forceinline__ float rsp_gelu(float x) {
-  const float ax = __builtin_fabsf(x);
-  const float u = __builtin_fminf(ax, RSP_GELU_U_MAX);
+  const float u = __builtin_fminf(__builtin_fabsf(x), RSP_GELU_U_MAX);
   float q = __builtin_fmaf(RSP_GELU_C8, u, RSP_GELU_C7);
   q = __builtin_fmaf(q, u, RSP_GELU_C6);
   q = __builtin_fmaf(q, u, RSP_GELU_C5);
@@ -132,14 +131,13 @@ __device__ __forceinline__ float rsp_gelu(float x) {
   q = __builtin_fmaf(q, u, RSP_GELU_C2);
   q = __builtin_fmaf(q, u, RSP_GELU_C1);
   const float e = __builtin_amdgcn_exp2f(-(q * u));       // erfc(|x| / sqrt 2)
-  return __builtin_fmaf(-0.5f * ax, e, __builtin_fmaxf(x, 0.0f));
+  return __builtin_fmaf(-0.5f * u, e, __builtin_fmaxf(x, 0.0f));     // (u instead of |x|: where they differ e is exactly 0)
 }
 // the same arithmetic on four values (identical results element by element: fma / mul are the same operations packed)
 __device__ __forceinline__ f32x4 rsp_gelu4(const f32x4 x) {
-  const f32x4 ax = __builtin_elementwise_abs(x);
   f32x4 u;
 #pragma unroll
-  for (int e = 0; e < 4; ++e) u[e] = __builtin_fminf(ax[e], RSP_GELU_U_MAX);
+  for (int e = 0; e < 4; ++e) u[e] = __builtin_fminf(__builtin_fabsf(x[e]), RSP_GELU_U_MAX);   // |x|: a source modifier
   const auto k = [](float c) { return f32x4{c, c, c, c}; };
   f32x4 q = __builtin_elementwise_fma(k(RSP_GELU_C8), u, k(RSP_GELU_C7));
   q = __builtin_elementwise_fma(q, u, k(RSP_GELU_C6));
@@ -149,7 +147,7 @@ __device__ __forceinline__ f32x4 rsp_gelu4(const f32x4 x) {
   q = __builtin_elementwise_fma(q, u, k(RSP_GELU_C2));
   q = __builtin_elementwise_fma(q, u, k(RSP_GELU_C1));
   const f32x4 pu = q * u;
-  const f32x4 hx = ax * -0.5f;
+  const f32x4 hx = u * -0.5f;
   f32x4 ex, rl;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {

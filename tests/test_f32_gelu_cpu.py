@@ -38,7 +38,7 @@ def gelu_f32(x):
     with np.errstate(under='ignore'):
         e = np.exp2(-pu.astype(np.float64)).astype(f32)
     e = np.where(np.abs(e) < np.finfo(f32).tiny, f32(0), e)        # the device flushes denormal results
-    return _fma((f32(-0.5) * ax).astype(f32), e, np.maximum(x, f32(0)))
+    return _fma((f32(-0.5) * u).astype(f32), e, np.maximum(x, f32(0)))
 
 
 def test_gelu_error_bound_against_fp64():
