@@ -221,6 +221,8 @@ int rsp_vit_attention_planes_ex(const float* q, int64_t q_ld, const uint16_t* kv
 /* rel_tab = the layer's two tables packed once by rsp_pack_relpos_tables; q / K | V planes / outputs / window grid as    */
 /* above with S = 14.  The kernel is persistent (a block walks the windows of one head); variant: 0 = product (768        */
 /* blocks), n > 0 = 16 n blocks (tests and measurements).                                                                 */
+/* The K | V plane exponent (kv_scale_log2) must lie in [-8, 4] for S = 14 (both entry points): the padded-key mask and   */
+/* the rel-pos bias share the score scale 2^(6 + exponent); outside that range the call returns RSP_EINVAL.                */
 int rsp_vit_window_attention(const float* q, int64_t q_ld, const uint16_t* kv_hi, const uint16_t* kv_lo,
                              int64_t kv_rows, int32_t kv_scale_log2, const uint16_t* rel_tab, float* out,
                              uint16_t* out_hi, uint16_t* out_lo, int32_t out_scale_log2, int32_t Bp, int32_t nh,

@@ -403,6 +403,8 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   }
 }
 
+// (round 5: a three-deep ring, <DH, NW, 64, 3> = 141 KB of LDS at dh = 80, measured 8.89-8.93 against 8.97 ms for the four
+//  ViT-H layers on one box: DMA distance is not what the waves wait for; the two-deep ring stays)
 template <int DH>
 int launch_stream(const AttnSP& p, int Bp, hipStream_t s) {
   constexpr int NW = 8;

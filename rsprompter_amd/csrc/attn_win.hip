@@ -594,6 +594,10 @@ int rsp_attn_win_dispatch(const float* q, int64_t q_ld, const uint16_t* kv_hi, c
   const int D = nh * dh;
   if ((D & 31) || (q_ld & 3) || kv_rows < (int64_t)Bp * WT) return RSP_EINVAL;
   if (RSP_PLANE_IS_F8(kv_scale_log2)) return RSP_EINVAL;   // K | V are consumed as fp16 hi / lo planes
+  // the padded-key mask (NEG_RAW) and the rel-pos bias enter the scores as fp16 values scaled by 2^(EQ + kv_e): with a key
+  // plane exponent above 4 the mask would no longer underflow the softmax (-60000 * 2^-(EQ + kv_e) * log2 e > -85) and a
+  // bias beyond |t| ~ 64 would saturate fp16; below -8 the biases lose their low bits.  The encoder uses 2.
+  if (RSP_PLANE_EXP(kv_scale_log2) > 4 || RSP_PLANE_EXP(kv_scale_log2) < -8) return RSP_EINVAL;
   if (rel_tab && (reinterpret_cast<uintptr_t>(rel_tab) & 15)) return RSP_EINVAL;
   if (variant < 0 || variant > 64) return RSP_EINVAL;
   AttnWP p;

@@ -15,11 +15,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define RSP_WAVE 64
 
 // Marks a point where lanes of ONE wave exchange data through LDS without a block barrier: the DS operations of a wave
-// execute in order and its 64 lanes in lockstep, so the reads behind this point see the writes in front of it.  Expands
-// to nothing on the device (no instruction, no scheduling effect); the lane-level emulator the CPU tests compile these
-// sources against (tests/wave_emu/emu_hip.h) runs lanes one at a time and turns it into a wave rendezvous.
+// execute in order and its 64 lanes in lockstep, so the reads behind this point see the writes in front of it.  On the
+// device it is __builtin_amdgcn_wave_barrier(): no instruction, but the compiler may not move an LDS read of one lane's
+// address above the LDS write another lane makes to it (legal for single-thread semantics otherwise; round 5 -- the
+// instruction counts of the five files that use it are unchanged, the schedules of two epilogues shift slightly).  The
+// lane-level emulator the CPU tests compile these sources against (tests/wave_emu/emu_hip.h) runs lanes one at a time
+// and turns it into a wave rendezvous.
 #ifndef RSP_WAVE_LOCKSTEP
-#define RSP_WAVE_LOCKSTEP() ((void)0)
+#define RSP_WAVE_LOCKSTEP() __builtin_amdgcn_wave_barrier()
 #endif
 
 #define RSP_CHECK_LAUNCH()                         \

@@ -136,6 +136,12 @@ class ExchangeState:
 _STATES = {}
 
 
+def release_state(group=None):
+    """Forget the ExchangeState (capacities, pinned buffers) of a process group -- call it before destroying the group;
+    `_STATES` otherwise keeps the group object and its buffers alive for the life of the process."""
+    _STATES.pop(id(group) if group is not None else 0, None)
+
+
 def _state_of(group):
     """one ExchangeState per process group.  The entry keeps a reference to the group object, so its id() cannot be handed
     to another group while the state exists."""
@@ -166,15 +172,34 @@ class DeviceCodec:
 
 
 class PendingGather:
-    """Handle of an exchange in flight (device work queued on `stream`); `collect()` finishes it on the host."""
+    """Handle of an exchange in flight (device work queued on `stream`); `collect()` finishes it on the host.
 
-    def __init__(self, fn):
-        self._fn, self._out = fn, None
+    A handle that is dropped without `collect()` -- an exception in the step loop between the two calls -- must not leave
+    its process group blocked: `cancel()` (also run by `__del__`) waits for the side stream's queued work, so that the
+    pinned buffers are no longer written to, and releases the group's state for the next exchange.  Nothing is
+    unpacked; if this step's headers did not fit the agreed capacities the re-send that `collect()` would have queued
+    on every rank is skipped on this one -- cancel on all ranks or on none."""
+
+    def __init__(self, fn, abandon=None):
+        self._fn, self._out, self._abandon = fn, None, abandon
 
     def collect(self):
         if self._fn is not None:
-            self._out, self._fn = self._fn(), None
+            self._out, self._fn, self._abandon = self._fn(), None, None
         return self._out
+
+    def cancel(self):
+        if self._fn is not None and self._abandon is not None:
+            try:
+                self._abandon()
+            finally:
+                self._fn = self._abandon = None
+
+    def __del__(self):
+        try:
+            self.cancel()
+        except Exception:                  # interpreter shutdown: the CUDA context may already be gone
+            pass
 
 
 class GatheredResults:
@@ -386,7 +411,16 @@ def gather_results(results_list, dataset_size=None, group=None, stream=None, dst
             state.live = weakref.ref(out)
         return out
 
-    return PendingGather(finish) if use_stream else finish()
+    def abandon():
+        nonlocal inflight
+        try:
+            ev = inflight[2]
+            if ev is not None:
+                ev.synchronize()
+        finally:
+            state.in_flight = False
+
+    return PendingGather(finish, abandon) if use_stream else finish()
 
 
 class _null:

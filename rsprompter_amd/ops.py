@@ -1050,6 +1050,10 @@ class RpnSelector:
 
 NMS_LDS_CANDIDATES = 16384     # rsp_batched_nms sorts up to here in LDS (det.hip NMS_LDS_KEYS), in memory above
 NMS_MAX_CANDIDATES = 131072    # ... and holds this many candidates per image at most
+# the pair mask of the in-memory path is quadratic: B * cap * cap / 8 bytes (200 MB per image at 40 k candidates, 2 GiB at
+# the kernel's limit).  A call that would need more than this many bytes of workspace is refused with the figures in the
+# message instead of failing inside the allocator (settable: a box with spare HBM may raise it).
+NMS_WORKSPACE_LIMIT_BYTES = 8 << 30
 
 
 def _cand_buffers(B, cap, dev):
@@ -1065,7 +1069,12 @@ def batched_nms(cand, B, cap, iou_thr, max_out):
     lib = _lib.load()
     boxes, scores, ids, src, cnt = cand
     dev = boxes.device
-    ws = torch.empty((int(lib.rsp_nms_workspace_bytes(B, cap)),), dtype=torch.uint8, device=dev)
+    ws_bytes = int(lib.rsp_nms_workspace_bytes(B, cap))
+    if ws_bytes > NMS_WORKSPACE_LIMIT_BYTES:
+        raise ValueError(f'batched_nms: {B} images x {cap} candidates need a {ws_bytes / 2 ** 30:.1f} GiB pair mask '
+                         f'(limit ops.NMS_WORKSPACE_LIMIT_BYTES = {NMS_WORKSPACE_LIMIT_BYTES / 2 ** 30:.0f} GiB): raise score_thr, '
+                         'lower the number of proposals, or run fewer images per call')
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     keep = torch.empty((B, max_out), dtype=torch.int32, device=dev)
     keep_cnt = torch.empty((B,), dtype=torch.int32, device=dev)
     ob = torch.empty((B, max_out, 4), dtype=torch.float32, device=dev)

@@ -139,6 +139,29 @@ def test_gather_results_device_codec_side_stream(dev):
                 assert np.array_equal(dec, r.masks[j].cpu().numpy())
 
 
+def test_gather_results_dropped_handle_releases_the_group(dev):
+    """an exchange whose handle is dropped without collect() (an exception between the two calls) must not block the next
+    one: the handle's cancel() / __del__ waits for the side stream and clears the in-flight mark."""
+    from rsprompter_amd import dist as rdist
+    res = _blob_results(0, 2, dev)
+    side = torch.cuda.Stream(device=dev)
+    state = rdist.ExchangeState()
+    h = rdist.gather_results(res, stream=side, state=state)
+    assert state.in_flight
+    with pytest.raises(RuntimeError):                      # still guarded while the handle lives
+        rdist.gather_results(res, stream=side, state=state)
+    del h                                                  # dropped: __del__ -> cancel()
+    assert not state.in_flight
+    h2 = rdist.gather_results(res, stream=side, state=state)
+    h2.cancel()
+    assert not state.in_flight and h2.collect() is None
+    got = rdist.gather_results(res, stream=side, state=state).collect()
+    assert len(got) == 2 and torch.equal(got[0]['bboxes'], res[0].bboxes.cpu())
+    rdist._state_of(None)
+    rdist.release_state(None)
+    assert 0 not in rdist._STATES
+
+
 def _worker_rle(rank, world, port, ret, dst=0):
     os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1',
                       MASTER_PORT=str(port))

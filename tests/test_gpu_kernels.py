@@ -268,6 +268,23 @@ def test_vit_window_attention_fused_relpos(dev, nw, real, nh, dh, B, variant):
     assert float((other[is_real] - got[is_real]).abs().max()) < 1e-5
 
 
+def test_vit_window_attention_refuses_key_planes_with_a_large_exponent(dev):
+    """the padded-key mask and the rel-pos bias share the score scale 2^(6 + kv exponent): beyond 4 the mask would stop
+    underflowing the softmax, so both window entry points return RSP_EINVAL instead of a silently wrong answer."""
+    from rsprompter_amd import ops
+    S, nh, dh, Bp = 14, 2, 64, 1
+    D = nh * dh
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn(Bp * S * S, D, generator=g).to(dev)
+    kvf = torch.randn(Bp * S * S, 2 * D, generator=g).to(dev)
+    tab = ops.pack_relpos_tables((torch.randn(27, dh, generator=g) * 0.2).to(dev), (torch.randn(27, dh, generator=g) * 0.2).to(dev), S, dh)
+    ok = ops.vit_window_attention(q, ops.to_planes(kvf, 4), tab, Bp, nh, dh, dh ** -0.5)
+    ref = ops.vit_window_attention(q, ops.to_planes(kvf), tab, Bp, nh, dh, dh ** -0.5)
+    assert float((ok - ref).abs().max()) < 2e-5
+    with pytest.raises(RuntimeError, match='rsp_vit_window_attention'):
+        ops.vit_window_attention(q, ops.to_planes(kvf, 8), tab, Bp, nh, dh, dh ** -0.5)
+
+
 def test_gemm_column_range_outputs(dev):
     """rsp_gemm c_ncols / pl_col0 (the qkv projection's split hand-off): fp32 for the first D columns only, planes for
     the rest, with a row-gather map and padded rows like the windowed layers."""
@@ -461,6 +478,20 @@ def test_batched_nms_matches_oracle(dev, n, nid, thr, max_out):
         assert k == keep.numel()
         assert torch.equal(out['keep'][b, :k].cpu().long(), keep)
         assert torch.equal(out['boxes'][b, :k].cpu(), boxes[b, :m][keep])
+
+
+def test_batched_nms_refuses_a_workspace_beyond_the_limit(dev, monkeypatch):
+    """the in-memory NMS path needs B * cap^2 / 8 bytes of pair mask: a call beyond ops.NMS_WORKSPACE_LIMIT_BYTES fails with
+    the figures in the message, before anything is allocated or launched."""
+    from rsprompter_amd import ops
+    cap = 40000
+    cand = (torch.zeros(1, cap, 4, device=dev), torch.zeros(1, cap, device=dev), torch.zeros(1, cap, dtype=torch.int32, device=dev),
+            torch.zeros(1, cap, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev))
+    monkeypatch.setattr(ops, 'NMS_WORKSPACE_LIMIT_BYTES', 64 << 20)
+    with pytest.raises(ValueError, match='GiB pair mask'):
+        ops.batched_nms(cand, 1, cap, 0.5, 100)
+    monkeypatch.setattr(ops, 'NMS_WORKSPACE_LIMIT_BYTES', 8 << 30)
+    assert int(ops.batched_nms(cand, 1, cap, 0.5, 100)['count'][0]) == 0
 
 
 def test_rpn_topk_ties_and_small_levels(dev):
