@@ -3,7 +3,7 @@
 
   python tools/ab_bench.py [--arch huge] [--batch 8] [--steps 4] [--rounds 2] "name:attr=value,attr=value" ...
 
-Every arm sets attributes on the model's SAM decoder(s) / vision encoder (`t2i_fold`, `upscale_fused`) or module globals (`ops.X=...`), then times `steps` whole test_steps; the arms are interleaved `rounds` times so
+Every arm sets attributes on every module of the model that has them (`t2i_fold`, `upscale_fused`, `branch_width`) or module globals (`ops.X=...`), then times `steps` whole test_steps; the arms are interleaved `rounds` times so
 that clock drift hits all of them.  Prints one line per arm: median ms per step, and the per-kernel HIP-event table of the
 kernels whose time differs between the arms.  Synthetic weights / tiles exactly as bench.py builds them.
 """
@@ -49,7 +49,7 @@ def main():
     model = bench.build_model(args.arch, 10 if args.model == 'anchor' else 1, dev, args.model, False)
     imgs = [im.to(dev) for im in synth_images(args.batch, seed=1234)]
     metas = bench.bench_metas(args.batch, args.model, False)
-    targets = [m for m in model.modules() if isinstance(m, (SamMaskDecoderHIP, SamVisionEncoderHIP))]
+    targets = list(model.modules())          # an attribute is set on every module that has it
 
     def apply(kv):
         for k, v in kv.items():
