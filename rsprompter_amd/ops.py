@@ -137,7 +137,11 @@ class fork_branches:
             key = (self.dev.index if self.dev.index is not None else torch.cuda.current_device())
             pool = _BRANCH_STREAMS.setdefault(key, [])
             while len(pool) < self.width:
-                pool.append(torch.cuda.Stream(device=self.dev))
+                # from the HIGH-priority pool: torch hands out its 32 pooled streams per priority round-robin, so a
+                # default-priority stream somebody else creates later (bench.py's exchange stream, a test's) can be the
+                # SAME stream as a cached default-priority one -- the branches of the next step would then queue behind
+                # that user's work and the main stream with them (seen: the step loop with the exchange 33 % slower)
+                pool.append(torch.cuda.Stream(device=self.dev, priority=-1))
             self.streams = pool[:self.width]
             self.main = torch.cuda.current_stream(self.dev)
             ev = torch.cuda.Event()

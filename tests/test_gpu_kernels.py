@@ -908,3 +908,8 @@ def test_feature_aggregator_branches_on_side_streams_are_bit_identical(dev):
             got = agg(hs)
             assert torch.equal(got, ref)
     torch.cuda.synchronize()
+    # the branch streams must not be streams anybody else can be handed: torch's default-priority pool is round-robin
+    from rsprompter_amd import ops
+    mine = {st.cuda_stream for pool in ops._BRANCH_STREAMS.values() for st in pool}
+    others = {torch.cuda.Stream(device=dev).cuda_stream for _ in range(80)}
+    assert mine and not (mine & others)
