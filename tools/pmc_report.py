@@ -28,7 +28,7 @@ def load(root):
     for f in sorted(glob.glob(os.path.join(root, '*', '*counter_collection.csv'))):
         for r in csv.DictReader(open(f)):
             n = short(r['Kernel_Name'])
-            if not any(t in n for t in ('gemm', 'attn', 'layernorm', 'relpos', 'split')):
+            if not any(t in n for t in ('gemm', 'attn', 'layernorm', 'relpos', 'split', 'sam_', 'upscale', 'rpn_', 'nms_')):
                 continue
             key = (n, int(r['Grid_Size']))
             agg[key][r['Counter_Name']].append(float(r['Counter_Value']))
