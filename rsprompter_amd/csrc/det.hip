@@ -489,7 +489,22 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const NmsP p) {
   const int32_t* sorder = p.sorder + (int64_t)b * p.cap;
   int32_t* keep = p.keep + (int64_t)b * p.max_out;
   int kept = 0;
+  // A block's inputs -- its diagonal mask word and its sort-order entry per row -- are requested one block AHEAD, and the
+  // rows a block keeps are propagated four at a time with their loads in flight together: the walk is serial by nature
+  // (one wave per image), and round 5's counters showed it 81 % of its cycles waiting for one load after the other.
+  auto load_blk = [&](int bk, unsigned long long& dm, int& so) {
+    const int r = bk * 64 + lane;
+    const bool ok = bk < nblk && r < n;
+    dm = ok ? mask[(int64_t)r * p.words + bk] : 0ull;
+    so = ok ? sorder[r] : 0;
+  };
+  unsigned long long dmask;
+  int sord;
+  load_blk(0, dmask, sord);
   for (int blk = 0; blk < nblk && kept < p.max_out; ++blk) {
+    unsigned long long dnext;
+    int snext;
+    load_blk(blk + 1, dnext, snext);
     // removal word of this block lives in lane (blk & 63), slot (blk >> 6)
     unsigned long long mine = 0ull;
 #pragma unroll
@@ -497,17 +512,16 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const NmsP p) {
     const unsigned int lo = __shfl((unsigned int)(mine & 0xffffffffull), blk & 63, 64);
     const unsigned int hi = __shfl((unsigned int)(mine >> 32), blk & 63, 64);
     unsigned long long cur = ((unsigned long long)hi << 32) | lo;
-    const int row = blk * 64 + lane;
-    const unsigned long long dmask = row < n ? mask[(int64_t)row * p.words + blk] : 0ull;
     const int rows_here = min(64, n - blk * 64);
     unsigned long long kept_bits = 0ull;
     for (int t = 0; t < rows_here; ++t) {
       const unsigned int dlo = __shfl((unsigned int)(dmask & 0xffffffffull), t, 64);
       const unsigned int dhi = __shfl((unsigned int)(dmask >> 32), t, 64);
+      const int so = __shfl(sord, t, 64);
       if (!((cur >> t) & 1ull)) {
         if (kept < p.max_out) {
           kept_bits |= (1ull << t);
-          if (lane == 0) keep[kept] = sorder[blk * 64 + t];
+          if (lane == 0) keep[kept] = so;
           ++kept;
           cur |= ((unsigned long long)dhi << 32) | dlo;
         }
@@ -515,15 +529,32 @@ __global__ __launch_bounds__(64) void nms_reduce_kernel(const NmsP p) {
     }
     if (kept >= p.max_out) break;
     // propagate the kept rows of this block to all later words
-    for (int t = 0; t < rows_here; ++t) {
-      if (!((kept_bits >> t) & 1ull)) continue;
-      const unsigned long long* mrow = mask + (int64_t)(blk * 64 + t) * p.words;
+    constexpr int CH = NMS_MAXW <= 4 ? 4 : 1;              // rows per batch of loads (register budget of the large form)
+    unsigned long long kb = kept_bits;
+    while (kb) {
+      int tt[CH];
 #pragma unroll
-      for (int i = 0; i < NMS_MAXW; ++i) {
-        const int w = lane + 64 * i;
-        if (w > blk && w < nblk) remv[i] |= mrow[w];
+      for (int j = 0; j < CH; ++j) {
+        tt[j] = -1;
+        if (kb) { tt[j] = __builtin_ctzll(kb); kb &= kb - 1ull; }
       }
+      unsigned long long v[CH][NMS_MAXW];
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const unsigned long long* mrow = mask + (int64_t)(blk * 64 + max(tt[j], 0)) * p.words;
+#pragma unroll
+        for (int i = 0; i < NMS_MAXW; ++i) {
+          const int w = lane + 64 * i;
+          v[j][i] = (tt[j] >= 0 && w > blk && w < nblk) ? mrow[w] : 0ull;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CH; ++j)
+#pragma unroll
+        for (int i = 0; i < NMS_MAXW; ++i) remv[i] |= v[j][i];
     }
+    dmask = dnext;
+    sord = snext;
   }
   if (lane == 0) p.keep_cnt[b] = kept;
 }
