@@ -73,7 +73,6 @@ class RSFeatureAggregator(HIPModule):
         self.in_channels = self.in_channels_dict[infer_sam_arch(in_channels)]
         self.select_layers = list(select_layers)
         self.hidden_channels, self.out_channels = hidden_channels, out_channels
-        self.branch_width = 8            # side streams for the per-layer branches (0: inline; forward())
         h = hidden_channels
         for i, l in enumerate(self.select_layers):
             _add_conv(self, f'downconvs.{i}.0', h, self.in_channels[l], 1)
@@ -117,28 +116,16 @@ class RSFeatureAggregator(HIPModule):
         B, H, W, _ = inputs[0].shape
         hc = self.hidden_channels
         x = None
-        # The per-layer part -- relu(bn(conv3x3(relu(bn(conv1x1(hidden state)))))) -- does not depend on the running sum:
-        # the branches run `branch_width` at a time on side streams (each is two small-grid kernels that leave most of
-        # the chip idle), the chain below joins them one by one.  x + g is the same fp32 addition the GEMM epilogue made
-        # with res=x: results are bit-identical to the inline order (branch_width = 0).
-        n_sel = len(self.select_layers)
-        g = [None] * n_sel
-        with ops.fork_branches(inputs[0].device, self.branch_width) as fk:
-            for i, l in enumerate(self.select_layers):
-                with fk.branch(i):
-                    hs = inputs[l]
-                    if not hs.is_contiguous():
-                        hs = hs.contiguous()
-                    d0, d3 = P['down'][i]
-                    f = ops.gemm(hs.view(B * H * W, -1), d0, act=ops.ACT_RELU)
-                    g[i] = fk.keep(ops.gemm(f.view(B, H, W, hc), d3, act=ops.ACT_RELU, conv=(3, 1, 1)))
-            for i in range(n_sel):
-                fk.join(i)
-                # hidden_state = x + relu(bn(conv3x3(f)))  (models.py:1050-1053)
-                hsx = g[i] if x is None else ops.add_rows(x, g[i])
-                g[i] = None
-                # x = hidden_state + relu(bn(conv3x3(hidden_state)))  (models.py:1054-1055)
-                x = ops.gemm(hsx.view(B, H, W, hc), P['hid'][i], act=ops.ACT_RELU, conv=(3, 1, 1), res=hsx)
+        for i, l in enumerate(self.select_layers):
+            hs = inputs[l]
+            if not hs.is_contiguous():
+                hs = hs.contiguous()
+            d0, d3 = P['down'][i]
+            f = ops.gemm(hs.view(B * H * W, -1), d0, act=ops.ACT_RELU)
+            # hidden_state = x + relu(bn(conv3x3(f)))  (models.py:1050-1053)
+            hsx = ops.gemm(f.view(B, H, W, hc), d3, act=ops.ACT_RELU, conv=(3, 1, 1), res=x)
+            # x = hidden_state + relu(bn(conv3x3(hidden_state)))  (models.py:1054-1055)
+            x = ops.gemm(hsx.view(B, H, W, hc), P['hid'][i], act=ops.ACT_RELU, conv=(3, 1, 1), res=hsx)
         y = ops.gemm(x, P['f0'], act=ops.ACT_RELU)
         y = ops.gemm(y.view(B, H, W, self.out_channels), P['f3'], act=ops.ACT_RELU, conv=(3, 1, 1))
         y = ops.gemm(y.view(B, H, W, self.out_channels), P['f6'], conv=(3, 1, 1))

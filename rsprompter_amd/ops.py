@@ -108,84 +108,6 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-_BRANCH_STREAMS = {}
-
-
-class fork_branches:
-    """Independent, LOW-OCCUPANCY kernel chains on side streams (the feature aggregator's 16 per-layer branches: a
-    [32768, 1280] x [1280, 32] product is 256 blocks, one wave per SIMD, and runs at 2.6 TB/s alone).
-
-        with ops.fork_branches(dev, width=4) as fk:
-            for i in ...:
-                with fk.branch(i):            # kernels launched in here go to side stream i % width
-                    g[i] = fk.keep(<tensor made in the branch and read later on the main stream>)
-                ...
-                fk.join(i)                    # the main stream waits for branch i (and only for it)
-
-    Ordering: every side stream first waits for what the main stream had queued at entry; `join(i)` makes the main
-    stream wait for the event recorded at the end of branch i.  Memory: a tensor allocated inside a branch belongs to
-    that side stream's pool -- `keep()` marks it as used by the main stream (Tensor.record_stream), temporaries of a
-    branch are reused in stream order.  `width=0` (or a CPU device) runs everything inline on the current stream."""
-
-    def __init__(self, dev, width=8):
-        self.dev = torch.device(dev)
-        self.width = width if self.dev.type == 'cuda' else 0
-        self.events = {}
-
-    def __enter__(self):
-        if self.width:
-            key = (self.dev.index if self.dev.index is not None else torch.cuda.current_device())
-            pool = _BRANCH_STREAMS.setdefault(key, [])
-            while len(pool) < self.width:
-                # from the HIGH-priority pool: torch hands out its 32 pooled streams per priority round-robin, so a
-                # default-priority stream somebody else creates later (bench.py's exchange stream, a test's) can be the
-                # SAME stream as a cached default-priority one -- the branches of the next step would then queue behind
-                # that user's work and the main stream with them (seen: the step loop with the exchange 33 % slower)
-                pool.append(torch.cuda.Stream(device=self.dev, priority=-1))
-            self.streams = pool[:self.width]
-            self.main = torch.cuda.current_stream(self.dev)
-            ev = torch.cuda.Event()
-            ev.record(self.main)
-            for st in self.streams:
-                st.wait_event(ev)
-        return self
-
-    def branch(self, i):
-        fk = self
-
-        class _B:
-            def __enter__(b):
-                if fk.width:
-                    b.ctx = torch.cuda.stream(fk.streams[i % fk.width])
-                    b.ctx.__enter__()
-                return b
-
-            def __exit__(b, *a):
-                if fk.width:
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(fk.dev))
-                    fk.events[i] = ev
-                    b.ctx.__exit__(*a)
-                return False
-        return _B()
-
-    def keep(self, t):
-        if self.width:
-            t.record_stream(self.main)
-        return t
-
-    def join(self, i):
-        if self.width:
-            self.main.wait_event(self.events.pop(i))
-
-    def __exit__(self, *a):
-        if self.width:
-            for ev in self.events.values():       # branches nobody joined: the main stream still waits for them
-                self.main.wait_event(ev)
-            self.events = {}
-        return False
-
-
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 

@@ -887,29 +887,3 @@ def test_sam_t2i_fold_matches_fp64_attention(dev, R, N, T):
     e_unf = float((ao.cpu().double() - ref).abs().max())
     print(f't2i fold R={R} N={N} T={T}: folded err {e_fold:.2e}, unfolded err {e_unf:.2e} (max |ref| {float(ref.abs().max()):.2f})')
     assert e_fold < 2e-5 and e_unf < 2e-5
-
-
-def test_feature_aggregator_branches_on_side_streams_are_bit_identical(dev):
-    """RSFeatureAggregator (models.py:1005-1060): the per-layer branches forked onto side streams (ops.fork_branches,
-    branch_width = 8 is the product setting) against the inline order (0) -- same kernels, same fp32 additions, so the
-    outputs must be equal bit for bit; repeated, so that a missing stream dependency would show."""
-    from rsprompter_amd.necks import RSFeatureAggregator
-    from rsprompter_amd.synth import synth_state_dict
-    agg = RSFeatureAggregator('base', hidden_channels=32, out_channels=256, select_layers=range(1, 13, 2))
-    agg.load_state_dict(synth_state_dict(agg, 5))
-    agg = agg.to(dev)
-    g = torch.Generator().manual_seed(17)
-    hs = tuple(torch.randn(2, 32, 32, 768, generator=g).to(dev) for _ in range(13))
-    agg.branch_width = 0
-    ref = agg(hs).clone()
-    for width in (8, 2, 4):
-        agg.branch_width = width
-        for _ in range(3):
-            got = agg(hs)
-            assert torch.equal(got, ref)
-    torch.cuda.synchronize()
-    # the branch streams must not be streams anybody else can be handed: torch's default-priority pool is round-robin
-    from rsprompter_amd import ops
-    mine = {st.cuda_stream for pool in ops._BRANCH_STREAMS.values() for st in pool}
-    others = {torch.cuda.Stream(device=dev).cuda_stream for _ in range(80)}
-    assert mine and not (mine & others)

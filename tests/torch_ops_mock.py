@@ -531,24 +531,3 @@ def sam_upscale_fused(x, w1, bias1, gamma, beta, eps, w2p, bias2, hyper, h, w):
     m = torch.einsum('nabcdk,nk->nabcd', z, hyper.repeat_interleave(h * w, 0))
     return m.view(R, h, w, 2, 2, 2, 2).permute(0, 1, 3, 5, 2, 4, 6).reshape(R, 4 * h, 4 * w)
 
-
-class fork_branches:
-    """ops.fork_branches on the CPU: the branches run inline, in program order."""
-
-    def __init__(self, dev, width=4):
-        pass
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *a):
-        return False
-
-    def branch(self, i):
-        return self
-
-    def keep(self, t):
-        return t
-
-    def join(self, i):
-        pass

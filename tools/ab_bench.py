@@ -3,7 +3,7 @@
 
   python tools/ab_bench.py [--arch huge] [--batch 8] [--steps 4] [--rounds 2] "name:attr=value,attr=value" ...
 
-Every arm sets attributes on every module of the model that has them (`t2i_fold`, `upscale_fused`, `branch_width`) or module globals (`ops.X=...`), then times `steps` whole test_steps; the arms are interleaved `rounds` times so
+Every arm sets attributes on every module of the model that has them (`t2i_fold`, `upscale_fused`) or module globals (`ops.X=...`), then times `steps` whole test_steps; the arms are interleaved `rounds` times so
 that clock drift hits all of them.  Prints one line per arm: median ms per step, and the per-kernel HIP-event table of the
 kernels whose time differs between the arms.  Synthetic weights / tiles exactly as bench.py builds them.
 """
