@@ -76,3 +76,16 @@ def test_shipped_library_has_no_ablation_kernels():
     lib = _lib.load()
     d = _lib.RspGemmDesc()
     assert lib.rsp_gemm_s2_epilogue(None) == -1 and lib.rsp_gemm_s2_epilogue(ctypes.byref(d)) == -1
+
+
+def test_product_code_creates_no_streams():
+    """Round 5's lesson: a HIGH-priority stream anywhere in the process made every kernel launch ~75 us
+    slower on this stack, and torch's pooled default-priority streams can be the very stream a caller obtains later.  The
+    package therefore launches on the caller's current stream only; `bench.py` owns the one side stream of the exchange."""
+    import glob
+    import os
+    import re
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'rsprompter_amd')
+    for f in glob.glob(os.path.join(root, '*.py')):
+        src = open(f).read()
+        assert not re.search(r'cuda\.Stream\(|ExternalStream\(|priority\s*=', src), f
