@@ -116,6 +116,8 @@ SWEEP = [
     ('test_gpu_kernels', 'test_sam_i2t_fused_matches_composition', (3, 64, False, 'valu')),
     ('test_gpu_kernels', 'test_sam_i2t_fused_matches_composition', (3, 64, False, 'mfma')),
     ('test_gpu_kernels', 'test_sam_i2t_fused_matches_composition', (7, 520, True, 'mfma')),
+    ('test_gpu_kernels', 'test_sam_i2t_fused_matches_composition', (10, 600, False, 'mfma')),   # T = 10: the bench's form (5 k-steps)
+    ('test_gpu_kernels', 'test_sam_i2t_fused_matches_composition', (10, 1024, True, 'mfma')),
     ('test_gpu_kernels', 'test_gemm_fp8_corrected_product', (14,)),             # v_mfma_scale_f32_32x32x64_f8f6f4 (e4m3 x e4m3)
     ('test_gpu_kernels', 'test_roi_align_matches_oracle', ()),
     ('test_gpu_kernels', 'test_mask_post_matches_reference_formula', ()),
