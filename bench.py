@@ -248,7 +248,8 @@ def parity_canary(model, imgs, metas, arch, kind, lora=False):
         k0 = int(pi.labels.shape[0])
         pb, ps, pl = pi.bboxes.float().cpu(), pi.scores.float().cpu(), pi.labels.cpu()
         sample = low[:k0, 0, ::16, ::16].float().cpu()
-        used, errs = set(), []
+        used, errs, same_idx = set(), [], 0
+        pc = pi.cand_index.cpu().long() if hasattr(pi, 'cand_index') else None
         for j in range(g['labels'].shape[0]):          # same label, same box (1e-2 px), same score (1e-4): tests/_match.py
             d = (pb - g['bboxes'][j]).abs().amax(1)
             d[(pl != g['labels'][j])] = float('inf')
@@ -259,6 +260,12 @@ def parity_canary(model, imgs, metas, arch, kind, lora=False):
                 used.add(i)
                 errs.append(float((sample[i] - g['low_res_sample'][j]).abs().max()))
         out['detections_matched'] = f'{len(errs)}/{int(g["labels"].shape[0])}'
+        if pc is not None and 'cand' in g:
+            # index equality, position by position: detection j of the tile is the oracle's detection j -- the same kept
+            # candidate (proposal x class entry of the free-running R-CNN stage) with the same label
+            n = min(k0, int(g['cand'].shape[0]))
+            same_idx = int(((pc[:n] == g['cand'][:n]) & (pl[:n] == g['labels'][:n])).sum())
+            out['indices_equal'] = f'{same_idx}/{int(g["cand"].shape[0])}'
         out['mask_logit_max_abs_err'] = max(errs) if errs else None
         out['mask_logit_range'] = g['low_res_absmax']
         out['tolerance'] = 1e-3
@@ -275,14 +282,16 @@ def _pmc_traffic(arch):
     process, so the number is the one measured with tools/pmc_round2.sh on the kernel's most expensive shape of this
     architecture; None when no pass exists for it."""
     root = os.path.dirname(os.path.abspath(__file__))
-    for rel in (f'profiles/r5_pmc/gemm_traffic_{arch}.json', f'profiles/r4_pmc/gemm_traffic_{arch}.json', f'profiles/r3_pmc/gemm_traffic_{arch}.json', f'profiles/r2_pmc/gemm_traffic_{arch}.json', 'profiles/r1_pmc/gemm_lin1_traffic.json'):
+    for rel in (f'profiles/r6_pmc/gemm_traffic_{arch}.json', f'profiles/r5_pmc/gemm_traffic_{arch}.json', f'profiles/r4_pmc/gemm_traffic_{arch}.json', f'profiles/r3_pmc/gemm_traffic_{arch}.json', f'profiles/r2_pmc/gemm_traffic_{arch}.json', 'profiles/r1_pmc/gemm_lin1_traffic.json'):
         try:
             with open(os.path.join(root, rel)) as fh:
                 t = json.load(fh)
             if arch != 'base' and rel.startswith('profiles/r1_pmc'):
                 return None                      # that pass was taken on the ViT-B shape only
             return {'bytes_per_launch': t['traffic_bytes_per_launch'], 'algorithmic_bytes_per_launch': t['algorithmic_bytes_per_launch'],
-                    'shape': t['shape'], 'source': rel}
+                    'shape': t['shape'], 'source': rel, 'measured_in_this_run': False,
+                    'how': 'rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this kernel shape on another MI355X box, committed under '
+                           'profiles/; PMC counters cannot be read from inside the benchmark process'}
         except Exception:
             continue
     return None
@@ -318,12 +327,13 @@ def main():
     ap.add_argument('--shapes', action='store_true', help='break the kernel table down by GEMM/attention shape')
     ap.add_argument('--host-inputs', action='store_true',
                     help='NOT the headline: the tiles start in pinned host memory every step (PCIe-inclusive rate for DESIGN.md)')
-    ap.add_argument('--f8corr', action='store_true',
+    ap.add_argument('--f8corr', nargs='?', const='all', default=None, choices=['all', 'mlp'],
                     help='opt-in fast mode: encoder GEMMs as fp16 hi.hi + one fp8 correction MFMA (DESIGN.md section 3); '
                          'NOT the headline configuration -- parity margins are 8x smaller')
-    ap.add_argument('--exchange', choices=['gather', 'allgather'], default='gather',
-                    help="N > 1: where the per-image results of a step go -- 'gather': rank 0 only (mmengine collect_results, "
-                         "what tools/dist_test.sh evaluates); 'allgather': every rank (BASELINE.json north_star's wording)")
+    ap.add_argument('--exchange', choices=['gather', 'allgather'], default='allgather',
+                    help="N > 1: where the per-image results of a step go -- 'allgather' (default since round 6): every rank, "
+                         "BASELINE.json north_star's \"RCCL all-gather of instance results\"; 'gather': rank 0 only (mmengine "
+                         "collect_results, what tools/dist_test.sh evaluates)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -346,7 +356,7 @@ def main():
     from rsprompter_amd import dist as rdist
     from rsprompter_amd import ops
     if args.f8corr:
-        ops.F8_CORR = True
+        ops.F8_CORR = True if args.f8corr == 'all' else args.f8corr
     from rsprompter_amd.structures import DetDataSample
     from rsprompter_amd.synth import synth_images, synth_metas
     import torch.distributed as tdist
@@ -405,7 +415,7 @@ def main():
         elapsed = float(t.item())
     n_dets = sum(len(r.bboxes) for r in step())
     sync()
-    canary = parity_canary(model, imgs, metas, args.arch, args.model, args.lora) if rank == 0 and not args.f8corr else None
+    canary = parity_canary(model, imgs, metas, args.arch, args.model, args.lora) if rank == 0 else None
 
     result = None
     # ---- roofline leg: one extra instrumented step, per-kernel HIP events on the launch stream.  Every rank runs
@@ -463,6 +473,7 @@ def main():
                          'ms_per_step': round(dom['ms'], 3), 'achieved': round(achieved, 2),
                          'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F16_MFMA_TFLOPS, 4),
                          'traffic': (_pmc_traffic(args.arch) or {}).get('bytes_per_launch'), 'traffic_detail': _pmc_traffic(args.arch),
+                         'traffic_measured_in_this_run': False,
                          'note': 'achieved = algorithmic fp32 FLOPs (2MNK) of all launches of the kernel in one step / '
                                  'their summed HIP-event durations; the kernel issues 3 fp16 MFMA passes per algorithmic '
                                  'FLOP (fp16x3), so its ceiling is peak/3 = 833 TFLOP/s'
@@ -476,6 +487,9 @@ def main():
                                    'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                    'frac': None if attn_tf is None else round(attn_tf / PEAK_F16_MFMA_TFLOPS, 4),
                                    'attention_gemm_gflop_per_image': ATTN_GEMM_GFLOP_PER_IMAGE[args.arch]},
+            'exchange': None if world == 1 else ('all-gather of instance results (records + COCO RLE strings) to every rank' if args.exchange == 'allgather'
+                                                 else 'gather of instance results to rank 0'),
+            'rccl_ranks': world if world > 1 else 0,
             'parity_canary': canary,
             'kernels': kernels,
         }

@@ -262,14 +262,17 @@ extern "C" int rsp_layernorm_ex(const float* x, const float* gamma, const float*
   if (yhi && (C & 63) == 0 && C >= 256 && C <= 1280) {          // the encoder's plane-producing LayerNorms
     const int64_t blocks16 = (rows + 15) / 16;
     if (blocks16 > 0x7fffffffLL) return RSP_EINVAL;
-    if (!f8 && (C & 127) == 0) {      // (ViT-H rows: 4.07 -> 4.36 TB/s; profiles/r5_layernorm_x8_vs_x4.txt)
+    // (ViT-H rows: 4.07 -> 4.36 TB/s; profiles/r5_layernorm_x8_vs_x4.txt).  One instantiation per width in use; every
+    // other multiple of 128 (384, 640, 896, 1152) goes on to the x4 switch / the one-row-per-wave kernel below (round 5
+    // sent them to the C = 1280 instantiation: wrong row stride)
+    if (!f8 && (C & 127) == 0 && (C == 256 || C == 512 || C == 768 || C == 1024 || C == 1280)) {
 #define RSP_LN8_LAUNCH(NC) hipLaunchKernelGGL((layernorm_rows4x8_kernel<NC>), dim3((unsigned)blocks16), dim3(256), 0, s, x, gamma, beta, y, rows, eps, act, hi, lo, ps)
       switch (C / 128) {
         case 2: RSP_LN8_LAUNCH(2); break;
         case 4: RSP_LN8_LAUNCH(4); break;
         case 6: RSP_LN8_LAUNCH(6); break;
         case 8: RSP_LN8_LAUNCH(8); break;
-        default: RSP_LN8_LAUNCH(10); break;
+        default: RSP_LN8_LAUNCH(10); break;      // C == 1280
       }
 #undef RSP_LN8_LAUNCH
       RSP_CHECK_LAUNCH();

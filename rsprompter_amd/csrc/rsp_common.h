@@ -134,7 +134,9 @@ __device__ __forceinline__ float rsp_gelu(float x) {
   q = __builtin_fmaf(q, u, RSP_GELU_C2);
   q = __builtin_fmaf(q, u, RSP_GELU_C1);
   const float e = __builtin_amdgcn_exp2f(-(q * u));       // erfc(|x| / sqrt 2)
-  return __builtin_fmaf(-0.5f * u, e, __builtin_fmaxf(x, 0.0f));     // (u instead of |x|: where they differ e is exactly 0)
+  // (u instead of |x|: where they differ e is exactly 0.)  max(x, 0) is written 0.5 x + 0.5 |x|: the same bits for every
+  // finite normal x, but a NaN input stays NaN as in torch / HF (fmaxf(NaN, 0) = 0 silently zeroed a bad activation: ADVICE r5)
+  return __builtin_fmaf(-0.5f * u, e, __builtin_fmaf(0.5f, x, 0.5f * __builtin_fabsf(x)));
 }
 // the same arithmetic on four values (identical results element by element: fma / mul are the same operations packed)
 __device__ __forceinline__ f32x4 rsp_gelu4(const f32x4 x) {
@@ -155,7 +157,7 @@ __device__ __forceinline__ f32x4 rsp_gelu4(const f32x4 x) {
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     ex[e] = __builtin_amdgcn_exp2f(-pu[e]);
-    rl[e] = __builtin_fmaxf(x[e], 0.0f);
+    rl[e] = __builtin_fmaf(0.5f, x[e], 0.5f * __builtin_fabsf(x[e]));      // max(x, 0), NaN-propagating (see rsp_gelu)
   }
   return __builtin_elementwise_fma(hx, ex, rl);
 }

@@ -163,7 +163,8 @@ PLANE_F8 = 0x100        # include/rsp_hip.h "Plane format word"
 # Measured: GEMMs 1.15-1.25x faster, image embeddings 1.0-1.4e-4 instead of 1.2-1.6e-5 off the fp32
 # reference -- inside the 1e-3 budget, but the masked query decoder then flips 10 instead of 4 attention-mask decisions
 # on the ViT-H + LoRA fixture, so the default stays the three-pass fp16x3 product.
-F8_CORR = os.environ.get('RSP_F8CORR', '0') == '1'
+# RSP_F8CORR=mlp (round 6 study): only lin1 / lin2 of every block.
+F8_CORR = {'0': False, '': False, '1': True, 'all': True, 'mlp': 'mlp'}[os.environ.get('RSP_F8CORR', '0')]
 
 
 def plane_word(scale_log2, f8=False):

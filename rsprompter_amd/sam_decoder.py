@@ -96,6 +96,10 @@ class SamMaskDecoderHIP(HIPModule):
         self.t2i_fold = True
         # the upscaler tail in one kernel (csrc/upscale.hip, sam_upscale_fused_kernel)
         self.upscale_fused = True
+        # parity tests: keep the stage tensors of the last decode() (per-RoI key planes, tokens, upscaler planes, hyper-network
+        # vectors) in `_last_stages` so that a failure names its kernel; pins GBs at R = 800, hence off by default
+        self.keep_stages = False
+        self._last_stages = None
 
     # ------------------------------------------------------------------ packing
     def _pw(self, name, with_bias=True):
@@ -348,6 +352,7 @@ class SamMaskDecoderHIP(HIPModule):
         q = self._ln(q, 'transformer.layer_norm_final_attn', eps=1e-5)
         del kv, qi, ai
         q3 = q.view(R, T, HID)
+        stages = dict(keys=keys_pl, tokens=q3, up=None, hyper=[]) if self.keep_stages else None
 
         # ---------------- upscaling + hyper-network (HF:513-531) ----------------
         # mask token 0 is the only mask kept with multimask_output=False, tokens 1..3 otherwise (HF:537-542)
@@ -359,12 +364,16 @@ class SamMaskDecoderHIP(HIPModule):
             up = ops.conv_transpose2x2(keys_pl.view(R, h, w, HID), *P['up1'], act=ops.ACT_GELU,
                                        ln=(self.upscale_layer_norm.weight, self.upscale_layer_norm.bias, 1e-6))
             del keys_pl                                                                 # [R, 2h, 2w, 64] planes
+            if stages is not None:
+                stages['up'] = up
         outs = []
         for i in toks:
             mt = q3[:, 1 + i, :].contiguous()
             hy = ops.gemm(mt, P[f'hyper{i}.proj_in'], act=ops.ACT_RELU)
             hy = ops.gemm(hy, P[f'hyper{i}.layers.0'], act=ops.ACT_RELU)
             hy = ops.gemm(hy, P[f'hyper{i}.proj_out'])
+            if stages is not None:
+                stages['hyper'].append(hy)
             if fused_up:
                 # one pass over the keys: no [R, 2h, 2w, 64] intermediate (csrc/upscale.hip, sam_upscale_fused_kernel)
                 outs.append(ops.sam_upscale_fused(keys_pl, P['up1'][0], P['up1'][1], self.upscale_layer_norm.weight,
@@ -374,6 +383,7 @@ class SamMaskDecoderHIP(HIPModule):
             # (multimask: the last ConvTranspose is recomputed per token -- a rarely used option, no [R,4h,4w,32] tensor)
             outs.append(ops.conv_transpose2x2(up, *P['up2'], act=ops.ACT_GELU, hyper=hy).view(R, 1, 4 * h, 4 * w))
         masks = outs[0] if len(outs) == 1 else torch.cat(outs, 1)
+        self._last_stages = stages
         iou = None
         if want_iou:
             it = q3[:, 0, :].contiguous()

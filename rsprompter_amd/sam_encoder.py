@@ -114,8 +114,12 @@ class SamVisionEncoderHIP(HIPModule):
         ops.require_device(dev)
         # the four big GEMMs of every block run the fp8-corrected product (ops.F8_CORR): weights and
         # the activation planes feeding them (LN / attention / GELU epilogues) carry the cat8 second plane
-        f8 = bool(ops.F8_CORR)
-        P = {'f8': f8}
+        # ops.F8_CORR: False | True / 'all' (qkv, proj, lin1, lin2) | 'mlp' (lin1 + lin2 only: 58 % of the encoder's GEMM FLOPs;
+        # round 6 study)
+        pol = ops.F8_CORR
+        f8 = bool(pol) and pol != 'mlp'          # qkv / proj (and the LayerNorm-1 / attention planes feeding them)
+        f8m = bool(pol)                          # lin1 / lin2 (LayerNorm-2 planes, lin1's GELU planes)
+        P = {'f8': f8, 'f8_mlp': f8m}
         w = self.patch_embed.projection.weight
         P['patch'] = ops.PackedWeight(w.reshape(w.shape[0], -1), self.patch_embed.projection.bias)
         P['pos'] = self.pos_embed.detach().reshape(-1, self.D).contiguous()
@@ -141,8 +145,8 @@ class SamVisionEncoderHIP(HIPModule):
                 ln2=(ln2.weight.detach(), ln2.bias.detach()),
                 qkv=ops.PackedWeight(wq, L.attn.qkv.bias, f8=f8),
                 proj=ops.PackedWeight(L.attn.proj.weight, L.attn.proj.bias, f8=f8),
-                lin1=ops.PackedWeight(lin1.weight, lin1.bias, f8=f8),
-                lin2=ops.PackedWeight(lin2.weight, lin2.bias, f8=f8),
+                lin1=ops.PackedWeight(lin1.weight, lin1.bias, f8=f8m),
+                lin2=ops.PackedWeight(lin2.weight, lin2.bias, f8=f8m),
                 rph=rph, rpw=rpw,
             ))
         nm = self.nm
@@ -179,8 +183,14 @@ class SamVisionEncoderHIP(HIPModule):
         return self._maps[key]
 
     def _kv_planes(self, layer, B, rows, L, pad_rows, device):
+        """the K | V plane buffer windowed layer `layer` keeps (padded rows = the bias, written once).  Footprint: 2 D fp32-
+        equivalents per window row -- 0.4 GB per layer at ViT-H / B = 8, 11 GB over its 28 windowed layers -- so only ONE
+        batch size's set stays resident: a call with another B (a short last batch) drops the previous set first.
+        The buffers belong to the module: two forwards of one module on different streams must not overlap."""
         key = ('kv', layer, B, str(device))
         if key not in self._maps:
+            for k in [k for k in self._maps if k[0] == 'kv' and k[2:] != key[2:]]:
+                del self._maps[k]
             kv = ops.empty_planes((rows, 2 * self.D), device)      # (fp16 hi / lo: the attention kernels' operand format)
             ops.fill_bias_rows(L['qkv'].bias, pad_rows, 3 * self.D, out=None, planes=kv, c_ncols=self.D, pl_col0=self.D)
             self._maps[key] = kv
@@ -212,7 +222,7 @@ class SamVisionEncoderHIP(HIPModule):
         del patches
         hidden = [x] if want_hidden else None
         scale = dh ** -0.5
-        f8 = P['f8']
+        f8, f8m = P['f8'], P['f8_mlp']
         for i in range(self.depth):
             L = P['layers'][i]
             S = L['S']
@@ -252,8 +262,8 @@ class SamVisionEncoderHIP(HIPModule):
             # window order (the padded rows are never multiplied)
             x1 = ops.gemm(att, L['proj'], res=x, a_rowmap=rowmap, M=B * T)
             del qkv, rel, att, xn
-            xn2 = ops.layernorm(x1, L['ln2'][0], L['ln2'][1], self.eps, planes=True, f32=False, f8=f8)
-            hmid = ops.gemm(xn2, L['lin1'], act=ops.ACT_GELU, out_planes=True, out_f32=False, out_f8=f8)
+            xn2 = ops.layernorm(x1, L['ln2'][0], L['ln2'][1], self.eps, planes=True, f32=False, f8=f8m)
+            hmid = ops.gemm(xn2, L['lin1'], act=ops.ACT_GELU, out_planes=True, out_f32=False, out_f8=f8m)
             x = ops.gemm(hmid, L['lin2'], res=x1)
             del hmid, xn2, x1
             if want_hidden:

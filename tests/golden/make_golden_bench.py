@@ -7,7 +7,7 @@
   python tests/golden/make_golden_bench.py query huge --lora    -> bench_canary_query_huge_lora.pt (configs[4] slice,
                                                                    WHU-shape metas: ori_shape 512, scale_factor 2)
 
-Stored (0.2-0.4 MB each).  anchor: the detections of the tile (boxes, scores, labels), a strided sample of each
+Stored (0.2-0.4 MB each).  anchor: the detections of the tile (boxes, scores, labels, kept-candidate indices), a strided sample of each
 detection's 256x256 low-resolution SAM mask logits (every 16th row / column) and of the image embedding (every 8th
 position).  query: class logits of all Nq queries, the same strided sample of every query's SAM mask logits, the selected
 query indices, the embedding sample.  bench.py compares the HIP path's tile 0 with these numbers OUTSIDE its timed region
@@ -52,6 +52,7 @@ def main(kind='anchor', arch='huge', lora=False):
         low = tr['low_res_masks']                             # [k, 1, 256, 256]
         out = dict(kind=kind, arch=arch, image_seed=1234, weight_seed=0,
                    bboxes=r['bboxes'].float(), scores=r['scores'].float(), labels=r['labels'].long(),
+                   cand=tr['dets'][0]['cand'].long(),            # kept candidates: index into the tile's (proposal, class) score matrix
                    low_res_sample=low[:, 0, ::16, ::16].contiguous().float(),
                    low_res_absmax=float(low.abs().max()))
         n = r['labels'].shape[0]

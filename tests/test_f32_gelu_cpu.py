@@ -38,7 +38,9 @@ def gelu_f32(x):
     with np.errstate(under='ignore'):
         e = np.exp2(-pu.astype(np.float64)).astype(f32)
     e = np.where(np.abs(e) < np.finfo(f32).tiny, f32(0), e)        # the device flushes denormal results
-    return _fma((f32(-0.5) * u).astype(f32), e, np.maximum(x, f32(0)))
+    with np.errstate(invalid='ignore'):
+        rl = (f32(0.5) * x + f32(0.5) * ax).astype(f32)         # max(x, 0) for finite x, NaN for NaN (and for -inf, as torch)
+    return _fma((f32(-0.5) * u).astype(f32), e, rl)
 
 
 def test_gelu_error_bound_against_fp64():
@@ -60,6 +62,16 @@ def test_gelu_exponent_polynomial_is_monotone_and_tail_is_zero():
     big = np.array([-13.5, -14, -100, -1e4, -1e30, 13.5, 100, 1e30, 0.0, -0.0], dtype=f32)
     got = gelu_f32(big)
     assert np.array_equal(got[:5], np.zeros(5, f32)) and np.array_equal(got[5:8], big[5:8]) and np.all(got[8:] == 0)
+
+
+def test_gelu_propagates_nan_and_equals_the_max_form_on_finite_inputs():
+    """fmaxf(NaN, 0) = 0 used to turn a NaN activation into 0; 0.5 x + 0.5 |x| keeps it and has the bits of max(x, 0)
+    for every finite x"""
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.normal(size=200_000) * 4, [0.0, -0.0, 1e-30, -1e-30, 3.4e38, -3.4e38, 65504.0, -65504.0]]).astype(f32)
+    assert np.array_equal((f32(0.5) * x + f32(0.5) * np.abs(x)).astype(f32), np.maximum(x, f32(0)))
+    got = gelu_f32(np.array([np.nan, np.inf, 1.0], dtype=f32))
+    assert np.isnan(got[0]) and got[1] == np.inf and abs(got[2] - 0.8413447) < 1e-6
 
 
 @pytest.mark.parametrize('n', [64])

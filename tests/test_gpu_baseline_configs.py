@@ -440,9 +440,36 @@ def test_query_head_option_branches(dev, opts):
     _check_query(model, oracle, imgs, metas, dev, tag)
 
 
-def test_anchor_mask_head_multimask_output(dev):
+def _planes_f32(pl):
+    """fp16 KB32 planes [K/32][rows][32] (hi + lo at scale 2^e) -> the fp32 matrix [rows, K] they stand for"""
+    return ((pl.hi.float() + pl.lo.float()).permute(1, 0, 2).reshape(pl.rows, -1) / 2.0 ** pl.scale_log2).cpu()
+
+
+def _hf_decoder_stages(dec, **kw):
+    """HF SamMaskDecoder.forward (HF:461-543) with the tensors between its stages captured by forward hooks: the two-way
+    transformer's outputs (tokens, per-RoI keys), the first ConvTranspose + LayerNorm2d + GELU, every hyper-network MLP"""
+    got, hooks = {}, []
+    hooks.append(dec.transformer.register_forward_hook(lambda m, a, o: got.update(tokens=o[0], keys=o[1])))
+    hooks.append(dec.upscale_layer_norm.register_forward_hook(lambda m, a, o: got.update(up_ln=o)))
+    for i, mlp in enumerate(dec.output_hypernetworks_mlps):
+        hooks.append(mlp.register_forward_hook(lambda m, a, o, i=i: got.update({f'hyper{i}': o})))
+    try:
+        with torch.no_grad():
+            out = dec(**kw)
+    finally:
+        for h in hooks:
+            h.remove()
+    got['up'] = torch.nn.functional.gelu(got['up_ln'])           # [R, 64, 2h, 2w] (HF:519-520)
+    return out, got
+
+
+@pytest.mark.parametrize('hw', [16, 64])
+def test_anchor_mask_head_multimask_output(dev, hw):
     """RSPrompterAnchorMaskHead(multimask_output=True): the three masks / iou scores of mask tokens 1..3 (HF:537-542) against
-    the HF decoder fed the oracle's prompts."""
+    the HF decoder fed the oracle's prompts -- and, stage by stage, the kernel chain that only this option (and shapes
+    the fused kernels do not take) runs: the per-RoI keys and tokens out of the two-way transformer, ConvTranspose +
+    LayerNorm2d + GELU planes (the LN epilogue of gemm_f16x3_dma_kernel), each token's hyper-network vector, the product
+    (sam_upscale2_kernel), so that a failure names its kernel.  hw = 64 is the shipped embedding size."""
     from oracle import hf_sam
     from rsprompter_amd.registry import MODELS
     from rsprompter_amd.synth import synth_state_dict
@@ -457,20 +484,30 @@ def test_anchor_mask_head_multimask_output(dev):
     g = torch.Generator().manual_seed(0)
     R, B = 7, 2
     x = torch.randn(R, 256, 14, 14, generator=g)
-    emb = torch.randn(B, 256, 64, 64, generator=g)
-    ipe = torch.randn(1, 256, 64, 64, generator=g).expand(B, -1, -1, -1).contiguous()
+    emb = torch.randn(B, 256, hw, hw, generator=g)
+    ipe = torch.randn(1, 256, hw, hw, generator=g).expand(B, -1, -1, -1).contiguous()
     roi_img = torch.tensor([0, 0, 0, 1, 1, 1, 1])
     cl = lambda t: t.to(dev).contiguous(memory_format=torch.channels_last)
+    hip = head.mask_decoder.mask_decoder
+    hip.keep_stages = True
     low, iou = head(cl(x), cl(emb), cl(ipe), roi_img.to(dev))
-    assert tuple(low.shape) == (R, 3, 256, 256) and tuple(iou.shape) == (R, 3)
+    assert tuple(low.shape) == (R, 3, 4 * hw, 4 * hw) and tuple(iou.shape) == (R, 3)
     sparse = head.point_embeddings(cl(x)).cpu()
-    with torch.no_grad():
-        ref_m, ref_i = dec(image_embeddings=emb[roi_img], image_positional_embeddings=ipe[roi_img],
-                           sparse_prompt_embeddings=sparse.unsqueeze(1),
-                           dense_prompt_embeddings=sd['no_mask_embed.weight'].reshape(1, -1, 1, 1).expand(R, -1, 64, 64),
-                           multimask_output=True)[:2]
-    e_m, e_i = _maxerr(low, ref_m.reshape(R, 3, 256, 256)), _maxerr(iou, ref_i.reshape(R, 3))
-    print(f'multimask_output=True: masks err {e_m:.2e} (range {float(ref_m.abs().max()):.1f}), iou err {e_i:.2e}')
+    (ref_m, ref_i, *_), ref = _hf_decoder_stages(
+        dec, image_embeddings=emb[roi_img], image_positional_embeddings=ipe[roi_img], sparse_prompt_embeddings=sparse.unsqueeze(1),
+        dense_prompt_embeddings=sd['no_mask_embed.weight'].reshape(1, -1, 1, 1).expand(R, -1, hw, hw), multimask_output=True)
+    st = hip._last_stages
+    T = 1 + 4 + 5
+    errs = dict(
+        tokens=_maxerr(st['tokens'], ref['tokens'].reshape(R, T, 256)),
+        keys=_maxerr(_planes_f32(st['keys']), ref['keys'].reshape(R * hw * hw, 256)),
+        up=_maxerr(_planes_f32(st['up']), ref['up'].permute(0, 2, 3, 1).reshape(-1, 64)),
+        hyper=max(_maxerr(h, ref[f'hyper{i}'].reshape(R, 32)) for i, h in zip((1, 2, 3), st['hyper'])))
+    e_m, e_i = _maxerr(low, ref_m.reshape(R, 3, 4 * hw, 4 * hw)), _maxerr(iou, ref_i.reshape(R, 3))
+    print(f'multimask_output=True at {hw}x{hw}: masks err {e_m:.2e} (range {float(ref_m.abs().max()):.1f}), iou err {e_i:.2e}; stages '
+          + ', '.join(f'{k} {v:.2e}' for k, v in errs.items()))
+    for k, v in errs.items():
+        assert v < LOGIT_TOL, f'stage {k}: {v:.2e}'
     assert e_m < LOGIT_TOL and e_i < LOGIT_TOL
 
 

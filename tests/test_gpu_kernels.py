@@ -110,6 +110,15 @@ def test_layernorm(dev):
         assert float((got.cpu().double() - ref).abs().max()) < 2e-5
         got = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-6, act=ops.ACT_GELU)
         assert float((got.cpu().double() - F.gelu(ref)).abs().max()) < 2e-5
+    # plane outputs at every multiple of 128 up to 1408 (the eight-column kernel has five widths; 384 / 640 / 896 / 1152 once
+    # ran its C = 1280 instantiation: ADVICE r5) and the widths only the other kernels take
+    for C in (256, 320, 384, 512, 640, 768, 896, 1024, 1152, 1280, 1408):
+        x = torch.randn(203, C, generator=g) * 3 + 1
+        w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        ref = F.layer_norm(x.double(), (C,), w.double(), b.double(), 1e-6)
+        y, pl = ops.layernorm(x.to(dev), w.to(dev), b.to(dev), 1e-6, planes=True)
+        assert float((y.cpu().double() - ref).abs().max()) < 2e-5, C
+        assert float((_planes_to_f32(pl).cpu().double() - ref).abs().max()) < 2e-5, C
 
 
 def _ref_vit_attention(qkv, rph, rpw, S, nh, dh, scale):

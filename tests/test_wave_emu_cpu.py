@@ -374,8 +374,8 @@ def test_emu_layernorm_shapes_property(emu):
     import torch.nn.functional as F
     import test_gpu_kernels as tk
 
-    @settings(max_examples=40, deadline=None, derandomize=True)
-    @given(st.integers(1, 130), st.sampled_from([32, 64, 96, 128, 256, 320, 768, 1280]), st.booleans(), st.integers(0, 2 ** 31 - 1))
+    @settings(max_examples=70, deadline=None, derandomize=True)
+    @given(st.integers(1, 130), st.sampled_from([32, 64, 96, 128, 256, 320, 384, 512, 640, 768, 896, 1024, 1152, 1280, 1408]), st.booleans(), st.integers(0, 2 ** 31 - 1))
     def check(rows, C, planes, seed):
         g = torch.Generator().manual_seed(seed)
         x = torch.randn(rows, C, generator=g) * 3 + 1

@@ -38,7 +38,10 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+// LDS arrays are function-local statics gathered in ONE linker section, so that the poison mode (emu_set_poison_lds) can
+// overwrite all of LDS with 0xFF bytes (NaN as fp32 / fp16) at the start of every block: on the device a block inherits whatever
+// the previous block on its CU left there, and a kernel that reads LDS it has not written is box- and timing-dependent
+#define __shared__ static __attribute__((section("emu_lds")))
 
 struct dim3 {
   unsigned x, y, z;
@@ -165,6 +168,7 @@ struct State {
   // refilled while another wave still reads it); 1: it writes LDS only when an `s_waitcnt vmcnt(n)` of the wave demands it
   // (the LATEST the hardware may do it: exposes a missing wait in front of the barrier).  Tests run DMA kernels both ways.
   int lazy_dma = 0;
+  int poison_lds = 0;      // 1: every block starts with all of LDS = 0xFF bytes
 };
 extern State g;
 #ifdef EMU_IMPLEMENTATION
@@ -273,6 +277,7 @@ inline void lane_exit() {
 
 void fiber_main();
 void run_launch();
+void poison_lds_now();
 #ifdef EMU_IMPLEMENTATION
 void fiber_main() {
   g.L.body();
@@ -300,6 +305,7 @@ void run_launch() {
     for (unsigned by = 0; by < L.grid.y; ++by)
       for (unsigned bx = 0; bx < L.grid.x; ++bx) {
         g.L.block_idx = uint3_emu{bx, by, bz};
+        if (g.poison_lds) poison_lds_now();
         g.blk = &blk;
         blk.live = T; blk.bar_arrived = 0;
         for (int w = 0; w < nw; ++w) {
@@ -356,6 +362,12 @@ alignas(64) extern unsigned char dyn_smem_buf[160 * 1024];
 #ifdef EMU_IMPLEMENTATION
 alignas(64) unsigned char dyn_smem_buf[160 * 1024];
 extern "C" void emu_set_lazy_dma(int on) { g.lazy_dma = on; }
+extern "C" void emu_set_poison_lds(int on) { g.poison_lds = on; }
+extern "C" unsigned char __start_emu_lds[], __stop_emu_lds[];
+void poison_lds_now() {
+  memset(__start_emu_lds, 0xFF, (size_t)(__stop_emu_lds - __start_emu_lds));
+  memset(dyn_smem_buf, 0xFF, sizeof(dyn_smem_buf));
+}
 #endif
 inline void* dyn_smem() { return dyn_smem_buf; }
 

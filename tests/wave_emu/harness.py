@@ -24,6 +24,7 @@ def load_emu():
             fn = getattr(lib, name)        # every symbol of include/rsp_hip.h must exist in the emulated build too
             fn.restype, fn.argtypes = res, args
         lib.emu_set_lazy_dma.argtypes = [ctypes.c_int]
+        lib.emu_set_poison_lds.argtypes = [ctypes.c_int]
         if os.environ.get('RSP_WAVE_EMU_COUNT'):
             lib = _Counting(lib, os.environ['RSP_WAVE_EMU_COUNT'])
         _EMU = lib
@@ -81,6 +82,8 @@ def emulated_ops():
             raise ValueError(f'{name}: expected float32')
     ops._stream, ops._chk_f32, ops.require_device, ops._is_device = (lambda: 0), chk, (lambda dev: None), (lambda t: True)
     lib.emu_set_lazy_dma(1 if os.environ.get('RSP_WAVE_EMU_LAZY') == '1' else 0)     # audit mode: see lazy_dma()
+    # audit mode 2 (round 6): every block starts with LDS = 0xFF bytes (NaN): a read of LDS nobody wrote shows up
+    lib.emu_set_poison_lds(1 if os.environ.get('RSP_WAVE_EMU_POISON_LDS', '1') == '1' else 0)
     try:
         yield ops
     finally:

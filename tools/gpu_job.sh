@@ -5,6 +5,7 @@
 #
 # Every step writes into gpurun_out/<out-subdir>/ and prints one status line; a failing step does not stop the next.
 #   t:<name>:<pytest args>     python -m pytest -m gpu -q <args>                -> <name>.log      (timeout 1500 s)
+#   n:<name>:<pytest args>     the same under RSP_POISON_EMPTY=1 (tests/conftest.py: torch.empty starts as NaN bytes)
 #   b:<name>:<bench args>      python bench.py <args>                           -> bench_<name>.json / .err
 #   p:<name>:<bench args>      rocprofv3 --kernel-trace --stats -- bench.py ... -> prof_<name>/ + prof_<name>_kernel_stats.csv
 #   x:<name>:<command>         bash -c <command>                                -> <name>.log      (timeout 900 s)
@@ -20,6 +21,8 @@ for step in "$@"; do
   t0=$(date +%s)
   case $kind in
     t) eval "timeout 1500 python -m pytest -m gpu -q $args" > "$O/$name.log" 2>&1; rc=$?
+       tail -n 3 "$O/$name.log" | tr '\n' ' ' ;;
+    n) eval "RSP_POISON_EMPTY=1 timeout 1500 python -m pytest -m gpu -q $args" > "$O/$name.log" 2>&1; rc=$?
        tail -n 3 "$O/$name.log" | tr '\n' ' ' ;;
     b) timeout 900 python bench.py $args > "$O/bench_$name.json" 2> "$O/bench_$name.err"; rc=$?
        python - "$O/bench_$name.json" <<'PY'
