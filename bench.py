@@ -209,18 +209,21 @@ def _parity_canary_query(model, res, out, path):
     return out
 
 
-def parity_canary(model, imgs, metas, arch, kind, lora=False):
+def parity_canary(model, imgs, metas, arch, kind, lora=False, res=None):
     """One extra step OUTSIDE the timed region on the bench's own inputs, tile 0 compared with the CPU oracle's answer
     for exactly this fixture (tests/golden/bench_canary_anchor_<arch>.pt, written by tests/golden/make_golden_bench.py;
     nothing under oracle/ is imported here).  Reports whether every output of the step is finite, the max-abs error
     of the image embedding and of the SAM low-resolution mask logits of the detections matched to the oracle's, and how
-    many matched.  A bench that runs on NaN rows, stale kernels or a wrong weight layout says so on its own line."""
+    many matched.  A bench that runs on NaN rows, stale kernels or a wrong weight layout says so on its own line.
+    res: the outputs of a test_step the caller has just run on these inputs with rsprompter_amd.debug.KEEP_TRACES on (the GPU
+    tests hold tile 0 of the bench fixtures against the same goldens); None: run the step here."""
     import rsprompter_amd.debug as dbg
     from rsprompter_amd.structures import DetDataSample
     out = dict(finite=None, golden=None)
     keep, dbg.KEEP_TRACES = dbg.KEEP_TRACES, True
     try:
-        res = model.test_step(dict(inputs=imgs, data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
+        if res is None:
+            res = model.test_step(dict(inputs=imgs, data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
         torch.cuda.synchronize()
         fin = True
         for r in res:

@@ -389,8 +389,6 @@ class RSPrompterAnchorMaskHead(HIPModule):
             img_h = np.round(img_h * np.float32(sf_h)).astype(np.int32)
             img_w = np.round(img_w * np.float32(sf_w)).astype(np.int32)
         thr = rcnn_test_cfg['mask_thr_binary'] if isinstance(rcnn_test_cfg, dict) else rcnn_test_cfg.mask_thr_binary
-        if thr < 0:
-            raise NotImplementedError('mask_thr_binary < 0 (visualisation mode)')
         if mask_preds.shape[1] != 1:
             # the reference's own post-processing is written for one mask per instance: with the three masks of
             # multimask_output=True its `.squeeze(1)` is a no-op and the second F.interpolate gets a 5-D tensor
@@ -400,6 +398,11 @@ class RSPrompterAnchorMaskHead(HIPModule):
         Hb, Wb = img_meta['batch_input_shape']
         crop = (min(int(img_h * sf_h), Hb), min(int(img_w * sf_w), Wb))
         h, w = img_meta['ori_shape'][:2]
+        if thr < 0:
+            # models.py:1779-1783 "for visualization and debugging": the resized probabilities as uint8, (p * 255) truncated
+            _, prob = ops.mask_post(mask_preds[:, 0].contiguous(), (Hb, Wb), crop, (h, w), 0.5, True)
+            soft = (prob * 255).to(torch.uint8)
+            return (soft, prob) if want_prob else soft
         return ops.mask_post(mask_preds[:, 0].contiguous(), (Hb, Wb), crop, (h, w), float(thr), want_prob)
 
 

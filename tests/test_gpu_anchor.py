@@ -37,16 +37,19 @@ def setup(dev):
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         model = ra.build_model(rsprompter_anchor(ARCH, 10))
-    oracle = AnchorOracle(ARCH, 10)
-    sd = synth_state_dict(oracle, seed=0)
-    oracle.load_state_dict(sd)
+    if ARCH == 'base':
+        from _oracle_cache import anchor_base_two_tiles          # one oracle run, shared with test_gpu_f8corr.py
+        oracle, sd, imgs, metas, x, results, trace = anchor_base_two_tiles()
+    else:
+        oracle = AnchorOracle(ARCH, 10)
+        sd = synth_state_dict(oracle, seed=0)
+        oracle.load_state_dict(sd)
+        imgs, metas = synth_images(B), synth_metas(B)
+        x = glue.data_preprocess(imgs, MEAN, STD, True, 32)
+        results, trace = oracle.predict(x, metas)
     missing = model.load_state_dict(sd, strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     model = model.to(dev)
-    imgs = synth_images(B)
-    metas = synth_metas(B)
-    x = glue.data_preprocess(imgs, MEAN, STD, True, 32)
-    results, trace = oracle.predict(x, metas)
     return dict(model=model, oracle=oracle, imgs=imgs, metas=metas, x=x, results=results, trace=trace)
 
 

@@ -183,20 +183,25 @@ def _check_query(model, oracle, imgs, metas, dev, tag, fp64_floor=False):
 
 
 def test_config2_query_vitl_nq100_whu(dev):
-    """BASELINE.json configs[2] tree (rsprompter_query-whu.py with the large ids): 2 tiles, Nq = 100 -> 200 prompt sets
-    through the two-way decoder; WHU metas: ori_shape 512, scale_factor 2 (second resize of the logits)."""
+    """BASELINE.json configs[2] tree (rsprompter_query-whu.py with the large ids): one tile (the batch-16 test below runs
+    1600 prompt sets), Nq = 100 prompt sets through the two-way decoder; WHU metas: ori_shape 512, scale_factor 2 (second
+    resize of the logits).  The live-oracle test of the ViT-L query variant."""
     from oracle.query import QueryOracle
     from rsprompter_amd.default_configs import rsprompter_query
     from rsprompter_amd.synth import synth_images, synth_metas
     oracle = QueryOracle('large', 1, 100, max_per_image=100)
     model = _build(rsprompter_query('large', 1, (100, 5)), oracle, dev)
-    imgs = synth_images(2)
-    metas = synth_metas(2, ori_shape=(512, 512), scale_factor=(2.0, 2.0))
+    imgs = synth_images(1)
+    metas = synth_metas(1, ori_shape=(512, 512), scale_factor=(2.0, 2.0))
     _check_query(model, oracle, imgs, metas, dev, 'configs[2] query ViT-L')
 
 
 def test_config4_query_vith_lora_nq100_whu(dev):
-    """BASELINE.json configs[4]: query path on ViT-H + LoRA adapters (non-zero A and B), Nq = 100, WHU-shape."""
+    """BASELINE.json configs[4]: query path on ViT-H + LoRA adapters (non-zero A and B), Nq = 100, WHU-shape.  The live-oracle
+    test of the ViT-H + LoRA query variant.  (Rounds 3-5 also ran the oracle in fp64 here -- `_check_query(fp64_floor=True)`,
+    a second 60-s CPU forward -- to show the floor the reference's own fp32 forward has against fp64; that study lives in
+    tools/parity_fp64_study.py, results profiles/r3_parity_fp64_study_config4.json; the criterion WHERE a decision may differ
+    -- only at a tie of the oracle's own logit -- is asserted either way.)"""
     from oracle.query import QueryOracle
     from rsprompter_amd.default_configs import rsprompter_query_lora
     from rsprompter_amd.synth import synth_images, synth_metas
@@ -205,7 +210,7 @@ def test_config4_query_vith_lora_nq100_whu(dev):
     assert any('lora_B.default' in k for k in model.state_dict())
     imgs = synth_images(1, seed=77)
     metas = synth_metas(1, ori_shape=(512, 512), scale_factor=(2.0, 2.0))
-    _check_query(model, oracle, imgs, metas, dev, 'configs[4] query ViT-H+LoRA', fp64_floor=True)
+    _check_query(model, oracle, imgs, metas, dev, 'configs[4] query ViT-H+LoRA')
 
 
 def test_query_nwpu_peft512_config(dev):
@@ -223,9 +228,27 @@ def test_query_nwpu_peft512_config(dev):
 _SHARED = {}
 
 
+def _bench_canary(model, out, imgs_dev, metas, arch, kind, lora=False):
+    """tile 0 of a bench fixture (weight seed 0, synth_images(B, seed=1234), bench.py's metas) against the CPU oracle's answer
+    for exactly that tile, committed by tests/golden/make_golden_bench.py -- bench.py's own parity canary, asserted.  Round 6:
+    replaces one live 25-60 s oracle forward per test; every encoder / prompter variant keeps one live-oracle test."""
+    if _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))) not in _sys.path:
+        _sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+    import bench
+    c = bench.parity_canary(model, imgs_dev, metas, arch, kind, lora, res=out)
+    print(f'bench canary ({kind} ViT-{arch}{" + LoRA" if lora else ""}, tile 0 vs {c.get("golden")}): '
+          + ', '.join(f'{k} {v}' for k, v in c.items() if k not in ('golden', 'tolerance')))
+    assert c['golden'] is not None and c['finite'] and c['ok'], c
+    assert c['image_embedding_max_abs_err'] < LOGIT_TOL
+    if kind == 'anchor':
+        assert c['mask_logit_max_abs_err'] < LOGIT_TOL
+    return c
+
+
 def _vith_anchor_shared(dev):
-    """configs[3] fixture of the two ViT-H anchor tests: ONE model, ONE oracle run (tiles 0, 1, 7 of the bench batch) -- the CPU
-    oracle's ViT-H forward costs ~25 s per tile, and the suite runs against a wall-clock limit"""
+    """configs[3] fixture of the two ViT-H anchor tests: ONE model, ONE oracle run (tiles 1 and 7 of the bench batch; tile 0 is
+    held against the committed golden of the bench canary) -- the CPU oracle's ViT-H forward costs ~25 s per tile, and the suite
+    runs against a wall-clock limit"""
     if 'vith_anchor' not in _SHARED:
         from oracle import glue
         from oracle.anchor import AnchorOracle
@@ -234,89 +257,84 @@ def _vith_anchor_shared(dev):
         oracle = AnchorOracle('huge', 10)
         model = _build(rsprompter_anchor('huge', 10), oracle, dev)
         imgs, metas = synth_images(8, seed=1234), synth_metas(8)
-        pick = [0, 1, 7]
+        pick = [1, 7]
         x = glue.data_preprocess([imgs[b] for b in pick], MEAN, STD, True, 32)
         ref, tr = oracle.predict(x, [metas[b] for b in pick])
         _SHARED['vith_anchor'] = dict(oracle=oracle, model=model, imgs=imgs, metas=metas, pick=pick, ref=ref, tr=tr)
     return _SHARED['vith_anchor']
 
 
-def test_config3_anchor_vith_batch2(dev):
-    """BASELINE.json configs[3] per-GPU slice (rsprompter_anchor, SAM ViT-H; `_base_/rsprompter_anchor.py` defaults are
-    huge): 2 tiles free-running; detections matched to the oracle's, then the LOW-RES MASK LOGITS of the matched
-    instances compared (the anchor path's logits depend on which boxes were detected, hence the matching)."""
-    B = 2
-    sh = _vith_anchor_shared(dev)
-    model, imgs, metas = sh['model'], sh['imgs'][:B], sh['metas'][:B]
-    ref, tr = sh['ref'], sh['tr']                         # oracle run on tiles 0, 1, 7: the first two are this test's
-    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
-    low = model.roi_head._last_mask_trace['mask_preds'].cpu()                # [sum k, 1, 256, 256], image-major
-    assert low.shape[0] == sum(o.pred_instances.labels.shape[0] for o in out)
-    ours0 = ref0 = 0
-    worst = 0.0
-    for b in range(B):
-        pi, r = out[b].pred_instances, ref[b]
+def _check_anchor_tiles(tag, out, low, emb, ks, pairs_of, ref, tr):
+    """images `b` of the free-running step against the oracle's n-th result: detections matched, then the LOW-RES MASK LOGITS of
+    the matched instances, the image embedding and the pasted masks"""
+    ref0 = 0
+    for n, b in pairs_of:
+        pi, r = out[b].pred_instances, ref[n]
         k = r['labels'].shape[0]
         assert pi.labels.shape[0] == k and tuple(pi.masks.shape[1:]) == (1024, 1024)
         pairs = match_detections(pi.bboxes, pi.scores, pi.labels, r['bboxes'], r['scores'], r['labels'])
         ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
-        e_low = _maxerr(low[ours0 + ii], tr['low_res_masks'][ref0 + jj])
+        o0 = sum(ks[:b])
+        r0 = sum(int(ref[m]['labels'].shape[0]) for m in range(n))
+        e_low = _maxerr(low[o0 + ii], tr['low_res_masks'][r0 + jj])
+        e_emb = _maxerr(emb[b], tr['image_embeddings'][n])
         mism = float((pi.masks.cpu()[ii] != r['masks'][jj]).float().mean())
-        print(f'configs[3] anchor ViT-H img {b}: {k} dets, {len(pairs)} matched, low_res_masks err {e_low:.2e} '
-              f'(range {float(tr["low_res_masks"].abs().max()):.1f}), mask pixel mismatch {mism:.2e}')
-        assert e_low < LOGIT_TOL and mism < 1e-3
-        worst = max(worst, e_low)
-        ours0 += pi.labels.shape[0]
-        ref0 += k
-    e_emb = _maxerr(model._last_embeddings, tr['image_embeddings'][:B])
-    print(f'configs[3]: image embedding err {e_emb:.2e}, worst matched mask-logit err {worst:.2e}')
-    assert e_emb < LOGIT_TOL
+        print(f'{tag} img {b}: {k} dets, {len(pairs)} matched, low_res_masks err {e_low:.2e} '
+              f'(range {float(tr["low_res_masks"].abs().max()):.1f}), embedding err {e_emb:.2e}, mask pixel mismatch {mism:.2e}')
+        assert e_low < LOGIT_TOL and e_emb < LOGIT_TOL and mism < 1e-3
+
+
+def test_config3_anchor_vith_batch2(dev):
+    """BASELINE.json configs[3] per-GPU slice (rsprompter_anchor, SAM ViT-H; `_base_/rsprompter_anchor.py` defaults are
+    huge): 2 tiles free-running; tile 1 against the live oracle run -- detections matched to the oracle's, then the LOW-RES
+    MASK LOGITS of the matched instances compared (the anchor path's logits depend on which boxes were detected, hence the
+    matching) --, tile 0 against the committed golden of the same oracle (bench canary)."""
+    B = 2
+    sh = _vith_anchor_shared(dev)
+    model, imgs, metas = sh['model'], sh['imgs'][:B], sh['metas'][:B]
+    imgs_dev = [i.to(dev) for i in imgs]
+    out = model.test_step(dict(inputs=imgs_dev, data_samples=_samples(metas)))
+    low = model.roi_head._last_mask_trace['mask_preds'].cpu()                # [sum k, 1, 256, 256], image-major
+    emb = model._last_embeddings.cpu()
+    ks = [int(o.pred_instances.labels.shape[0]) for o in out]
+    assert low.shape[0] == sum(ks)
+    _check_anchor_tiles('configs[3] anchor ViT-H', out, low, emb, ks, [(0, 1)], sh['ref'], sh['tr'])      # oracle result 0 = tile 1
+    _bench_canary(model, out, imgs_dev, metas, 'huge', 'anchor')
 
 
 def test_config3_anchor_vith_bench_batch8(dev):
     """The bench's own batch (bench.py default: rsprompter_anchor SAM ViT-H, 8 tiles per step, 800 prompt sets through
-    the SAM decoder): images 0, 1 and 7 of the free-running batch-8 step against the oracle run on those three tiles
-    (images are independent; the oracle run -- 3 tiles -- is shared with test_config3_anchor_vith_batch2).  Round 1's ViT-H bench ran on NaN neck rows unnoticed because
-    no test looked at this configuration at this batch."""
+    the SAM decoder): images 1 and 7 of the free-running batch-8 step against the oracle run on those tiles (images are
+    independent; the oracle run is shared with test_config3_anchor_vith_batch2), image 0 against the bench canary's golden.
+    Round 1's ViT-H bench ran on NaN neck rows unnoticed because no test looked at this configuration at this batch."""
     sh = _vith_anchor_shared(dev)
-    B, pick = 8, sh['pick']
     model, imgs, metas = sh['model'], sh['imgs'], sh['metas']
-    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
+    imgs_dev = [i.to(dev) for i in imgs]
+    out = model.test_step(dict(inputs=imgs_dev, data_samples=_samples(metas)))
     low = model.roi_head._last_mask_trace['mask_preds'].cpu()                # [sum k, 1, 256, 256], image-major
     emb = model._last_embeddings.cpu()
     ks = [int(o.pred_instances.labels.shape[0]) for o in out]
     assert low.shape[0] == sum(ks) and bool(torch.isfinite(low).all()) and bool(torch.isfinite(emb).all())
-    ref, tr = sh['ref'], sh['tr']
-    ref0 = 0
-    for n, b in enumerate(pick):
-        pi, r = out[b].pred_instances, ref[n]
-        k = r['labels'].shape[0]
-        assert pi.labels.shape[0] == k
-        pairs = match_detections(pi.bboxes, pi.scores, pi.labels, r['bboxes'], r['scores'], r['labels'])
-        ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
-        o0 = sum(ks[:b])
-        e_low = _maxerr(low[o0 + ii], tr['low_res_masks'][ref0 + jj])
-        e_emb = _maxerr(emb[b], tr['image_embeddings'][n])
-        mism = float((pi.masks.cpu()[ii] != r['masks'][jj]).float().mean())
-        print(f'bench batch (anchor ViT-H, 8 tiles) img {b}: {k} dets, {len(pairs)} matched, low_res_masks err {e_low:.2e}, '
-              f'embedding err {e_emb:.2e}, mask pixel mismatch {mism:.2e}')
-        assert e_low < LOGIT_TOL and e_emb < LOGIT_TOL and mism < 1e-3
-        ref0 += k
+    _check_anchor_tiles('bench batch (anchor ViT-H, 8 tiles)', out, low, emb, ks, list(enumerate(sh['pick'])), sh['ref'], sh['tr'])
+    _bench_canary(model, out, imgs_dev, metas, 'huge', 'anchor')
 
 
 def test_config2_query_vitl_batch16_r1600(dev):
     """BASELINE.json configs[2] at its own batch: 16 tiles x 100 queries = 1600 prompt sets through the two-way decoder
-    in ONE step; images 0 and 15 against the oracle run on those two tiles."""
+    in ONE step on the bench's own fixture (bench.py --model query --arch large --batch 16): image 15 against the oracle run on
+    that tile, image 0 against the bench canary's golden (the WHU-shape metas of this tree: test_config2_query_vitl_nq100_whu)."""
     from oracle import glue
     from oracle.query import QueryOracle
     from rsprompter_amd.default_configs import rsprompter_query
     from rsprompter_amd.synth import synth_images, synth_metas
-    B, pick = 16, [0, 15]
+    B, pick = 16, [15]
     oracle = QueryOracle('large', 1, 100, max_per_image=100)
     model = _build(rsprompter_query('large', 1, (100, 5)), oracle, dev)
-    imgs = synth_images(B, seed=31)
-    metas = synth_metas(B, ori_shape=(512, 512), scale_factor=(2.0, 2.0))
-    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
+    imgs = synth_images(B, seed=1234)
+    metas = synth_metas(B)
+    imgs_dev = [i.to(dev) for i in imgs]
+    out = model.test_step(dict(inputs=imgs_dev, data_samples=_samples(metas)))
+    _bench_canary(model, out, imgs_dev, metas, 'large', 'query')
     cls, lazy = model._last_head_out
     ours = lazy.low_res.detach().float().cpu()                               # [16, 100, 256, 256]
     assert ours.shape[:2] == (B, 100) and bool(torch.isfinite(ours).all())
@@ -339,77 +357,53 @@ def test_config2_query_vitl_batch16_r1600(dev):
 
 
 def test_config1_anchor_vitb_batch8(dev):
-    """BASELINE.json configs[1] at its own batch (rsprompter_anchor SAM ViT-B, 8 x 1024 x 1024 on one GPU): images 0, 4
-    and 7 of the free-running batch-8 step against the oracle -- detections matched, then the LOW-RES MASK LOGITS of the
-    matched instances (north star: <= 1e-3) and the image embedding."""
+    """BASELINE.json configs[1] at its own batch (rsprompter_anchor SAM ViT-B, 8 x 1024 x 1024 on one GPU): images 4 and 7 of
+    the free-running batch-8 step against the live oracle -- detections matched, then the LOW-RES MASK LOGITS of the matched
+    instances (north star: <= 1e-3) and the image embedding --, image 0 against the bench canary's golden."""
     from oracle import glue
     from oracle.anchor import AnchorOracle
     from rsprompter_amd.default_configs import rsprompter_anchor
     from rsprompter_amd.synth import synth_images, synth_metas
-    B, pick = 8, [0, 4, 7]
+    B, pick = 8, [4, 7]
     oracle = AnchorOracle('base', 10)
     model = _build(rsprompter_anchor('base', 10), oracle, dev)
     imgs, metas = synth_images(B, seed=1234), synth_metas(B)
-    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
+    imgs_dev = [i.to(dev) for i in imgs]
+    out = model.test_step(dict(inputs=imgs_dev, data_samples=_samples(metas)))
     low = model.roi_head._last_mask_trace['mask_preds'].cpu()
     emb = model._last_embeddings.cpu()
     ks = [int(o.pred_instances.labels.shape[0]) for o in out]
     assert low.shape[0] == sum(ks) and bool(torch.isfinite(low).all()) and bool(torch.isfinite(emb).all())
+    _bench_canary(model, out, imgs_dev, metas, 'base', 'anchor')
     x = glue.data_preprocess([imgs[b] for b in pick], MEAN, STD, True, 32)
     ref, tr = oracle.predict(x, [metas[b] for b in pick])
-    ref0 = 0
-    for n, b in enumerate(pick):
-        pi, r = out[b].pred_instances, ref[n]
-        k = r['labels'].shape[0]
-        assert pi.labels.shape[0] == k and tuple(pi.masks.shape[1:]) == (1024, 1024)
-        pairs = match_detections(pi.bboxes, pi.scores, pi.labels, r['bboxes'], r['scores'], r['labels'])
-        ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
-        o0 = sum(ks[:b])
-        e_low = _maxerr(low[o0 + ii], tr['low_res_masks'][ref0 + jj])
-        e_emb = _maxerr(emb[b], tr['image_embeddings'][n])
-        mism = float((pi.masks.cpu()[ii] != r['masks'][jj]).float().mean())
-        print(f'configs[1] anchor ViT-B at batch 8, img {b}: {k} dets, {len(pairs)} matched, low_res_masks err {e_low:.2e} '
-              f'(range {float(tr["low_res_masks"].abs().max()):.1f}), embedding err {e_emb:.2e}, mask pixel mismatch {mism:.2e}')
-        assert e_low < LOGIT_TOL and e_emb < LOGIT_TOL and mism < 1e-3
-        ref0 += k
+    _check_anchor_tiles('configs[1] anchor ViT-B at batch 8', out, low, emb, ks, list(enumerate(pick)), ref, tr)
 
 
 def test_config4_query_vith_lora_batch4(dev):
     """BASELINE.json configs[4] at its per-GPU batch (32 tiles over 8 GPUs = 4 per GPU; ViT-H + LoRA, Nq = 100, WHU-shape
-    metas): images 0 and 3 of the free-running batch-4 step against the fp32 oracle on those tiles.  Decisions of the
-    masked decoder may differ from the oracle's only at ties (_flips_are_ties); queries whose masks are identical are held
-    to 1e-3, touched ones to 1e-2 (the oracle's own fp32 forward moves by 1.4e-3 on such queries)."""
-    from oracle import glue
+    metas) on the bench's own fixture (bench.py --model query --arch huge --batch 4 --lora): every output of the batch finite,
+    image 0 against the oracle's answer for that tile (the bench canary's golden: class logits and SAM mask logits of ALL 100
+    queries, the selected query indices, the image embedding).  The live-oracle test of this variant -- with the criterion
+    that decisions of the masked decoder may differ from the oracle's only at ties -- is
+    test_config4_query_vith_lora_nq100_whu; rounds 2-5 ran the 60-s CPU oracle here as well, on two tiles."""
     from oracle.query import QueryOracle
     from rsprompter_amd.default_configs import rsprompter_query_lora
     from rsprompter_amd.synth import synth_images, synth_metas
-    B, pick = 4, [0, 3]
-    oracle = QueryOracle('huge', 1, 100, max_per_image=100, lora=dict(r=16, alpha=32))
+    B = 4
+    oracle = QueryOracle('huge', 1, 100, max_per_image=100, lora=dict(r=16, alpha=32))      # (the key layout the weights load in)
     model = _build(rsprompter_query_lora('huge', 1, (100, 5)), oracle, dev, seed=0)
     imgs = synth_images(B, seed=1234)
     metas = synth_metas(B, ori_shape=(512, 512), scale_factor=(2.0, 2.0))
-    out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=_samples(metas)))
+    imgs_dev = [i.to(dev) for i in imgs]
+    out = model.test_step(dict(inputs=imgs_dev, data_samples=_samples(metas)))
     cls, lazy = model._last_head_out
     ours = lazy.low_res.detach().float().cpu()
-    assert ours.shape[:2] == (B, 100) and bool(torch.isfinite(ours).all())
-    x = glue.data_preprocess([imgs[b] for b in pick], MEAN, STD, True, 32)
-    ref, tr = oracle.predict(x, [metas[b] for b in pick])
-    flips, touched, tie_z = _flips_are_ties(model.panoptic_head._last_trace['attn_masks'], tr, len(pick), pick=pick)
-    per_q = (ours[pick] - tr['mask_pred']).abs().flatten(2).amax(2)
-    e_cls = _maxerr(cls[pick], tr['cls_pred'])
-    e_emb = _maxerr(model._last_embeddings[pick], tr['image_embeddings'])
-    print(f'configs[4] at batch 4, images {pick}: SAM mask logits err {float(per_q.max()):.2e} (untouched queries '
-          f'{float(per_q[~touched].max()):.2e}), class logits {e_cls:.2e}, embedding {e_emb:.2e}, attention-mask decisions '
-          f'that differ {flips} ({int(touched.sum())} queries, largest oracle |logit| at a first flip {tie_z:.2e})')
-    assert tie_z <= TIE
-    assert float(per_q[~touched].max()) < LOGIT_TOL and e_cls < LOGIT_TOL and e_emb < LOGIT_TOL
-    assert float(per_q.max()) < 1e-2
-    for n, b in enumerate(pick):
-        pi, r = out[b].pred_instances, ref[n]
-        same = pi.query_indices.cpu().long() == r['query_indices']
-        assert int((~same).sum()) <= 4
-        mism = float((pi.masks.cpu()[same] != r['masks'][same]).float().mean())
-        assert mism < 1e-3
+    assert ours.shape[:2] == (B, 100) and bool(torch.isfinite(ours).all()) and bool(torch.isfinite(cls).all())
+    for o in out:
+        assert o.pred_instances.masks.dtype == torch.bool and tuple(o.pred_instances.masks.shape[1:]) == (512, 512)
+    c = _bench_canary(model, out, imgs_dev, metas, 'huge', 'query', lora=True)
+    assert c['class_logit_max_abs_err'] < LOGIT_TOL and c['mask_logit_max_abs_err'] < 1e-2
 
 
 @pytest.mark.parametrize('opts', [dict(decoder_plus=False), dict(with_sincos=False), dict(enforce_decoder_input_project=True),
@@ -419,7 +413,7 @@ def test_query_head_option_branches(dev, opts):
     runs in all 7 stages and its masks drive the attention masks; :315-318 / 346-347 with_sincos=False;
     mask2former_head.py:93-100 enforce_decoder_input_project; num_transformer_feat_level = pixel-decoder num_levels != 3,
     mask2former_head.py:103-135 / models.py:404-409, 438, 457) on the device against the oracle (pinned on the real class
-    run with the same arguments: test_oracle_forwards.py), ViT-B, 2 tiles, Nq = 30."""
+    run with the same arguments: test_oracle_forwards.py), ViT-B, 1 tile (2 until round 6: the CPU oracle), Nq = 30."""
     from oracle.query import QueryOracle
     from rsprompter_amd.default_configs import rsprompter_query
     from rsprompter_amd.synth import synth_images, synth_metas
@@ -436,7 +430,7 @@ def test_query_head_option_branches(dev, opts):
               input_proj=opts.get('enforce_decoder_input_project', False), levels=levels)
     oracle = QueryOracle('base', 1, NQ, max_per_image=20, head_kwargs=hk)
     model = _build(cfg, oracle, dev, seed=5)
-    imgs, metas = synth_images(2, seed=11), synth_metas(2)
+    imgs, metas = synth_images(1, seed=11), synth_metas(1)
     _check_query(model, oracle, imgs, metas, dev, tag)
 
 
@@ -609,7 +603,7 @@ def test_encoder_batch8_row_maps(dev):
     x = torch.randn(8, 3, 1024, 1024, generator=g)
     out = m.to(dev)(x.to(dev))
     emb, hs = out[0].cpu(), [h.cpu() for h in out[1]]
-    for b in (0, 3, 7):
+    for b in (3, 7):
         emb_ref, hs_ref = hf_sam.run_vision_encoder(o, x[b:b + 1])
         e = max(float((h[b:b + 1] - r).abs().max()) for h, r in zip(hs, hs_ref))
         e_emb = float((emb[b:b + 1] - emb_ref).abs().max())

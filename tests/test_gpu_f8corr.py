@@ -61,14 +61,10 @@ def test_anchor_f8corr_end_to_end(dev, monkeypatch):
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         model = ra.build_model(rsprompter_anchor('base', 10))
-    oracle = AnchorOracle('base', 10)
-    sd = synth_state_dict(oracle, seed=0)
-    oracle.load_state_dict(sd)
+    from _oracle_cache import anchor_base_two_tiles              # the oracle run of tests/test_gpu_anchor.py's fixture
+    oracle, sd, imgs, metas, x, ref, tr = anchor_base_two_tiles()
     model.load_state_dict(sd, strict=True)
     model = model.to(dev)
-    imgs, metas = synth_images(2), synth_metas(2)
-    x = glue.data_preprocess(imgs, MEAN, STD, True, 32)
-    ref, tr = oracle.predict(x, metas)
     out = model.test_step(dict(inputs=[i.to(dev) for i in imgs], data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
     assert model.backbone.vision_encoder._packed['f8']
     low = model.roi_head._last_mask_trace['mask_preds'].cpu()

@@ -562,6 +562,17 @@ def test_mask_post_matches_reference_formula(dev):
         got, prob = ops.mask_post(low[:, 0].contiguous().to(dev), (1024, 1024), crop, (h, w), 0.5, want_prob=True)
         assert float((prob.cpu() - ref_prob).abs().max()) < 2e-6
         assert float((got.cpu() != ref_mask).float().mean()) < 1e-5
+    # mask_thr_binary < 0 (models.py:1779-1783, "for visualization and debugging"): uint8 soft masks (p * 255 truncated);
+    # a probability 2e-6 from the oracle's may truncate one count lower / higher where p * 255 is within 5e-4 of an integer
+    from rsprompter_amd.anchor_heads import RSPrompterAnchorMaskHead
+    from rsprompter_amd.structures import InstanceData
+    r = InstanceData()
+    r.bboxes = boxes.clone().to(dev)
+    soft = RSPrompterAnchorMaskHead._predict_by_feat_single(None, low.to(dev), r, meta, dict(mask_thr_binary=-1), rescale=True)
+    ref_soft = (ref_prob * 255).to(torch.uint8)
+    assert soft.dtype == torch.uint8 and soft.shape == ref_soft.shape
+    d = (soft.cpu().int() - ref_soft.int()).abs()
+    assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-4
 
 
 def test_hyper_mask(dev):

@@ -25,12 +25,20 @@ def main():
     ap.add_argument('--multimask', type=int, default=1)
     ap.add_argument('--fused', type=int, default=1, help='0: the kernel chains instead of t2i_fold / upscale_fused')
     ap.add_argument('--rois', type=int, default=7)
+    ap.add_argument('--empty-cache', type=int, default=1)
     a = ap.parse_args()
     from oracle import hf_sam
     from rsprompter_amd.registry import MODELS
     from rsprompter_amd.synth import synth_state_dict
     from test_gpu_baseline_configs import _hf_decoder_stages, _planes_f32
-    dev = torch.device('cuda:0')
+    emu = os.environ.get('RSP_WAVE_EMU') == '1'           # developer check of this script on the CPU emulator (small --hw)
+    if emu:
+        sys.path.insert(0, os.path.join(ROOT, 'tests', 'wave_emu'))
+        import harness
+        ctx = harness.emulated_ops()
+        ctx.__enter__()
+        torch.cuda.empty_cache = lambda: None
+    dev = torch.device('cpu' if emu else 'cuda:0')
     hw, R, B = a.hw, a.rois, 2
     mm = bool(a.multimask)
     head = MODELS.build(dict(type='RSPrompterAnchorMaskHead', mask_decoder=dict(type='RSSamMaskDecoder', hf_pretrain_name='sam_vit_base'),
@@ -67,7 +75,7 @@ def main():
     e, el = torch.empty, torch.empty_like
 
     def fill(t):
-        if pattern[0] is not None and t.numel() and t.is_contiguous() and t.is_cuda:
+        if pattern[0] is not None and t.numel() and t.is_contiguous():
             t.view(torch.uint8).fill_(pattern[0])
         return t
     torch.empty = lambda *aa, **k: fill(e(*aa, **k))
@@ -76,34 +84,53 @@ def main():
     def run():
         low, iou = head(xs, es, ps, ri)
         st = hip._last_stages
-        out = dict(tokens=st['tokens'].cpu(), keys=_planes_f32(st['keys']), masks=low.cpu(), iou=iou.cpu())
+        out = dict(tokens=st['tokens'], keys_hi=st['keys'].hi, keys_lo=st['keys'].lo, masks=low, iou=iou)
         if st['up'] is not None:
-            out['up'] = _planes_f32(st['up'])
+            out['up_hi'], out['up_lo'] = st['up'].hi, st['up'].lo
         for n, h in enumerate(st['hyper']):
-            out[f'hyper{n}'] = h.cpu()
+            out[f'hyper{n}'] = h
         return out
 
-    first, bad = None, 0
+    def to_ref_form(k, dct):
+        if k == 'keys_hi':
+            return _planes_f32(hip._last_stages['keys']), refs['keys']
+        if k == 'up_hi':
+            return _planes_f32(hip._last_stages['up']), refs['up']
+        if k in refs:
+            return dct[k].cpu(), refs[k]
+        return None, None
+
+    pattern[0] = None
+    first = {k: v.clone() for k, v in run().items()}
+    for k in first:
+        got, want = to_ref_form(k, first)
+        if got is not None:
+            print(f'iteration 0: {k} err {float((got - want).abs().max()):.2e}', flush=True)
+    bad = 0
     pats = [0xFF, 0x00, 0x7B, None]
-    for it in range(a.iters):
+    for it in range(1, a.iters):
         pattern[0] = pats[it % 4]
-        if pattern[0] is None:
+        if pattern[0] is None and a.empty_cache:
             torch.cuda.empty_cache()
         out = run()
-        msgs = []
-        for k, v in out.items():
-            nan = int(torch.isnan(v).sum())
-            err = float((v - refs[k]).abs().nan_to_num(1e9).max())
-            moved = 0 if first is None else int((v != first[k]).sum())
-            if nan or err > 1e-3 or moved:
-                msgs.append(f'{k}: err {err:.2e} nan {nan} moved {moved}')
-        if first is None:
-            first = out
-            print('iteration 0:', {k: f'{float((v - refs[k]).abs().max()):.2e}' for k, v in out.items()}, flush=True)
-        if msgs:
-            bad += 1
-            print(f'iteration {it} (pattern {pattern[0]}): ' + '; '.join(msgs), flush=True)
-    print(f'multimask={mm} fused={a.fused} hw={hw} R={R}: {bad} of {a.iters} iterations differ')
+        torch.cuda.synchronize()
+        moved = [k for k, v in out.items() if not torch.equal(v, first[k])]
+        if not moved:
+            continue
+        bad += 1
+        for k in moved:
+            v = out[k]
+            c1, c2 = v.cpu(), v.cpu()                       # two copies: is the DEVICE tensor wrong, or one copy of it?
+            again = torch.equal(v, first[k])                 # ... and a second comparison on the device
+            f = first[k].cpu()
+            d = (c1 != f) | (torch.isnan(c1) != torch.isnan(f))
+            idx = d.nonzero()
+            lo, hi_ = idx.min(0).values.tolist(), idx.max(0).values.tolist()
+            print(f'iteration {it} (pattern {pattern[0]}): {k} shape {tuple(v.shape)} dtype {v.dtype}: {int(d.sum())} values moved, index box '
+                  f'{lo} .. {hi_}; second device comparison equal={again}; two host copies equal={torch.equal(c1, c2)}; '
+                  f'got {c1[d][:6].tolist()} first {f[d][:6].tolist()}; flat offsets {(d.flatten().nonzero().flatten()[:4]).tolist()} '
+                  f'data_ptr {v.data_ptr():#x} nan {int(torch.isnan(c1.float()).sum())}', flush=True)
+    print(f'multimask={mm} fused={a.fused} hw={hw} R={R}: {bad} of {a.iters} iterations differ', flush=True)
 
 
 if __name__ == '__main__':
