@@ -363,6 +363,15 @@ int rsp_batched_nms(const float* boxes, const float* scores, const int32_t* ids,
                     void* workspace, int32_t* keep, int32_t* keep_cnt, float* out_boxes,
                     float* out_scores, int32_t* out_ids, int32_t* out_src, rsp_stream_t stream);
 
+/* Glue of the folded token -> image attention below (round 6: torch index_put / gather before).  expand: tq [R*T, 128]    */
+/* (q_proj output, head h at columns 16 h ..; HF:243-262 "_separate_heads") -> fp16 planes of the block-diagonal matrix      */
+/* [R*96, 128]: row r*96 + h*T + t = scale * tq[r, t, head h] in columns 16 h .. 16 h + 15, zeros elsewhere; rows of the    */
+/* columns >= 8 T zero.  gather: full [R*96, 128] -> ao [R*T, 128], ao[r*T + t, 16 h + d] = full[r*96 + h*T + t, 16 h + d]    */
+/* (HF:264-268 "_recombine_heads" of the columns' own heads).  8 T <= 96.                                                   */
+int rsp_sam_fold_expand(const float* tq, uint16_t* out_hi, uint16_t* out_lo, int32_t out_scale_log2, int32_t R, int32_t T,
+                        float scale, rsp_stream_t stream);
+int rsp_sam_fold_gather(const float* full, float* ao, int32_t R, int32_t T, rsp_stream_t stream);
+
 /* Token -> image attention of the SAM two-way transformer with the K | V projections of the PER-RoI keys folded in   */
 /* (HF:326-331, 397-400; csrc/t2i_fold.hip): keys = fp16 planes of [k_rows >= R*N, 256]; pek = planes of k_proj(pe) +    */
 /* bias [N, 128]; qp = planes of q' [q_rows >= R*96, 256] with q'[r*96 + h*T + t] = Wk_h^T tq[r, t, h] (softmax scale     */

@@ -143,6 +143,8 @@ PROTOTYPES = {
                               c_void_p, c_void_p]),
     "rsp_sam_t2i_fold": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                  c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "rsp_sam_fold_expand": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p]),
+    "rsp_sam_fold_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "rsp_sam_upscale_fused": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                       c_float, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                       c_void_p]),

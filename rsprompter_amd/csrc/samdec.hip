@@ -286,3 +286,65 @@ extern "C" int rsp_paste_masks(const float* logits, const int32_t* labels, const
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Host-glue kernels of the folded token -> image attention (sam_decoder.py::_t2i_folded, csrc/t2i_fold.hip).  Round 5 built
+// the block-diagonal query with torch (mul, permute, zeros, index_put, split: 6 launches) and picked every column's own head
+// out of the v_proj result with an advanced index + permute (4 launches), twice per decoder call.
+//   expand: tq [R*T, 128] (projected queries, head h at columns 16 h ..) -> fp16 planes of the block-diagonal matrix
+//           [R*96, 128]: row r*96 + h*T + t holds scale * tq[r, t, 16 h .. 16 h + 15] in columns 16 h .., zeros elsewhere;
+//           rows of columns >= 8 T are zero
+//   gather: full [R*96, 128] (v_proj applied to every column) -> ao [R*T, 128] with ao[r*T + t, 16 h + d] = full[r*96 + h*T + t, 16 h + d]
+namespace {
+__global__ __launch_bounds__(256) void sam_fold_expand_kernel(const float* __restrict__ tq, half_t* __restrict__ hi, half_t* __restrict__ lo,
+                                                                int64_t rows, int T, float scale, float pscale) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // one thread = 4 consecutive columns of one output row
+  if (i >= rows * 32) return;
+  const int64_t row = i >> 5;
+  const int c = (int)(i & 31) * 4;
+  const int64_t r = row / 96;
+  const int col = (int)(row - r * 96);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (col < 8 * T) {
+    const int h = col / T, t = col - h * T;
+    if ((c >> 4) == h) {
+      v = *reinterpret_cast<const f32x4*>(tq + (r * T + t) * 128 + c);
+      v = v * scale;
+    }
+  }
+  rsp_store_planes4(hi, lo, ((int64_t)(c >> 5) * rows + row) * 32 + (c & 31), v * pscale, false);
+}
+
+__global__ __launch_bounds__(256) void sam_fold_gather_kernel(const float* __restrict__ full, float* __restrict__ ao, int64_t n4, int T) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;        // 4 consecutive columns of one (RoI, token) row
+  if (i >= n4) return;
+  const int64_t row = i >> 5;                                        // r * T + t
+  const int c = (int)(i & 31) * 4;
+  const int64_t r = row / T;
+  const int t = (int)(row - r * T), h = c >> 4;
+  *reinterpret_cast<f32x4*>(ao + row * 128 + c) = *reinterpret_cast<const f32x4*>(full + (r * 96 + h * T + t) * 128 + c);
+}
+}  // namespace
+
+extern "C" int rsp_sam_fold_expand(const float* tq, uint16_t* out_hi, uint16_t* out_lo, int32_t out_scale_log2, int32_t R, int32_t T,
+                                   float scale, rsp_stream_t stream) {
+  if (!tq || !out_hi || !out_lo || R < 0 || T <= 0 || 8 * T > 96 || !RSP_PLANE_WORD_VALID(out_scale_log2) ||
+      RSP_PLANE_IS_F8(out_scale_log2))
+    return RSP_EINVAL;
+  if (R == 0) return RSP_OK;
+  const int64_t rows = (int64_t)R * 96, n = rows * 32;
+  hipLaunchKernelGGL(sam_fold_expand_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tq,
+                     reinterpret_cast<half_t*>(out_hi), reinterpret_cast<half_t*>(out_lo), rows, T, scale,
+                     ldexpf(1.0f, RSP_PLANE_EXP(out_scale_log2)));
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}
+
+extern "C" int rsp_sam_fold_gather(const float* full, float* ao, int32_t R, int32_t T, rsp_stream_t stream) {
+  if (!full || !ao || R < 0 || T <= 0 || 8 * T > 96) return RSP_EINVAL;
+  if (R == 0) return RSP_OK;
+  const int64_t n4 = (int64_t)R * T * 32;
+  hipLaunchKernelGGL(sam_fold_gather_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, full, ao, n4, T);
+  RSP_CHECK_LAUNCH();
+  return RSP_OK;
+}

@@ -6,7 +6,6 @@
 // barrier in the loop, next tile's loads in flight during the current tile's math), and the transposed accumulator
 // (lane = pixel, registers = channels) makes GELU + the hyper-network dot an in-lane reduction.  The [R, 4h, 4w, 32]
 // tensor never exists.  Same fp16x3 arithmetic as gemm_dma.hip.
-#include <stdlib.h>
 #include "rsp_common.h"
 
 namespace {
@@ -23,9 +22,17 @@ struct Up2P {
   int ntiles;
 };
 
-// VAR (round-6 experiment, RSP_UP2_VAR): 0 = as shipped in round 5; 1 = s_nop padding between the channel sums and the
-// cross-half exchange; 2 = sums kept scalar (no SLP packing across sub-pixels); 3 = exchange through v_permlane32_swap (VALU)
-template <int VAR>
+// Round 6 ("the box-dependent multimask answer"): this kernel as shipped in rounds 4-5 produced, about once
+// in 5 ... 1500 launches depending on the box, 16 wrong outputs -- pixels 16..31 of ONE wave tile, ONE sub-pixel, off by about one
+// addend of its 32-channel sum -- but only (a) with several blocks co-resident on a CU (2 waves per SIMD; one block per CU:
+// 0 of 6000 launches) and (b) in the builds whose channel sums hipcc SLP-packed ACROSS sub-pixel pairs (v_mov register
+// shuffles + v_pk_mul_f32 / v_pk_add_f32 with op_sel, 204-244 VGPRs); builds that finish each sub-pixel's sum with scalar
+// adds before the next one starts (156-192 VGPRs): 0 of 7500.  Excluded by experiment: uninitialised HBM / LDS reads (poisoned
+// allocations on the GPU, poisoned LDS on the lane emulator), the copy to the host, the cross-half exchange instruction
+// (ds_bpermute_b32 and v_permlane32_swap both fail), GELU / transcendentals, the bias loads (through LDS: still fails), the
+// MFMA -> accumulator-read distance (32 more wait states: still fails), a write-after-read on MFMA sources
+// (tools/probes/mfma_war_probe.hip: 0 of 10^11).  The mechanism inside the CU is not known; both conditions are removed
+// here: the sums are pinned scalar per sub-pixel, and the grid is one persistent block per CU.
 __global__ __launch_bounds__(256) void sam_upscale2_kernel(const Up2P p) {
   // weight image in LDS: [plane][kb][128 rows][64 B], 16-byte chunks XOR-swizzled with (row >> 2) & 3 (the fragment
   // reads of 32 consecutive rows would otherwise be 4-way bank conflicts, as in gemm_dma.hip)
@@ -96,24 +103,11 @@ __global__ __launch_bounds__(256) void sam_upscale2_kernel(const Up2P p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) sum += t4[e] * hy[g][e];
       }
-      if constexpr (VAR == 2) asm volatile("" : "+v"(sum));
-      if constexpr (VAR == 0 || VAR == 2) sum += __shfl_xor(sum, 32, 64);
+      // pinned: this sub-pixel's sum is complete (scalar adds) before the next sub-pixel's epilogue starts -- no SLP packing of
+      // the four sums across sub-pixels (see the note above the kernel)
+      asm volatile("" : "+v"(sum));
+      sum += __shfl_xor(sum, 32, 64);
       res[j] = sum;
-    }
-    if constexpr (VAR == 1) {
-      asm volatile("s_nop 7\n\ts_nop 7" : "+v"(res[0]), "+v"(res[1]), "+v"(res[2]), "+v"(res[3]));
-#pragma unroll
-      for (int j = 0; j < 4; ++j) res[j] += __shfl_xor(res[j], 32, 64);
-    }
-    if constexpr (VAR == 3) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // v_permlane32_swap: lanes 0-31 of `a` <-> lanes 32-63 of `b`; with a = b = res[j] the first result holds the partner's value
-        const unsigned u = __builtin_bit_cast(unsigned, res[j]);
-        const auto sw = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-        const float other = __builtin_bit_cast(float, hh ? sw[1] : sw[0]);
-        res[j] += other;
-      }
     }
     if (rok) {
       // the half waves split the four stores: hh == 0 writes the dy = 0 row pair, hh == 1 the dy = 1 one
@@ -360,12 +354,8 @@ extern "C" int rsp_sam_upscale2(const uint16_t* a_hi, const uint16_t* a_lo, int6
   if (nt > 0x7fffffffLL) return RSP_EINVAL;
   p.ntiles = (int)nt;
   int64_t blocks = (nt + 3) / 4;
-  if (blocks > 256 * 8) blocks = 256 * 8;          // persistent: up to 8 blocks (32 waves) per CU
-  static const int var = getenv("RSP_UP2_VAR") ? atoi(getenv("RSP_UP2_VAR")) : 0;
-  if (var == 1) hipLaunchKernelGGL(sam_upscale2_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-  else if (var == 2) hipLaunchKernelGGL(sam_upscale2_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-  else if (var == 3) hipLaunchKernelGGL(sam_upscale2_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(sam_upscale2_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+  if (blocks > 256) blocks = 256;                  // persistent, ONE block per CU (round 6: see the note above the kernel; rounds 4-5: up to 8)
+  hipLaunchKernelGGL(sam_upscale2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
   RSP_CHECK_LAUNCH();
   return RSP_OK;
 }

@@ -120,6 +120,9 @@ class ExchangeState:
         self.host = {}
         self.live = None             # weakref to the GatheredResults that still aliases `host` (see GatheredResults._detach)
         self.in_flight = False       # an exchange queued on a side stream whose collect() has not run: it owns `host`
+        # set by a CANCELLED exchange whose headers exceeded the agreed capacities (world > 1): the ranks that collected it
+        # queued a re-send and grew their capacities, this rank did neither -- the next exchange must not issue collectives
+        self.poisoned = None
 
     def fits(self, need):
         return need[0] <= self.img_cap and need[1] <= self.inst_cap and need[2] <= self.byte_cap and need[3] <= 0
@@ -178,7 +181,8 @@ class PendingGather:
     its process group blocked: `cancel()` (also run by `__del__`) waits for the side stream's queued work, so that the
     pinned buffers are no longer written to, and releases the group's state for the next exchange.  Nothing is
     unpacked; if this step's headers did not fit the agreed capacities the re-send that `collect()` would have queued
-    on every rank is skipped on this one -- cancel on all ranks or on none."""
+    on every rank is skipped on this one -- cancel on all ranks or on none.  A cancel that finds such headers (world > 1)
+    marks the group's ExchangeState poisoned: the next gather_results raises instead of issuing mismatched collectives."""
 
     def __init__(self, fn, abandon=None):
         self._fn, self._out, self._abandon = fn, None, abandon
@@ -283,6 +287,8 @@ def gather_results(results_list, dataset_size=None, group=None, stream=None, dst
         if prev is not None:
             prev._detach()
         state.live = None
+    if state.poisoned:
+        raise RuntimeError('gather_results: ' + state.poisoned)
     if state.in_flight:
         raise RuntimeError('gather_results: the previous exchange of this process group has not been collected '
                            '(its pinned host buffers would be overwritten); call collect() first')
@@ -414,9 +420,18 @@ def gather_results(results_list, dataset_size=None, group=None, stream=None, dst
     def abandon():
         nonlocal inflight
         try:
-            ev = inflight[2]
+            headers, _, ev = inflight
             if ev is not None:
                 ev.synchronize()
+            # the headers are read even though nothing is unpacked: every rank that collects this step compares them with
+            # the capacities and, if they do not fit, queues a second round of collectives and grows -- a rank that only
+            # cancelled would issue mismatched collectives at its next exchange (hang or corruption)
+            if world > 1:
+                need = [int(v) for v in headers.cpu().numpy().max(0)]
+                if not state.fits(need):
+                    state.poisoned = ('a cancelled exchange of this process group needed capacities ' + str(need) +
+                                      ' above the agreed ones: the other ranks re-sent and grew, this rank did not -- '
+                                      'destroy the group / call release_state(group) on every rank')
         finally:
             state.in_flight = False
 

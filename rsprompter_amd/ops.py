@@ -830,6 +830,31 @@ def sam_t2i_fold(keys, pek, qp, tqx, *, R, N, ncols):
     return u
 
 
+def sam_fold_expand(tq, R, T, scale):
+    """projected token queries tq [R*T, 128] -> Planes [R*96, 128] of the block-diagonal, pre-scaled query (rsp_sam_fold_expand)"""
+    lib = _lib.load()
+    _chk_f32(tq, 'tq')
+    if not tq.is_contiguous() or tuple(tq.shape) != (R * T, 128):
+        raise ValueError('sam_fold_expand: tq must be a contiguous [R*T, 128] tensor')
+    pl = empty_planes((R * 96, 128), tq.device)
+    _timed('sam_fold_expand_kernel', 0, 4.0 * tq.numel() + 4.0 * R * 96 * 128,
+           lambda: _lib.check(lib.rsp_sam_fold_expand(tq.data_ptr(), pl.hi.data_ptr(), pl.lo.data_ptr(), pl.word, R, T, float(scale),
+                                                      _stream()), 'rsp_sam_fold_expand'))
+    return pl
+
+
+def sam_fold_gather(full, R, T):
+    """full [R*96, 128] (v_proj applied to every column of the folded attention's result) -> [R*T, 128]: every column's own head"""
+    lib = _lib.load()
+    _chk_f32(full, 'full')
+    if not full.is_contiguous() or tuple(full.shape) != (R * 96, 128):
+        raise ValueError('sam_fold_gather: full must be a contiguous [R*96, 128] tensor')
+    ao = torch.empty((R * T, 128), dtype=torch.float32, device=full.device)
+    _timed('sam_fold_gather_kernel', 0, 8.0 * ao.numel(),
+           lambda: _lib.check(lib.rsp_sam_fold_gather(full.data_ptr(), ao.data_ptr(), R, T, _stream()), 'rsp_sam_fold_gather'))
+    return ao
+
+
 def sam_i2t_attention(q, k, v, *, R, T, N, scale, q_map=None, out=None, out_planes=None):
     """SAM decoder image->token attention. q [Rq*N,128], k/v [R*T,128]; result [R*N,128] into `out` and/or Planes."""
     lib = _lib.load()

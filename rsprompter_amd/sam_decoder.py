@@ -180,22 +180,14 @@ class SamMaskDecoderHIP(HIPModule):
         sum_n p[n] keys[n] per (head, token) column, v_proj is applied to that -- HF:326-331 / 397-400 re-associated.
         tq [R*T, 128] projected queries; returns the attention output [R*T, 128] (before out_proj)."""
         P = self._packed
-        d2, dh2 = HID // 2, (HID // 2) // HEADS
-        dev = tq.device
-        key = ('fold_idx', T, str(dev))
-        if key not in self._pe_cache:
-            cols = torch.arange(HEADS * T, device=dev)
-            self._pe_cache[key] = (cols, cols // T)                # column h * T + t belongs to head h
-        cols, head = self._pe_cache[key]
-        tqs = (tq.view(R, T, HEADS, dh2) * dh2 ** -0.5).permute(0, 2, 1, 3).reshape(R, HEADS * T, dh2)
-        exp = torch.zeros((R, 96, HEADS, dh2), dtype=torch.float32, device=dev)
-        exp[:, cols, head] = tqs                                    # block diagonal: own head's 16 columns, zeros elsewhere
-        tqx = ops.to_planes(exp.view(R * 96, d2))
+        dh2 = (HID // 2) // HEADS
+        # block diagonal: column h * T + t carries head h's 16 query values (softmax scale inside), zeros elsewhere -- one
+        # kernel straight into planes (round 5: mul / permute / zeros / index_put / split in torch)
+        tqx = ops.sam_fold_expand(tq, R, T, dh2 ** -0.5)
         qp = ops.gemm(tqx, P[pre + '.k_projT'], bias=None, out_planes=True, out_f32=False)      # [R*96, 256] planes
         u = ops.sam_t2i_fold(keys_pl, pe_t[pre + '.pek_planes'], qp, tqx, R=R, N=N, ncols=HEADS * T)
         full = ops.gemm(u, P[pre + '.v_proj'])                      # [R*96, 128]: every head's Wv on every column
-        ao = full.view(R, 96, HEADS, dh2)[:, cols, head]            # keep the column's own head: [R, 8 T, 16]
-        return ao.view(R, HEADS, T, dh2).permute(0, 2, 1, 3).reshape(R * T, d2).contiguous()
+        return ops.sam_fold_gather(full, R, T)                      # keep the column's own head: [R*T, 128]
 
     def _i2t(self, qi, kt, vt, ai, R, T, N, q_map=None):
         """image -> tokens attention; the result feeds the out_proj GEMM as planes (HF:340-345)."""

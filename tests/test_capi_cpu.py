@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f'{n} declared in include/rsp_hip.h but not exported'
     assert set(_lib.PROTOTYPES) <= set(names)
-    assert lib.rsp_abi_version() == 4
+    assert lib.rsp_abi_version() == 5
     assert b'gfx950' in lib.rsp_build_info()
 
 

@@ -236,3 +236,17 @@ def test_dense_exchange_rejects_heterogeneous_sizes():
     from rsprompter_amd import dist as rdist
     with pytest.raises(ValueError):
         rdist.all_gather_results([_hetero_results(0), _hetero_results(2)], pack_fn=_np_pack)
+
+
+def test_poisoned_exchange_state_raises_instead_of_issuing_collectives():
+    """a rank that CANCELLED an exchange whose headers exceeded the agreed capacities skipped the re-send and the
+    capacity growth its peers performed; PendingGather.cancel() marks the group's state, and the next gather_results on it
+    must raise (mismatched collectives would hang or corrupt) until release_state() / a new group."""
+    from rsprompter_amd import dist as rdist
+    state = rdist.ExchangeState()
+    res = [_hetero_results(0)]
+    assert len(rdist.gather_results(res, codec=NumpyCodec(), state=state)) == 1        # a healthy state works
+    state.poisoned = 'a cancelled exchange of this process group needed capacities [9, 9, 9, 0] above the agreed ones'
+    with pytest.raises(RuntimeError, match='cancelled exchange'):
+        rdist.gather_results(res, codec=NumpyCodec(), state=state)
+    assert len(rdist.gather_results(res, codec=NumpyCodec(), state=rdist.ExchangeState())) == 1   # a fresh state again

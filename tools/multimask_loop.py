@@ -106,7 +106,8 @@ def main():
         got, want = to_ref_form(k, first)
         if got is not None:
             print(f'iteration 0: {k} err {float((got - want).abs().max()):.2e}', flush=True)
-    bad = 0
+    bad = wrong = 0
+    wrong += float((first['masks'].cpu() - refs['masks']).abs().max()) > 1e-3
     pats = [0xFF, 0x00, 0x7B, None]
     for it in range(1, a.iters):
         pattern[0] = pats[it % 4]
@@ -115,9 +116,13 @@ def main():
         out = run()
         torch.cuda.synchronize()
         moved = [k for k, v in out.items() if not torch.equal(v, first[k])]
+        e_ref = float((out['masks'].cpu() - refs['masks']).abs().max())
+        wrong += e_ref > 1e-3                        # against the HF reference: independent of what iteration 0 produced
         if not moved:
             continue
         bad += 1
+        if bad > 12:
+            continue
         for k in moved:
             v = out[k]
             c1, c2 = v.cpu(), v.cpu()                       # two copies: is the DEVICE tensor wrong, or one copy of it?
@@ -130,7 +135,8 @@ def main():
                   f'{lo} .. {hi_}; second device comparison equal={again}; two host copies equal={torch.equal(c1, c2)}; '
                   f'got {c1[d][:6].tolist()} first {f[d][:6].tolist()}; flat offsets {(d.flatten().nonzero().flatten()[:4]).tolist()} '
                   f'data_ptr {v.data_ptr():#x} nan {int(torch.isnan(c1.float()).sum())}', flush=True)
-    print(f'multimask={mm} fused={a.fused} hw={hw} R={R}: {bad} of {a.iters} iterations differ', flush=True)
+    print(f'multimask={mm} fused={a.fused} hw={hw} R={R}: {bad} of {a.iters} iterations differ from the first; '
+          f'{wrong} of {a.iters} off the HF reference by more than 1e-3 (iteration 0 included)', flush=True)
 
 
 if __name__ == '__main__':
