@@ -25,6 +25,36 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define RSP_WAVE_LOCKSTEP() __builtin_amdgcn_wave_barrier()
 #endif
 
+// A 16-byte global load the COMPILER does not know to be a load (inline assembly): no automatic s_waitcnt for it, no drain of
+// the outstanding operations at loop heads -- the kernel orders it with its own counted s_waitcnt (csrc/upscale.hip).  `dst` is
+// any 16-byte register vector, `ptr` a generic / global pointer.  The lane emulator replaces it by a plain load + a place in
+// its vmcnt order (tests/wave_emu/emu_hip.h).
+#ifndef RSP_GLOBAL_LOAD_B128
+#define RSP_GLOBAL_LOAD_B128(dst, ptr) \
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"((const __attribute__((address_space(1))) void*)(ptr)) : "memory")
+#endif
+
+// The LDS-DMA twin: 16 bytes per lane from `gptr` (per lane) to LDS at `lds` (an address_space(3) pointer, WAVE-UNIFORM; lane l lands at lds + 16 l),
+// as inline assembly, so that hipcc -- which models the builtin as a write to LDS and protects later ds_reads of anything that
+// may alias with s_waitcnt vmcnt(0) -- leaves the ordering to the kernel's own counted waits.  M0 carries the LDS base (one
+// wait state between the SALU write of M0 and the DMA instruction that reads it: the hazard hipcc pads for its own builtin).
+#ifndef RSP_GLOBAL_LOAD_LDS_B128
+#define RSP_GLOBAL_LOAD_LDS_B128(gptr, lds)                                                                                  \
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"                                                       \
+               :: "v"((const __attribute__((address_space(1))) void*)(gptr)),                                              \
+                  "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds)))                                             \
+               : "memory")
+#endif
+
+// ... and its raw-buffer form (`rsrc` = __amdgpu_buffer_rsrc_t, `voff` per lane, `soff` wave-uniform, bounds-checked by the resource)
+#ifndef RSP_BUFFER_LOAD_LDS_B128
+#define RSP_BUFFER_LOAD_LDS_B128(rsrc, lds, voff, soff)                                                   \
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"                 \
+               :: "v"((int)(voff)), "s"(rsrc), "s"((int)(soff)),                                        \
+                  "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds)))                      \
+               : "memory")
+#endif
+
 #define RSP_CHECK_LAUNCH()                         \
   do {                                             \
     hipError_t e__ = hipGetLastError();            \

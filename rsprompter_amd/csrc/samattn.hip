@@ -1,4 +1,7 @@
-// hipcc-flags: -ffp-contract=fast
+// hipcc-flags: -ffp-contract=fast -fno-slp-vectorize
+// (round 6, profiles/r6_slp_ab/: without hipcc's SLP packing of independent fp32 operations the image -> token block spills less and
+// runs 4.28 instead of 4.92-5.00 ms per ViT-H step, sam_t2i_kernel 0.67 instead of 0.77; every other file of the library is faster or
+// equal WITH it -- upscale.hip 3.46 vs 3.98, t2i_fold.hip 4.43 vs 4.60 -- so the flag is per file, tools/r6_slp_ab.sh)
 // SAM two-way-transformer cross attentions (HF:243-288 SamAttention inside HF:306-348, 396-404), the two shapes
 // that matter in the RSPrompter decoders:
 //   token -> image : T <= 12 prompt tokens attend over the N = h*w image positions   (many keys, few queries)

@@ -117,10 +117,15 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
     constexpr int i = decltype(ic)::value;
     const unsigned so_k = so_k0 + (unsigned)kt * (FKT * 64), so_p = (unsigned)kt * (FKT * 64);
     lptr_f l = (lptr_f)(&smem[buf][0] + (i * FNT + wave * 64) * 16);
-    if constexpr (i < 6) __builtin_amdgcn_raw_ptr_buffer_load_lds(rKh, l, 16, (int)voff_k[i], (int)so_k, 0, 0);
-    else if constexpr (i < 12) __builtin_amdgcn_raw_ptr_buffer_load_lds(rKl, l, 16, (int)voff_k[i - 6], (int)so_k, 0, 0);
-    else if constexpr (i < 15) __builtin_amdgcn_raw_ptr_buffer_load_lds(rPh, l, 16, (int)voff_p[i - 12], (int)so_p, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rPl, l, 16, (int)voff_p[i - 15], (int)so_p, 0, 0);
+    // (RSP_BUFFER_LOAD_LDS_B128 = the DMA as inline assembly, round 6: through the builtin hipcc knows that the instruction
+    // writes LDS and put its own s_waitcnt vmcnt(0) in front of the fragment reads of tile kt -- BEHIND this burst for tile
+    // kt + 1: rounds 4-5 ran this kernel without any overlap of the key stream and the matrix work.  The waits that order
+    // the ring are the loop's own: s_waitcnt vmcnt(0) + s_barrier at the top of a tile.)
+    // (operands through locals: an asm operand inside a generic lambda does not capture by itself)
+    const __amdgpu_buffer_rsrc_t rs = i < 6 ? rKh : (i < 12 ? rKl : (i < 15 ? rPh : rPl));
+    const unsigned vo = i < 12 ? voff_k[i < 12 ? i % 6 : 0] : voff_p[i >= 12 ? (i - 12) % 3 : 0];
+    const unsigned so = i < 12 ? so_k : so_p;
+    RSP_BUFFER_LOAD_LDS_B128(rs, l, vo, so);
   };
   static_for_f<0, FNDMA>([&](auto ic) { issue_slot(ic, 0, 0); });
 

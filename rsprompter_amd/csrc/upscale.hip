@@ -6,6 +6,7 @@
 // barrier in the loop, next tile's loads in flight during the current tile's math), and the transposed accumulator
 // (lane = pixel, registers = channels) makes GELU + the hyper-network dot an in-lane reduction.  The [R, 4h, 4w, 32]
 // tensor never exists.  Same fp16x3 arithmetic as gemm_dma.hip.
+#include <type_traits>
 #include "rsp_common.h"
 
 namespace {
@@ -149,7 +150,12 @@ constexpr int UF_YS = 8;                                    // the normalised ac
 __global__ __launch_bounds__(256) void sam_upscale_fused_kernel(const UpFP p) {
   // W2 image as in sam_upscale2_kernel; W1 ring: 2 x [plane][256 rows][64 B], 16-byte chunks XOR-swizzled with (row >> 2) & 3
   __shared__ __attribute__((aligned(16))) unsigned char sW2[2 * 2 * 128 * 64];
-  __shared__ __attribute__((aligned(1024))) unsigned char sW1[2][2 * 256 * 64];
+  // (two OBJECTS, and a K loop unrolled by two so that every access names its buffer at compile time: with one array
+  // indexed by a run-time `buf`, hipcc -- which knows that an LDS-DMA instruction writes LDS -- put an s_waitcnt vmcnt(0)
+  // between the DMA issue of chunk c + 1 and the fragment reads of chunk c: rounds 4-5 shipped this kernel without any
+  // overlap of the W1 stream and the matrix work, which is what "54 % of the wave cycles at s_waitcnt" in the r5 counters was)
+  __shared__ __attribute__((aligned(1024))) unsigned char sW1a[2 * 256 * 64];
+  __shared__ __attribute__((aligned(1024))) unsigned char sW1b[2 * 256 * 64];
   typedef const __attribute__((address_space(1))) void* gptr_u;
   typedef __attribute__((address_space(3))) void* lptr_u;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -171,62 +177,88 @@ __global__ __launch_bounds__(256) void sam_upscale_fused_kernel(const UpFP p) {
     const int row = u >> 2, c = (u & 3) ^ ((row >> 2) & 3);
     dsrc[i] = (row * 4 + c) * 16;
   }
-  auto issue_chunk = [&](int kc, int buf) {
+  typedef __attribute__((address_space(3))) unsigned char* lds_u8;
+  auto issue_chunk = [&](int kc, lds_u8 dst) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const unsigned char* base = reinterpret_cast<const unsigned char*>(i < 4 ? p.W1hi : p.W1lo) + (int64_t)kc * (256 * 64);
-      __builtin_amdgcn_global_load_lds((gptr_u)(base + dsrc[i]),
-                                       (lptr_u)(&sW1[buf][0] + ((i >> 2) * 1024 + (i & 3) * 256 + wave * 64) * 16), 16, 0, 0);
+      RSP_GLOBAL_LOAD_LDS_B128(base + dsrc[i], dst + ((i >> 2) * 1024 + (i & 3) * 256 + wave * 64) * 16);
     }
   };
-  issue_chunk(0, 0);
-  int cs = 0;                                               // chunks consumed so far: buffer cs & 1, K chunk cs & 7
+  // Pixel rows (the B operand, 1 KB per pixel straight from HBM): a ring of THREE register sets, chunk c + 2 requested while
+  // chunk c is multiplied -- also across the tile boundary, so the next tile's first two chunks fly during this tile's epilogue
+  // (round 6; round 5 requested chunk c + 1 only and started every tile with an exposed HBM round trip: 54 % of the wave
+  // cycles at s_waitcnt / s_barrier, PMC r5).  Order of this wave's vector-memory operations: [x(0)] [W1 chunk 0] [x(1)], then
+  // per K step [W1 chunk c + 1] [x(c + 2)] -- at the top of step c the four youngest are x(c + 1): vmcnt(4) = chunk c's DMA landed.
+  auto tile_row = [&](int t) -> int64_t {
+    const int64_t r = (int64_t)t * 128 + wave * 32 + l31;
+    return r < p.rows ? r : p.rows - 1;                      // (past the end: a valid row, results never stored)
+  };
+  // The loads are RSP_GLOBAL_LOAD_B128 (inline assembly on the device): hipcc does not see them as loads, so it neither waits
+  // for them on its own nor -- what ruled out plain C++ loads -- drains EVERY outstanding operation at the head of a loop whose
+  // back edge they cross.  The s_waitcnt at the top of a K step is therefore the only thing that orders them: a register set
+  // is read two steps after its request (behind two such waits, each leaving only the four youngest operations in flight) and
+  // is never copied while in flight -- the ring has FOUR sets (8 chunks per tile: chunk c always lives in set c & 3).
+  auto load_x = [&](int64_t rowc, int kc, half8_t (&h8)[2], half8_t (&l8)[2]) {
+#pragma unroll
+    for (int s_ = 0; s_ < 2; ++s_) {
+      const int64_t o = ((int64_t)kc * p.x_rows + rowc) * 32 + 16 * s_ + 8 * hh;
+      RSP_GLOBAL_LOAD_B128(h8[s_], p.Xhi + o);
+      RSP_GLOBAL_LOAD_B128(l8[s_], p.Xlo + o);
+    }
+  };
+  half8_t xh[4][2], xl[4][2];
+  {
+    const int64_t r0 = tile_row(blockIdx.x);
+    load_x(r0, 0, xh[0], xl[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    issue_chunk(0, (lds_u8)sW1a);
+    __builtin_amdgcn_sched_barrier(0);
+    load_x(r0, 1, xh[1], xl[1]);
+    __builtin_amdgcn_sched_barrier(0);
+  }
 
   for (int tile = blockIdx.x; tile < p.ntiles; tile += gridDim.x) {
     const int64_t row = (int64_t)tile * 128 + wave * 32 + l31;
     const bool rok = row < p.rows;
     const int64_t rowc = rok ? row : p.rows - 1;
+    const int64_t rown = tile_row(tile + (int)gridDim.x);   // the next tile's rows (clamped: dummy loads behind the last tile)
     f32x16 acc1[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
-    half8_t xh[2], xl[2];
-    auto load_x = [&](int kc, half8_t (&h8)[2], half8_t (&l8)[2]) {
-#pragma unroll
-      for (int s_ = 0; s_ < 2; ++s_) {
-        const int64_t o = ((int64_t)kc * p.x_rows + rowc) * 32 + 16 * s_ + 8 * hh;
-        h8[s_] = *reinterpret_cast<const half8_t*>(p.Xhi + o);
-        l8[s_] = *reinterpret_cast<const half8_t*>(p.Xlo + o);
-      }
-    };
-    load_x(0, xh, xl);
-    for (int kc = 0; kc < 8; ++kc, ++cs) {
-      const int buf = cs & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's part of the chunk (and its pixel rows) have landed
-      __builtin_amdgcn_s_barrier();                         // ... everybody's; the other buffer has been read
+    // one K step: chunk kc (pixel rows: register set kc & 3) is read from `rd` while the DMA of chunk kc + 1 fills `wr` and the
+    // pixel rows of chunk kc + 2 are requested into set (kc + 2) & 3
+    auto k_step = [&](auto kcc, int kc, const unsigned char* rd, lds_u8 wr) {
+      constexpr int cur = decltype(kcc)::value & 3, nxt = (decltype(kcc)::value + 2) & 3;     // kc & 3 == kcc
+      // this wave's part of W1 chunk kc and the pixel rows of chunk kc have landed (the four loads of x(kc + 1) may still fly)
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                         // ... everybody's; `wr` has been read by everybody
       const bool last = (kc == 7) && (tile + (int)gridDim.x >= p.ntiles);
-      if (!last) issue_chunk((kc + 1) & 7, buf ^ 1);
-      half8_t nh[2], nl[2];
-      if (kc < 7) load_x(kc + 1, nh, nl);
-      const unsigned char* w0 = &sW1[buf][0];
+      if (!last) issue_chunk((kc + 1) & 7, wr);
+      __builtin_amdgcn_sched_barrier(0);
+      load_x(kc < 6 ? rowc : rown, (kc + 2) & 7, xh[nxt], xl[nxt]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const int wrow = j * 32 + l31;
 #pragma unroll
         for (int s_ = 0; s_ < 2; ++s_) {
           const int off = (wrow * 4 + ((2 * s_ + hh) ^ ((wrow >> 2) & 3))) * 16;
-          const half8_t wh = *reinterpret_cast<const half8_t*>(w0 + off);
-          const half8_t wl = *reinterpret_cast<const half8_t*>(w0 + 256 * 64 + off);
-          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[s_], acc1[j], 0, 0, 0);
-          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[s_], acc1[j], 0, 0, 0);
-          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[s_], acc1[j], 0, 0, 0);
+          const half8_t wh = *reinterpret_cast<const half8_t*>(rd + off);
+          const half8_t wl = *reinterpret_cast<const half8_t*>(rd + 256 * 64 + off);
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[cur][s_], acc1[j], 0, 0, 0);
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[cur][s_], acc1[j], 0, 0, 0);
+          acc1[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[cur][s_], acc1[j], 0, 0, 0);
         }
       }
-      if (kc < 7) {
-#pragma unroll
-        for (int s_ = 0; s_ < 2; ++s_) { xh[s_] = nh[s_]; xl[s_] = nl[s_]; }
-      }
+    };
+    for (int half = 0; half < 2; ++half) {                  // 2 x 4 steps: the ring positions repeat, nothing is unrolled further
+      k_step(std::integral_constant<int, 0>{}, 4 * half + 0, sW1a, (lds_u8)sW1b);
+      k_step(std::integral_constant<int, 1>{}, 4 * half + 1, sW1b, (lds_u8)sW1a);
+      k_step(std::integral_constant<int, 2>{}, 4 * half + 2, sW1a, (lds_u8)sW1b);
+      k_step(std::integral_constant<int, 3>{}, 4 * half + 3, sW1b, (lds_u8)sW1a);
     }
 
     // ---- per sub-pixel (dy, dx): bias, LayerNorm over its 64 channels, GELU, second ConvTranspose, GELU, hyper dot ----

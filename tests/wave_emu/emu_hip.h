@@ -775,6 +775,14 @@ inline void vmem_store_marker() {
   w.dmaq.push_back(op);
 }
 }  // namespace emu
+// loads that a kernel issues as inline assembly and counts in its own `s_waitcnt vmcnt(n)` (csrc/rsp_common.h
+// RSP_GLOBAL_LOAD_B128): here a plain load (complete at issue, like every register load of the emulator) + a place in the
+// vmcnt order of the lazy-DMA mode, so that the counted waits of such a kernel mean what they mean on the device
+#define RSP_GLOBAL_LOAD_B128(dst, ptr) \
+  do { memcpy(&(dst), (const void*)(ptr), 16); emu::vmem_store_marker(); } while (0)
+// ... and the LDS-DMA twin: the emulated builtin (declared below)
+#define RSP_GLOBAL_LOAD_LDS_B128(gptr, lds) emu_amdgcn_global_load_lds((gptr), (lds), 16, 0, 0)
+#define RSP_BUFFER_LOAD_LDS_B128(rsrc, lds, voff, soff) emu_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lds), 16, (int)(voff), (int)(soff), 0, 0)
 inline void emu_amdgcn_raw_buffer_store_b128(emu_u32x4 v, emu_rsrc r, int voff, int soff, int) {
   emu_buf_write(r, (int64_t)(unsigned)voff + (unsigned)soff, &v, 16);
   emu::vmem_store_marker();
