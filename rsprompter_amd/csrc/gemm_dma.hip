@@ -130,7 +130,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
   const unsigned char* a_src[NAH];  // plain mode: row base (bytes) incl. chunk offset; conv: plane base
   bool a_ok[NAH];
   int a_chunkb[NAH];                // byte offset of the logical chunk inside the K tile
-  int64_t a_pix[NAH];               // conv: batch pixel base
+  int a_pix[NAH];                   // conv: batch pixel base (B * H * W < 2^31: checked by the dispatcher)
   int a_y[NAH], a_x[NAH];
   const int64_t a_plane_d = reinterpret_cast<const unsigned char*>(d.Alo) - reinterpret_cast<const unsigned char*>(d.Ahi);
   const int64_t b_plane_d = reinterpret_cast<const unsigned char*>(d.Blo) - reinterpret_cast<const unsigned char*>(d.Bhi);
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
         const int rem = gm - b * hw;
         const int yo = rem / d.conv_Wo;
         const int xo = rem - yo * d.conv_Wo;
-        a_pix[i] = (int64_t)b * d.conv_H * d.conv_W;
+        a_pix[i] = b * d.conv_H * d.conv_W;
         a_y[i] = yo * d.conv_stride - d.conv_pad;
         a_x[i] = xo * d.conv_stride - d.conv_pad;
       }
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void gemm_f16x3_dma_kernel(const Ge
       } else {
         const int y = a_y[H] + t.ky, x = a_x[H] + t.kx;
         const bool inb = a_ok[H] && (unsigned)y < (unsigned)d.conv_H && (unsigned)x < (unsigned)d.conv_W;
-        src = a_src[H] + koff + (a_pix[H] + (int64_t)y * d.conv_W + x) * ROWB + a_chunkb[H];
+        src = a_src[H] + koff + (int64_t)(a_pix[H] + y * d.conv_W + x) * ROWB + a_chunkb[H];
         src = inb ? src : zero;
       }
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (I * NT + wave * 64) * 16), 16, 0, 0);
@@ -708,6 +708,8 @@ int rsp_gemm_dma_dispatch(const RspGemmDesc& d, hipStream_t s) {
   if (d.ct_W > 0 && d.ct_dy < 0 && (d.N & 127)) return RSP_EINVAL;
   if (d.ct_W > 0 && d.Chi && ((d.N >> (d.ct_dy < 0 ? 2 : 1)) & 31)) return RSP_EINVAL;
   if (d.conv_k != 0 && (d.conv_C % BK) != 0) return RSP_EINVAL;
+  if (d.conv_k != 0 && (long long)d.conv_H * d.conv_W * ((d.M + (long long)d.conv_Ho * d.conv_Wo - 1) / ((long long)d.conv_Ho * d.conv_Wo)) > 0x7fffffffLL)
+    return RSP_EINVAL;   // the implicit-GEMM loader indexes input pixels with 32 bits
   if (d.ln_gamma && (!d.ln_beta || !(d.Chi && d.Clo) || d.C || d.ct_W <= 0 || d.ct_dy >= 0 || d.N != 256 || d.res ||
                      d.c_rowmap || d.hd_out))
     return RSP_EINVAL;

@@ -533,19 +533,25 @@ __global__ __launch_bounds__(F2_THREADS) void sam_i2t_fused_mfma_kernel(const I2
       }
     }
     __syncthreads();
-    // ================= phase B: O^T[g] = Vp^T (channel block `wave`) x P[g]^T for the 8 position groups =================
-    f32x16_t acc[8];
+    // Phases B and C run twice per round, over four position groups each (round 6): with all eight groups' accumulators (128
+    // registers) beside the 40 fragment registers and the residual prefetch the kernel spilled 70 dwords, the Vp fragments
+    // among them -- reloaded from scratch in front of the MFMAs of every round.  Two more block barriers per round buy that back.
+#pragma unroll 1
+    for (int g0 = 0; g0 < 8; g0 += 4) {
+    // ================= phase B: O^T[g] = Vp^T (channel block `wave`) x P[g]^T for four position groups =================
+    f32x16_t acc[4];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int gl = 0; gl < 4; ++gl) {
+      const int g = g0 + gl;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+      for (int e = 0; e < 16; ++e) acc[gl][e] = 0.f;
 #pragma unroll
       for (int s_ = 0; s_ < NKS; ++s_) {
         const half8_t bh = *reinterpret_cast<const half8_t*>(smem + g * REG + (s_ * 2 + 0) * 1024 + lane * 16);
         const half8_t bl = *reinterpret_cast<const half8_t*>(smem + g * REG + (s_ * 2 + 1) * 1024 + lane * 16);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s_], bh, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bl, acc[g], 0, 0, 0);
-        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bh, acc[g], 0, 0, 0);
+        acc[gl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[s_], bh, acc[gl], 0, 0, 0);
+        acc[gl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bl, acc[gl], 0, 0, 0);
+        acc[gl] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[s_], bh, acc[gl], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);                    // one group's fragments in registers at a time
     }
@@ -568,49 +574,52 @@ __global__ __launch_bounds__(F2_THREADS) void sam_i2t_fused_mfma_kernel(const I2
         }
       }
     };
-    res_load(0, 0);
+    res_load(g0, 0);
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      if (g + 1 < 8) res_load(g + 1, (g + 1) & 1);
+    for (int gl = 0; gl < 4; ++gl) {
+      const int g = g0 + gl;
+      if (gl + 1 < 4) res_load(g + 1, (gl + 1) & 1);
       float sm = 0.f;
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const f32x4 bo4 = *reinterpret_cast<const f32x4*>(sBo + ch0 + 8 * a);
         f32x4 rsd;
         if constexpr (RES_F32) {
-          rsd = rf[g & 1][a];
+          rsd = rf[gl & 1][a];
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) rsd[e] = ((float)rh[g & 1][a][e] + (float)rl[g & 1][a][e]) * p.res_inv_scale;
+          for (int e = 0; e < 4; ++e) rsd[e] = ((float)rh[gl & 1][a][e] + (float)rl[gl & 1][a][e]) * p.res_inv_scale;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float y = acc[g][4 * a + e] * unscale + bo4[e] + rsd[e];
-          acc[g][4 * a + e] = y;
+          const float y = acc[gl][4 * a + e] * unscale + bo4[e] + rsd[e];
+          acc[gl][4 * a + e] = y;
           sm += y;
         }
       }
       sm += __shfl_xor(sm, 32, 64);
       if (hh == 0) sSum[(g * 8 + wave) * 32 + l31] = sm;
-      __builtin_amdgcn_sched_barrier(0);                    // (the residual loads of all 8 groups at once would spill)
+      __builtin_amdgcn_sched_barrier(0);                    // (the residual loads of all groups at once would spill)
     }
     __syncthreads();
-    float mean[8];
+    float mean[4];
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int gl = 0; gl < 4; ++gl) {
+      const int g = g0 + gl;
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) t += sSum[(g * 8 + w) * 32 + l31];
-      mean[g] = t * (1.0f / CO);
+      mean[gl] = t * (1.0f / CO);
       float sq = 0.f;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) { const float dl = acc[g][e] - mean[g]; sq += dl * dl; }
+      for (int e = 0; e < 16; ++e) { const float dl = acc[gl][e] - mean[gl]; sq += dl * dl; }
       sq += __shfl_xor(sq, 32, 64);
       if (hh == 0) sSq[(g * 8 + wave) * 32 + l31] = sq;
     }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < 8; ++g) {
+    for (int gl = 0; gl < 4; ++gl) {
+      const int g = g0 + gl;
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) t += sSq[(g * 8 + w) * 32 + l31];
@@ -625,11 +634,12 @@ __global__ __launch_bounds__(F2_THREADS) void sam_i2t_fused_mfma_kernel(const I2
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(sB + ch);
           f32x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (acc[g][4 * a + e] - mean[g]) * rstd * g4[e] + b4[e];
+          for (int e = 0; e < 4; ++e) o[e] = (acc[gl][4 * a + e] - mean[gl]) * rstd * g4[e] + b4[e];
           rsp_store_planes4(p.ohi, p.olo, ((int64_t)wave * p.out_rows + orow) * 32 + (ch & 31), o * p.pscale, false);
         }
       }
     }
+    }   // g0: the two halves of the round
     // (the next round's phase A writes the pieces, phase C the statistics: both behind this round's barriers)
   }
 }

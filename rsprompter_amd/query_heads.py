@@ -510,7 +510,7 @@ class RSMask2FormerHead(_Mask2FormerCore):
         src = ops.sam_mask_embed(mpp.reshape(B * Nq, H0, W0), emb.reshape(B * he * we, -1), roi_img, P['sam_embed'], he, we)
         ident = torch.arange(B * Nq, dtype=torch.int32, device=emb.device)
         masks, _ = self.mask_decoder.mask_decoder.decode(None, image_positional_embeddings, sparse, None, ident,
-                                                         want_iou=False, src_rows=src, hw=(he, we))
+                                                         want_iou=False, src_rows=src, hw=(he, we), src_is_identity=True)
         mask_pred = masks.view(B, Nq, masks.shape[-2], masks.shape[-1])
         trace.update(mask_pred_plus=mpp, sparse_embeddings=sparse)
         return cls, mask_pred, trace

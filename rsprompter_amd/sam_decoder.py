@@ -100,6 +100,8 @@ class SamMaskDecoderHIP(HIPModule):
         # vectors) in `_last_stages` so that a failure names its kernel; pins GBs at R = 800, hence off by default
         self.keep_stages = False
         self._last_stages = None
+        # tests: decode() chunks above this many prompt sets (None: the folded attention's addressing limit, 1023 at 64 x 64)
+        self.max_prompt_sets = None
 
     # ------------------------------------------------------------------ packing
     def _pw(self, name, with_bias=True):
@@ -212,7 +214,40 @@ class SamMaskDecoderHIP(HIPModule):
         return ops.gemm(o, P[pfx + '.out_proj'], res=res)
 
     def decode(self, image_embeddings, image_pe, sparse, dense_vec, roi_img, want_iou=True, src_rows=None, hw=None,
-               multimask_output=False):
+               multimask_output=False, src_is_identity=False):
+        """The SAM mask decoder over R prompt sets (see _decode_chunk for the arguments).  Round 6: more prompt sets than the
+        folded token -> image attention can address (R * N * 512 bytes of key planes < 2^31: 1023 at N = 4096) are decoded in
+        chunks of equal size, each on the product path -- BASELINE configs[2] (16 tiles x 100 queries = 1600 prompt sets) used to
+        fall back to the round-2 kernel chain (K | V projection GEMMs over all per-RoI keys + sam_t2i_kernel) for that reason.
+        src_is_identity: roi_img is arange(R) over `src_rows` (the query variant: one dense-prompted source per prompt set), so a
+        chunk only needs its own rows of `src_rows`."""
+        R = sparse.shape[0]
+        if src_rows is None:
+            N = image_embeddings.shape[-2] * image_embeddings.shape[-1]
+        else:
+            N = hw[0] * hw[1]
+        max_r = self.max_prompt_sets or max(1, (2 ** 31 - 1) // (N * 512))
+        if R <= max_r or not self.t2i_fold:
+            return self._decode_chunk(image_embeddings, image_pe, sparse, dense_vec, roi_img, want_iou, src_rows, hw,
+                                      multimask_output)
+        n_chunks = -(-R // max_r)
+        per = -(-R // n_chunks)
+        masks, ious = [], []
+        for r0 in range(0, R, per):
+            r1 = min(R, r0 + per)
+            if src_rows is not None and src_is_identity:
+                src_c = src_rows[r0 * N:r1 * N]
+                map_c = roi_img[:r1 - r0]                     # arange(r1 - r0)
+            else:
+                src_c, map_c = src_rows, roi_img[r0:r1]
+            m, i = self._decode_chunk(image_embeddings, image_pe, sparse[r0:r1], dense_vec, map_c, want_iou, src_c, hw,
+                                      multimask_output)
+            masks.append(m)
+            ious.append(i)
+        return torch.cat(masks, 0), (torch.cat(ious, 0) if want_iou else None)
+
+    def _decode_chunk(self, image_embeddings, image_pe, sparse, dense_vec, roi_img, want_iou=True, src_rows=None, hw=None,
+                      multimask_output=False):
         """image_embeddings [B,256,h,w] (logical NCHW, channels-last), image_pe [1|B,256,h,w] (input
         independent; batch entry 0 is used), sparse [R, n_pts, 256], dense_vec [256] (the broadcast
         `no_mask_embed`, models.py:1680), roi_img int32 [R] image index of every RoI (sorted).

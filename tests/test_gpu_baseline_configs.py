@@ -544,6 +544,12 @@ def test_anchor_mask_head_with_folded_token_to_image_attention(dev, hw):
     print(f'mask decoder {hw}x{hw}: unfolded vs HF {e0:.2e}, folded vs HF {e1:.2e}, folded vs unfolded {d01:.2e} '
           f'(range {float(ref_m.abs().max()):.1f}); iou {_maxerr(iou1, ref_i.reshape(R, 1)):.2e}')
     assert e0 < LOGIT_TOL and e1 < LOGIT_TOL and _maxerr(iou1, ref_i.reshape(R, 1)) < LOGIT_TOL
+    # more prompt sets than the folded attention addresses in one launch (R * N * 512 >= 2^31: BASELINE configs[2] has 1600)
+    # are decoded in chunks: forced here at 2 per chunk (3 chunks, the last one short) -- bit-identical to the single pass
+    hip.max_prompt_sets = 2
+    low2, iou2 = head(cl(x), cl(emb), cl(ipe), roi_img.to(dev))
+    hip.max_prompt_sets = None
+    assert torch.equal(low2, low1) and torch.equal(iou2, iou1)
 
 
 @pytest.mark.parametrize('hw', [12, 16, 64])

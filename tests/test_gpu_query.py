@@ -151,6 +151,15 @@ def test_query_head_given_oracle_features(setup, dev):
     print('query head: query_feat %.2e cls %.2e mask_pred_plus %.2e sparse %.2e SAM mask logits %.2e (range %.2f)' %
           (e_q, e_cls, e_mpp, e_sp, e_mask, float(tr['mask_pred'].abs().max())))
     assert e_q < 1e-3 and e_cls < 1e-3 and e_mpp < 2e-3 and e_sp < 1e-3 and e_mask < 1e-3
+    # the SAM decoder in chunks of prompt sets (BASELINE configs[2]: 1600 per step, above the folded attention's 1023): every
+    # query has its own dense-prompted source here (src_rows + identity map), forced at 7 per chunk -- bit-identical
+    dec = m.panoptic_head.mask_decoder.mask_decoder
+    dec.max_prompt_sets = 7
+    try:
+        cls2, mask2, _ = m.panoptic_head(feats, None, emb, ipe)
+    finally:
+        dec.max_prompt_sets = None
+    assert torch.equal(mask2, mask_pred) and torch.equal(cls2, cls)
 
 
 def test_fusion_head_given_oracle_logits(setup, dev):
