@@ -124,6 +124,11 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
   constexpr int BUF_BYTES = (TILE_UNITS * 16 + 1023) / 1024 * 1024;   // lanes past the image are masked off the DMA
   constexpr bool LSUM_MFMA = (DH % 32) != 0;          // spare V^T rows exist: row sums through the MFMA (see g_ones16s)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NBUF][BUF_BYTES];
+  // rel_h of every key row for this wave's 32 queries, log2 domain: [wave][key row][query] (round 6).  Rounds 2-5 fetched the
+  // next tile's value from global memory inside the tile loop, "a whole tile ahead of its use" -- but hipcc waits for a load
+  // that crosses the loop's back edge at once, with s_waitcnt vmcnt(0): behind the QK^T products of every tile the wave drained
+  // the DMA burst of the next tile it had issued at the top of the tile.
+  __shared__ float sRelH[NW][64][32];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -179,14 +184,15 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
       drow[i] = row;
     }
   }
+  const rsp_lds_addr_t smem_a = rsp_lds_addr((lptr_t)&smem[0][0]);
   auto issue_tile = [&](int kt, int buf) {
-    unsigned char* lbase = &smem[buf][0];
+    const rsp_lds_addr_t lbase = smem_a + buf * BUF_BYTES;
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
       const bool ok = drow[i] >= 0;
       const unsigned char* src = ok ? dsrc[i] + (int64_t)kt * (KT * 64) : (drow[i] == -2 ? dsrc[i] : zero);
       if ((i + 1) * NT <= TILE_UNITS || i * NT + tid < TILE_UNITS)     // the last instruction may be partly masked
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (i * NT + wave * 64) * 16), 16, 0, 0);
+        RSP_GLOBAL_LOAD_LDS_B128(src, lbase + (i * NT + wave * 64) * 16);      // (inline assembly: csrc/rsp_common.h)
     }
   };
 
@@ -221,13 +227,20 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
       const int kl = 32 * blk + (r & 3) + 8 * (r >> 2) + 4 * hh;
       bw[blk][r] = qv ? rq[S + (kl % S)] * LOG2E_C : 0.f;
     }
-  auto load_bh = [&](int kt, float& b0, float& b1) {    // global: key row(s) of the tile's two 32-key blocks
+  // rel_h of all S key rows -> LDS: the half waves split the rows (hh = 0: rows 0 .. S/2 - 1); read back per tile by both
+  {
+    const int k0 = hh * (S >> 1);
+    for (int k = 0; k < (S >> 1); k += 4) {
+      const f32x4 v = qv ? *reinterpret_cast<const f32x4*>(rq + k0 + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sRelH[wave][k0 + k + e][l31] = v[e] * LOG2E_C;
+    }
+  }
+  auto load_bh = [&](int kt, float& b0, float& b1) {    // key row(s) of the tile's two 32-key blocks (behind the tile's barrier)
     const int kh0 = (kt * KT) / S, kh1 = (kt * KT + 32) / S;
-    b0 = qv ? rq[kh0] * LOG2E_C : 0.f;
-    b1 = (KT / S > 1 && qv) ? rq[kh1] * LOG2E_C : b0;   // S = 32: two key rows per tile
+    b0 = sRelH[wave][kh0][l31];
+    b1 = KT / S > 1 ? sRelH[wave][kh1][l31] : b0;       // S = 32: two key rows per tile
   };
-  float bhn0 = 0.f, bhn1 = 0.f;
-  load_bh(0, bhn0, bhn1);
 
   f32x16 acc_o[DBLK];
 #pragma unroll
@@ -297,8 +310,8 @@ __global__ __launch_bounds__(NW * 64) void attn_stream_kernel(const AttnSP p) {
     float tmax = -INFINITY;
     float k0s[NBLK];
     {
-      const float bh0 = bhn0, bh1 = bhn1;
-      if (kt + 1 < nt) load_bh(kt + 1, bhn0, bhn1);     // a whole tile ahead of its use
+      float bh0, bh1;
+      load_bh(kt, bh0, bh1);
 #pragma unroll
       for (int blk = 0; blk < NBLK; ++blk) {
         float tm = -INFINITY;

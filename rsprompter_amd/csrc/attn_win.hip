@@ -145,22 +145,21 @@ __global__ __launch_bounds__(448) void attn_win_kernel(const AttnWP p, const int
   int bp = (int)(blockIdx.x / (unsigned)nh);
   if (bp >= n_win) return;
 
+  const rsp_lds_addr_t smem_a = rsp_lds_addr((lptr_t)smem);   // wave-uniform LDS address of the block's image (DMA destinations)
   // ---- the one-hot table and the rel-pos tables of this layer: DMA first (oldest in the queue) ----
   {
     const unsigned char* osrc = reinterpret_cast<const unsigned char*>(g_onehot.v);
 #pragma unroll
     for (int i = 0; i < NOH; ++i)
       if ((i + 1) * NT <= OH_UNITS || i * NT + tid < OH_UNITS)
-        __builtin_amdgcn_global_load_lds((gptr_t)(osrc + (size_t)(i * NT + tid) * 16),
-                                         (lptr_t)(smem + OH_OFF + (i * NT + wave * 64) * 16), 16, 0, 0);
+        RSP_GLOBAL_LOAD_LDS_B128(osrc + (size_t)(i * NT + tid) * 16, smem_a + OH_OFF + (i * NT + wave * 64) * 16);
   }
   if constexpr (!REL_IN) {
     const unsigned char* tsrc = reinterpret_cast<const unsigned char*>(p.rel_tab);
 #pragma unroll
     for (int i = 0; i < NTAB; ++i)
       if ((i + 1) * NT <= TAB_UNITS || i * NT + tid < TAB_UNITS)
-        __builtin_amdgcn_global_load_lds((gptr_t)(tsrc + (size_t)(i * NT + tid) * 16),
-                                         (lptr_t)(smem + TAB_OFF + (i * NT + wave * 64) * 16), 16, 0, 0);
+        RSP_GLOBAL_LOAD_LDS_B128(tsrc + (size_t)(i * NT + tid) * 16, smem_a + TAB_OFF + (i * NT + wave * 64) * 16);
   }
 
   // ---- per-thread DMA slots: unit u = i*NT + tid of the tile image [K_hi | K_lo | V_hi | V_lo]; item-independent part ----
@@ -204,14 +203,16 @@ __global__ __launch_bounds__(448) void attn_win_kernel(const AttnWP p, const int
   const int64_t win_delta = (int64_t)bp_step * WT * 64;     // bytes between the K | V rows of consecutive windows of a block
   // tile kt of the current window (ahead = 0) or of the block's next one (ahead = 1) into ring buffer buf
   auto issue_tile = [&](int kt, int buf, int ahead) {
-    unsigned char* lbase = smem + buf * BUF_BYTES;
+    const rsp_lds_addr_t lbase = smem_a + buf * BUF_BYTES;
     const int64_t adv = (int64_t)kt * (KT * 64) + (ahead ? win_delta : 0);
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
       const bool ok = drow[i] >= 0 && kt * KT + drow[i] < WT;
       const unsigned char* src = ok ? dsrc[i] + adv : (drow[i] == -2 ? dsrc[i] : zero);
       if ((i + 1) * NT <= TILE_UNITS || i * NT + tid < TILE_UNITS)     // the last instruction may be partly masked
-        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(lbase + (i * NT + wave * 64) * 16), 16, 0, 0);
+        // (as inline assembly, round 6: hipcc models the builtin as a write to LDS and drained the burst it had just let this
+        // wave issue -- s_waitcnt vmcnt(0) in front of the second tile's fragment reads, four times per window: csrc/rsp_common.h)
+        RSP_GLOBAL_LOAD_LDS_B128(src, lbase + (i * NT + wave * 64) * 16);
     }
   };
   issue_tile(0, 0, 0);

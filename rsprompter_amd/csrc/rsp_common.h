@@ -34,25 +34,29 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
   asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"((const __attribute__((address_space(1))) void*)(ptr)) : "memory")
 #endif
 
-// The LDS-DMA twin: 16 bytes per lane from `gptr` (per lane) to LDS at `lds` (an address_space(3) pointer, WAVE-UNIFORM; lane l lands at lds + 16 l),
-// as inline assembly, so that hipcc -- which models the builtin as a write to LDS and protects later ds_reads of anything that
-// may alias with s_waitcnt vmcnt(0) -- leaves the ordering to the kernel's own counted waits.  M0 carries the LDS base (one
-// wait state between the SALU write of M0 and the DMA instruction that reads it: the hazard hipcc pads for its own builtin).
+// The LDS-DMA twin: 16 bytes per lane from `gptr` (per lane) to LDS, as inline assembly, so that hipcc -- which models the builtin
+// as a write to LDS and protects later ds_reads of anything that may alias with s_waitcnt vmcnt(0) -- leaves the ordering to the
+// kernel's own counted waits.  `lds` = the WAVE-UNIFORM LDS byte address as an integer (rsp_lds_addr() of an address_space(3)
+// pointer, + uniform offsets): lane l lands at lds + 16 l.  M0 carries it (one wait state between the SALU write of M0 and the
+// DMA instruction that reads it: the hazard hipcc pads for its own builtin).
 #ifndef RSP_GLOBAL_LOAD_LDS_B128
-#define RSP_GLOBAL_LOAD_LDS_B128(gptr, lds)                                                                                  \
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"                                                       \
-               :: "v"((const __attribute__((address_space(1))) void*)(gptr)),                                              \
-                  "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds)))                                             \
-               : "memory")
+#define RSP_GLOBAL_LOAD_LDS_B128(gptr, lds)                                                     \
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"                \
+               :: "v"((const __attribute__((address_space(1))) void*)(gptr)), "s"((int)(lds)) : "memory")
 #endif
-
 // ... and its raw-buffer form (`rsrc` = __amdgpu_buffer_rsrc_t, `voff` per lane, `soff` wave-uniform, bounds-checked by the resource)
 #ifndef RSP_BUFFER_LOAD_LDS_B128
-#define RSP_BUFFER_LOAD_LDS_B128(rsrc, lds, voff, soff)                                                   \
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"                 \
-               :: "v"((int)(voff)), "s"(rsrc), "s"((int)(soff)),                                        \
-                  "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lds)))                      \
-               : "memory")
+#define RSP_BUFFER_LOAD_LDS_B128(rsrc, lds, voff, soff)                                          \
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"        \
+               :: "v"((int)(voff)), "s"(rsrc), "s"((int)(soff)), "s"((int)(lds)) : "memory")
+#endif
+// the wave-uniform integer LDS address of an address_space(3) pointer (rsp_lds_addr_t; the emulator keeps pointers: tests/wave_emu/emu_hip.h)
+#ifndef RSP_HAVE_LDS_ADDR
+#define RSP_HAVE_LDS_ADDR 1
+typedef int rsp_lds_addr_t;
+__device__ __forceinline__ rsp_lds_addr_t rsp_lds_addr(const __attribute__((address_space(3))) void* p) {
+  return __builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)p);
+}
 #endif
 
 #define RSP_CHECK_LAUNCH()                         \

@@ -113,10 +113,11 @@ __global__ __launch_bounds__(FNT) void sam_t2i_fold_kernel(const T2iFoldP p) {
     voff_p[i] = (row < FKT && pc < 16) ? (unsigned)(((int64_t)(pc >> 2) * N + row) * 64 + (pc & 3) * 16) : F_OOB;
   }
   const unsigned so_k0 = (unsigned)((int64_t)r * N * 64);  // first key row of the RoI (bytes inside a 32-column block)
+  const rsp_lds_addr_t smem_a = rsp_lds_addr((lptr_f)&smem[0][0]);
   auto issue_slot = [&](auto ic, int kt, int buf) {        // DMA instruction i of tile kt
     constexpr int i = decltype(ic)::value;
     const unsigned so_k = so_k0 + (unsigned)kt * (FKT * 64), so_p = (unsigned)kt * (FKT * 64);
-    lptr_f l = (lptr_f)(&smem[buf][0] + (i * FNT + wave * 64) * 16);
+    const rsp_lds_addr_t l = smem_a + buf * FBUF_BYTES + (i * FNT + wave * 64) * 16;
     // (RSP_BUFFER_LOAD_LDS_B128 = the DMA as inline assembly, round 6: through the builtin hipcc knows that the instruction
     // writes LDS and put its own s_waitcnt vmcnt(0) in front of the fragment reads of tile kt -- BEHIND this burst for tile
     // kt + 1: rounds 4-5 ran this kernel without any overlap of the key stream and the matrix work.  The waits that order

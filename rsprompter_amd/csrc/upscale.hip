@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void sam_upscale_fused_kernel(const UpFP p) {
     dsrc[i] = (row * 4 + c) * 16;
   }
   typedef __attribute__((address_space(3))) unsigned char* lds_u8;
-  auto issue_chunk = [&](int kc, lds_u8 dst) {
+  const rsp_lds_addr_t sW1a_a = rsp_lds_addr((lds_u8)sW1a), sW1b_a = rsp_lds_addr((lds_u8)sW1b);
+  auto issue_chunk = [&](int kc, rsp_lds_addr_t dst) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const unsigned char* base = reinterpret_cast<const unsigned char*>(i < 4 ? p.W1hi : p.W1lo) + (int64_t)kc * (256 * 64);
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void sam_upscale_fused_kernel(const UpFP p) {
     const int64_t r0 = tile_row(blockIdx.x);
     load_x(r0, 0, xh[0], xl[0]);
     __builtin_amdgcn_sched_barrier(0);
-    issue_chunk(0, (lds_u8)sW1a);
+    issue_chunk(0, sW1a_a);
     __builtin_amdgcn_sched_barrier(0);
     load_x(r0, 1, xh[1], xl[1]);
     __builtin_amdgcn_sched_barrier(0);
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256) void sam_upscale_fused_kernel(const UpFP p) {
       for (int e = 0; e < 16; ++e) acc1[j][e] = 0.f;
     // one K step: chunk kc (pixel rows: register set kc & 3) is read from `rd` while the DMA of chunk kc + 1 fills `wr` and the
     // pixel rows of chunk kc + 2 are requested into set (kc + 2) & 3
-    auto k_step = [&](auto kcc, int kc, const unsigned char* rd, lds_u8 wr) {
+    auto k_step = [&](auto kcc, int kc, const unsigned char* rd, rsp_lds_addr_t wr) {
       constexpr int cur = decltype(kcc)::value & 3, nxt = (decltype(kcc)::value + 2) & 3;     // kc & 3 == kcc
       // this wave's part of W1 chunk kc and the pixel rows of chunk kc have landed (the four loads of x(kc + 1) may still fly)
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -255,10 +256,10 @@ __global__ __launch_bounds__(256) void sam_upscale_fused_kernel(const UpFP p) {
       }
     };
     for (int half = 0; half < 2; ++half) {                  // 2 x 4 steps: the ring positions repeat, nothing is unrolled further
-      k_step(std::integral_constant<int, 0>{}, 4 * half + 0, sW1a, (lds_u8)sW1b);
-      k_step(std::integral_constant<int, 1>{}, 4 * half + 1, sW1b, (lds_u8)sW1a);
-      k_step(std::integral_constant<int, 2>{}, 4 * half + 2, sW1a, (lds_u8)sW1b);
-      k_step(std::integral_constant<int, 3>{}, 4 * half + 3, sW1b, (lds_u8)sW1a);
+      k_step(std::integral_constant<int, 0>{}, 4 * half + 0, sW1a, sW1b_a);
+      k_step(std::integral_constant<int, 1>{}, 4 * half + 1, sW1b, sW1a_a);
+      k_step(std::integral_constant<int, 2>{}, 4 * half + 2, sW1a, sW1b_a);
+      k_step(std::integral_constant<int, 3>{}, 4 * half + 3, sW1b, sW1a_a);
     }
 
     // ---- per sub-pixel (dy, dx): bias, LayerNorm over its 64 channels, GELU, second ConvTranspose, GELU, hyper dot ----

@@ -781,6 +781,10 @@ inline void vmem_store_marker() {
 #define RSP_GLOBAL_LOAD_B128(dst, ptr) \
   do { memcpy(&(dst), (const void*)(ptr), 16); emu::vmem_store_marker(); } while (0)
 // ... and the LDS-DMA twin: the emulated builtin (declared below)
+// (the LDS "address" stays a byte pointer here: rsp_lds_addr_t / rsp_lds_addr)
+#define RSP_HAVE_LDS_ADDR 1
+typedef unsigned char* rsp_lds_addr_t;
+template <class P> inline rsp_lds_addr_t rsp_lds_addr(P p) { return (unsigned char*)(uintptr_t)p; }
 #define RSP_GLOBAL_LOAD_LDS_B128(gptr, lds) emu_amdgcn_global_load_lds((gptr), (lds), 16, 0, 0)
 #define RSP_BUFFER_LOAD_LDS_B128(rsrc, lds, voff, soff) emu_amdgcn_raw_ptr_buffer_load_lds((rsrc), (lds), 16, (int)(voff), (int)(soff), 0, 0)
 inline void emu_amdgcn_raw_buffer_store_b128(emu_u32x4 v, emu_rsrc r, int voff, int soff, int) {
