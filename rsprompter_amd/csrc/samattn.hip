@@ -557,8 +557,8 @@ __global__ __launch_bounds__(F2_THREADS) void sam_i2t_fused_mfma_kernel(const I2
     }
     // ================= phase C: bias + residual, LayerNorm over the 256 channels (8 waves), planes out =================
     // residual of group g + 1 requested before group g is processed (straight-line code: no branch, counted waits)
-    f32x4 rf[3][4];                                         // (a ring of three: two groups ahead -- round 6; the kernel is latency bound)
-    half4_t rh[3][4], rl[3][4];
+    f32x4 rf[2][4];                                         // (two groups ahead -- a ring of three -- measured: 4.14 vs 4.06 ms, not kept)
+    half4_t rh[2][4], rl[2][4];
     auto res_load = [&](int g, int b) {
       const int pos = min(p_round + g * 32 + l31, N - 1);
       if constexpr (RES_F32) {
@@ -575,21 +575,20 @@ __global__ __launch_bounds__(F2_THREADS) void sam_i2t_fused_mfma_kernel(const I2
       }
     };
     res_load(g0, 0);
-    res_load(g0 + 1, 1);
 #pragma unroll
     for (int gl = 0; gl < 4; ++gl) {
       const int g = g0 + gl;
-      if (gl + 2 < 4) res_load(g + 2, (gl + 2) % 3);
+      if (gl + 1 < 4) res_load(g + 1, (gl + 1) & 1);
       float sm = 0.f;
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         const f32x4 bo4 = *reinterpret_cast<const f32x4*>(sBo + ch0 + 8 * a);
         f32x4 rsd;
         if constexpr (RES_F32) {
-          rsd = rf[gl % 3][a];
+          rsd = rf[gl & 1][a];
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) rsd[e] = ((float)rh[gl % 3][a][e] + (float)rl[gl % 3][a][e]) * p.res_inv_scale;
+          for (int e = 0; e < 4; ++e) rsd[e] = ((float)rh[gl & 1][a][e] + (float)rl[gl & 1][a][e]) * p.res_inv_scale;
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {

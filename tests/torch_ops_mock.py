@@ -519,6 +519,24 @@ def sam_t2i_fold(keys, pek, qp, tqx, *, R, N, ncols):
     return u.reshape(R * 96, 256)
 
 
+def sam_fold_expand(tq, R, T, scale):
+    """tq [R*T, 128] -> block-diagonal [R*96, 128]: row r*96 + h*T + t = scale * tq[r, t, head h] in columns 16 h .. (rsp_sam_fold_expand)"""
+    out = torch.zeros((R, 96, 8, 16), dtype=tq.dtype)
+    t4 = tq.view(R, T, 8, 16) * scale
+    for h in range(8):
+        out[:, h * T:(h + 1) * T, h] = t4[:, :, h]
+    return out.view(R * 96, 128)
+
+
+def sam_fold_gather(full, R, T):
+    """full [R*96, 128] -> [R*T, 128]: column h*T + t's own head (rsp_sam_fold_gather)"""
+    f4 = full.view(R, 96, 8, 16)
+    ao = torch.empty((R, T, 8, 16), dtype=full.dtype)
+    for h in range(8):
+        ao[:, :, h] = f4[:, h * T:(h + 1) * T, h]
+    return ao.reshape(R * T, 128)
+
+
 def sam_upscale_fused(x, w1, bias1, gamma, beta, eps, w2p, bias2, hyper, h, w):
     """ConvT(256 -> 64) + LN2d + GELU + ConvT(64 -> 32) + GELU + <., hyper> (rsp_sam_upscale_fused); w2p's K columns are in
     sam_decoder._upscale2_k_order()"""

@@ -168,7 +168,7 @@ struct State {
   // refilled while another wave still reads it); 1: it writes LDS only when an `s_waitcnt vmcnt(n)` of the wave demands it
   // (the LATEST the hardware may do it: exposes a missing wait in front of the barrier).  Tests run DMA kernels both ways.
   int lazy_dma = 0;
-  int poison_lds = 0;      // 1: every block starts with all of LDS = 0xFF bytes
+  int poison_lds = 0;      // 1: every LAUNCH, 2: every BLOCK starts with all of LDS = 0xFF bytes (2 costs an 8 MB memset per block)
 };
 extern State g;
 #ifdef EMU_IMPLEMENTATION
@@ -305,7 +305,7 @@ void run_launch() {
     for (unsigned by = 0; by < L.grid.y; ++by)
       for (unsigned bx = 0; bx < L.grid.x; ++bx) {
         g.L.block_idx = uint3_emu{bx, by, bz};
-        if (g.poison_lds) poison_lds_now();
+        if (g.poison_lds == 2 || (g.poison_lds == 1 && bx == 0 && by == 0 && bz == 0)) poison_lds_now();
         g.blk = &blk;
         blk.live = T; blk.bar_arrived = 0;
         for (int w = 0; w < nw; ++w) {

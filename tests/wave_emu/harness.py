@@ -82,8 +82,9 @@ def emulated_ops():
             raise ValueError(f'{name}: expected float32')
     ops._stream, ops._chk_f32, ops.require_device, ops._is_device = (lambda: 0), chk, (lambda dev: None), (lambda t: True)
     lib.emu_set_lazy_dma(1 if os.environ.get('RSP_WAVE_EMU_LAZY') == '1' else 0)     # audit mode: see lazy_dma()
-    # audit mode 2 (round 6): every block starts with LDS = 0xFF bytes (NaN): a read of LDS nobody wrote shows up
-    lib.emu_set_poison_lds(1 if os.environ.get('RSP_WAVE_EMU_POISON_LDS', '1') == '1' else 0)
+    # round 6: LDS starts as 0xFF bytes (NaN) -- at every launch by default, at every BLOCK with RSP_WAVE_EMU_POISON_LDS=2 (audit:
+    # an 8 MB memset per block doubles the suite's time): a read of LDS nobody wrote shows up instead of a plausible stale value
+    lib.emu_set_poison_lds(int(os.environ.get('RSP_WAVE_EMU_POISON_LDS', '1')))
     try:
         yield ops
     finally:
