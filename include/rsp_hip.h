@@ -513,6 +513,7 @@ int rsp_preprocess(const void* src, int32_t src_is_u8, float* dst, int32_t H, in
 /* FCNMaskHead._predict_by_feat_single + _do_paste_mask (fcn_mask_head.py:276-480; the mask post-process of the       */
 /* SAMSegMaskRCNN sibling model, models.py:1219-1244): logits [k, Hm, Wm, C] NHWC, labels [k] (NULL / C == 1: class   */
 /* agnostic), boxes [k, 4] in output-image coordinates -> out bool [k, img_h, img_w] (sigmoid, bilinear paste, >= thr). */
+/* thr < 0 (:390-394): out holds the pasted probabilities as uint8, (p * 255) truncated.                               */
 int rsp_paste_masks(const float* logits, const int32_t* labels, const float* boxes, int32_t k, int32_t Hm, int32_t Wm,
                     int32_t C, int32_t img_h, int32_t img_w, float thr, uint8_t* out, rsp_stream_t stream);
 

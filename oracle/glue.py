@@ -140,12 +140,16 @@ def bbox_head_predict_single(roi, cls_score, bbox_pred, img_shape, num_classes, 
 
 # --------------------------------------------------------------------------- RPN
 def rpn_predict_single(cls_score_list, bbox_pred_list, mlvl_priors, img_shape, nms_pre=1000,
-                       max_per_img=1000, iou_thr=0.7, min_bbox_size=0, coder=None):
-    """rpn_head.py:134-304 for one image; cls/bbox lists are [A*1,H,W] / [A*4,H,W]."""
+                       max_per_img=1000, iou_thr=0.7, min_bbox_size=0, coder=None, use_sigmoid_cls=True):
+    """rpn_head.py:134-304 for one image; cls/bbox lists are [A*1,H,W] / [A*4,H,W] (softmax objectness,
+    use_sigmoid_cls=False: [A*2,H,W] as [fg, bg] per anchor, :193-200)."""
     mlvl_bbox, mlvl_prior, mlvl_score, level_ids, mlvl_src = [], [], [], [], []
     for lvl, (cls, reg, priors) in enumerate(zip(cls_score_list, bbox_pred_list, mlvl_priors)):
         reg = reg.permute(1, 2, 0).reshape(-1, 4)
-        scores = cls.permute(1, 2, 0).reshape(-1, 1).sigmoid().squeeze(1)
+        if use_sigmoid_cls:
+            scores = cls.permute(1, 2, 0).reshape(-1, 1).sigmoid().squeeze(1)
+        else:
+            scores = cls.permute(1, 2, 0).reshape(-1, 2).softmax(-1)[:, :-1].squeeze(1)
         src = torch.arange(scores.shape[0])
         if 0 < nms_pre < scores.shape[0]:
             ranked, rank_inds = scores.sort(descending=True, stable=True)

@@ -186,13 +186,20 @@ class QueryHead(nn.Module):
     """RSMask2FormerHead (decoder_plus=True): models.py:274-463."""
 
     def __init__(self, num_classes, num_queries, per_pointset_point=5, feat=128, out=256, decoder_plus=True,
-                 with_sincos=True, input_proj=False, levels=3):
+                 with_sincos=True, input_proj=False, levels=3, multimask_output=False):
         """decoder_plus=False (models.py:303-307, 361-385): no mask-embedding MLP, `no_mask_embed` as the dense prompt, the
         SAM decoder runs in every stage and its masks drive the attention masks; with_sincos=False (models.py:315-318,
         346-347): the point MLP emits the prompts directly; input_proj: `enforce_decoder_input_project=True`
         (mask2former_head.py:93-100: Conv2d 1x1 per level); levels: `num_transformer_feat_level` ==
-        the pixel decoder's `num_levels` (mask2former_head.py:106-107), with `num_outs` = levels memories."""
+        the pixel decoder's `num_levels` (mask2former_head.py:106-107), with `num_outs` = levels memories.
+        multimask_output=True (models.py:369-380): the decoder's three masks per prompt set are folded into the query axis
+        by `mask_pred.reshape(img_bs, -1, h, w)` -> [B, 3 Nq, h, w], mask 3 q + j = mask j of prompt set q; the class
+        predictions stay [B, Nq, .].  Only with decoder_plus=True: without it the folded masks are the attention-mask
+        source and nn.MultiheadAttention rejects their shape (pinned in test_oracle_forwards.py)."""
         super().__init__()
+        if multimask_output and not decoder_plus:
+            raise ValueError('multimask_output=True needs decoder_plus=True (the reference fails in its first decoder layer)')
+        self.multimask_output = bool(multimask_output)
         self.num_classes, self.num_queries, self.npts, self.num_heads = num_classes, num_queries, per_pointset_point, 8
         self.decoder_plus, self.with_sincos = decoder_plus, with_sincos
         self.levels = levels
@@ -241,7 +248,7 @@ class QueryHead(nn.Module):
             masks, _ = self.mask_decoder.mask_decoder(
                 image_embeddings=torch.repeat_interleave(emb, self.num_queries, 0),
                 image_positional_embeddings=torch.repeat_interleave(ipe, self.num_queries, 0),
-                sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense, multimask_output=False)
+                sparse_prompt_embeddings=sparse, dense_prompt_embeddings=dense, multimask_output=self.multimask_output)
             mask_pred = masks.reshape(bs, -1, *masks.shape[-2:])
         attn_src = mask_pred_plus if self.decoder_plus else mask_pred          # models.py:380-385
         attn_mask = F.interpolate(attn_src, attn_size, mode='bilinear', align_corners=False)

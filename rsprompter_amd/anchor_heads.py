@@ -129,27 +129,35 @@ class RPNHead(HIPModule):
         self.prior_generator = TASK_UTILS.build(anchor_generator)
         self.bbox_coder = TASK_UTILS.build(bbox_coder or dict(type='DeltaXYWHBBoxCoder'))
         self.num_base_priors = self.prior_generator.num_base_priors[0]
-        self.use_sigmoid_cls = (loss_cls or {}).get('use_sigmoid', True)
-        if not self.use_sigmoid_cls:
-            raise NotImplementedError('RPN with softmax objectness is not on the RSPrompter path')
-        self.cls_out_channels = 1
+        # anchor_head.py:60-77: the default loss_cls is the sigmoid one, a given loss_cls without the key means softmax;
+        # sigmoid objectness = one channel per anchor, softmax = [fg, bg] per anchor
+        self.use_sigmoid_cls = True if loss_cls is None else bool(loss_cls.get('use_sigmoid', False))
+        self.cls_out_channels = 1 if self.use_sigmoid_cls else 2
         self.test_cfg = test_cfg
-        A = self.num_base_priors
+        A, co = self.num_base_priors, self.cls_out_channels
         add_param(self, 'rpn_conv.weight', (feat_channels, in_channels, 3, 3))
         add_param(self, 'rpn_conv.bias', (feat_channels,))
-        add_param(self, 'rpn_cls.weight', (A, feat_channels, 1, 1))
-        add_param(self, 'rpn_cls.bias', (A,))
+        add_param(self, 'rpn_cls.weight', (A * co, feat_channels, 1, 1))
+        add_param(self, 'rpn_cls.bias', (A * co,))
         add_param(self, 'rpn_reg.weight', (A * 4, feat_channels, 1, 1))
         add_param(self, 'rpn_reg.bias', (A * 4,))
-        self.LD = 32 if A * 5 <= 32 else (A * 5 + 31) // 32 * 32
+        # columns of the packed 1x1 head: [0, A) objectness logit, [A, 5A) deltas, softmax only: [5A, 7A) the raw [fg, bg] scores
+        cols = A * 5 + (0 if self.use_sigmoid_cls else 2 * A)
+        self.LD = (cols + 31) // 32 * 32
 
     def _pack(self):
         A, fc = self.num_base_priors, self.feat_channels
         w = torch.zeros((self.LD, fc), dtype=torch.float32, device=self.rpn_cls.weight.device)
         b = torch.zeros((self.LD,), dtype=torch.float32, device=w.device)
-        w[:A] = self.rpn_cls.weight.detach().reshape(A, fc)
+        wc, bc = self.rpn_cls.weight.detach().reshape(-1, fc), self.rpn_cls.bias.detach()
+        if self.use_sigmoid_cls:
+            w[:A], b[:A] = wc, bc
+        else:
+            # rpn_head.py:193-197 `cls_score.softmax(-1)[:, :-1]` over [fg, bg] (channel a * 2 + k, :186-187) is
+            # sigmoid(fg - bg): the difference is folded into the 1x1 convolution, the selection kernels stay the sigmoid ones
+            w[:A], b[:A] = wc[0::2] - wc[1::2], bc[0::2] - bc[1::2]
+            w[5 * A:7 * A], b[5 * A:7 * A] = wc, bc
         w[A:5 * A] = self.rpn_reg.weight.detach().reshape(4 * A, fc)
-        b[:A] = self.rpn_cls.bias.detach()
         b[A:5 * A] = self.rpn_reg.bias.detach()
         self._packed = dict(conv=ops.PackedWeight(conv3x3_weight(self.rpn_conv.weight.detach()), self.rpn_conv.bias),
                             head=ops.PackedWeight(w, b), selector=None)
@@ -172,7 +180,8 @@ class RPNHead(HIPModule):
         heads, sizes = self._heads(x)
         A = self.num_base_priors
         B = x[0].shape[0]
-        cls = [h.view(B, H, W, self.LD)[..., :A].permute(0, 3, 1, 2) for h, (H, W) in zip(heads, sizes)]
+        c0, c1 = (0, A) if self.use_sigmoid_cls else (5 * A, 7 * A)
+        cls = [h.view(B, H, W, self.LD)[..., c0:c1].permute(0, 3, 1, 2) for h, (H, W) in zip(heads, sizes)]
         reg = [h.view(B, H, W, self.LD)[..., A:5 * A].permute(0, 3, 1, 2) for h, (H, W) in zip(heads, sizes)]
         return cls, reg
 
@@ -647,8 +656,6 @@ class FCNMaskHead(HIPModule):
             img_h = int(np.round(img_h * np.float32(sf_h)))
             img_w = int(np.round(img_w * np.float32(sf_w)))
         thr = rcnn_test_cfg['mask_thr_binary'] if isinstance(rcnn_test_cfg, dict) else rcnn_test_cfg.mask_thr_binary
-        if thr < 0:
-            raise NotImplementedError('mask_thr_binary < 0 (uint8 soft masks) is not used by the RSPrompter configs')
         lg = nhwc_view(mask_preds)
         labels = None if self.class_agnostic else results.labels
         return ops.paste_masks(lg, labels, results.bboxes, (img_h, img_w), float(thr))

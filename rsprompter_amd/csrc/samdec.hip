@@ -261,13 +261,15 @@ __global__ __launch_bounds__(256) void paste_masks_kernel(const float* __restric
       v += prob(yn, xw + 1) * (wx1 * wy0);
       v += prob(yn + 1, xw) * (wx0 * wy1);
       v += prob(yn + 1, xw + 1) * (wx1 * wy1);
-      if (v >= thr) word |= 1u << (8 * e);
+      // thr < 0 (:390-394): the probability itself as (p * 255) truncated to uint8
+      const uint32_t byte = thr >= 0.f ? (uint32_t)(v >= thr) : (uint32_t)(uint8_t)(v * 255.0f);
+      word |= byte << (8 * e);
     }
     uint8_t* o = out + (int64_t)n * img_h * img_w + i * 4;
     if (i * 4 + 3 < (int64_t)img_h * img_w && ((((int64_t)n * img_h * img_w) & 3) == 0)) {
       *reinterpret_cast<uint32_t*>(o) = word;
     } else {
-      for (int e = 0; e < 4 && i * 4 + e < (int64_t)img_h * img_w; ++e) o[e] = (word >> (8 * e)) & 1u;
+      for (int e = 0; e < 4 && i * 4 + e < (int64_t)img_h * img_w; ++e) o[e] = (word >> (8 * e)) & 0xffu;
     }
   }
 }

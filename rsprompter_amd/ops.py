@@ -616,12 +616,13 @@ def preprocess(imgs, mean, std, swap_rb, pad_divisor=1, pad_value=0.0, device=No
 
 
 def paste_masks(logits_nhwc, labels, boxes, img_hw, thr=0.5):
-    """FCNMaskHead mask paste: logits [k, Hm, Wm, C] (NHWC), labels int [k] or None, boxes [k, 4] -> bool [k, H, W]."""
+    """FCNMaskHead mask paste: logits [k, Hm, Wm, C] (NHWC), labels int [k] or None, boxes [k, 4] -> bool [k, H, W];
+    thr < 0: uint8 [k, H, W], the pasted probabilities as (p * 255) truncated (fcn_mask_head.py:390-394)."""
     lib = _lib.load()
     _chk_f32(logits_nhwc, 'logits')
     k, Hm, Wm, C = logits_nhwc.shape
     H, W = int(img_hw[0]), int(img_hw[1])
-    out = torch.empty((k, H, W), dtype=torch.bool, device=logits_nhwc.device)
+    out = torch.empty((k, H, W), dtype=torch.bool if thr >= 0 else torch.uint8, device=logits_nhwc.device)
     if k:
         lab = None if labels is None else labels.to(torch.int32).contiguous()
         _lib.check(lib.rsp_paste_masks(logits_nhwc.contiguous().data_ptr(), _ptr(lab), boxes.contiguous().data_ptr(), k, Hm, Wm,

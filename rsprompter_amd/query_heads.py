@@ -428,10 +428,14 @@ class RSMask2FormerHead(_Mask2FormerCore):
                  transformer_decoder=None, positional_encoding=None, loss_cls=None, loss_mask=None, loss_dice=None,
                  train_cfg=None, test_cfg=None, init_cfg=None, **kwargs):
         super().__init__()
-        if multimask_output:
-            # models.py:380: `mask_pred.reshape(img_bs, -1, h, w)` would fold the three masks into the query axis and the
-            # fusion head then mixes them up with queries -- no defined meaning in the reference
-            raise NotImplementedError('RSMask2FormerHead(multimask_output=True) has no consistent meaning in the reference')
+        if multimask_output and not decoder_plus:
+            # models.py:369-385: `mask_pred.reshape(img_bs, -1, h, w)` folds the three masks into the query axis; without
+            # decoder_plus those [B, 3 Nq, h, w] masks are the attention-mask source of Nq queries and the reference fails in
+            # its first decoder layer (nn.MultiheadAttention: "The shape of the 3D attn_mask is ..."; recorded from the real
+            # class in tests/golden/reference_vectors_query_options.pt)
+            raise ValueError('RSMask2FormerHead(multimask_output=True) needs decoder_plus=True: the reference itself fails '
+                             'with the folded masks as its attention mask')
+        self.multimask_output = bool(multimask_output)
         self.per_pointset_point, self.decoder_plus, self.with_sincos = per_pointset_point, bool(decoder_plus), bool(with_sincos)
         self._init_core(in_channels, feat_channels, out_channels, num_things_classes, num_stuff_classes, num_queries,
                         num_transformer_feat_level, pixel_decoder, enforce_decoder_input_project, transformer_decoder,
@@ -474,7 +478,9 @@ class RSMask2FormerHead(_Mask2FormerCore):
         self._packed = P
 
     def forward(self, x, batch_data_samples=None, image_embeddings=None, image_positional_embeddings=None):
-        """models.py:395-463 (inference schedule).  Returns (cls [B,Nq,nc+1], SAM low-res masks [B,Nq,4h,4w], trace)."""
+        """models.py:395-463 (inference schedule).  Returns (cls [B,Nq,nc+1], SAM low-res masks [B,Nq,4h,4w], trace);
+        multimask_output=True: masks [B, 3 Nq, 4h, 4w], entry 3 q + j = mask token j + 1 of prompt set q (models.py:369-380:
+        the reference's reshape folds the three masks into the query axis; the fusion head then reads mask `query index`)."""
         if self._packed is None:
             self._pack()
         P = self._packed
@@ -510,8 +516,9 @@ class RSMask2FormerHead(_Mask2FormerCore):
         src = ops.sam_mask_embed(mpp.reshape(B * Nq, H0, W0), emb.reshape(B * he * we, -1), roi_img, P['sam_embed'], he, we)
         ident = torch.arange(B * Nq, dtype=torch.int32, device=emb.device)
         masks, _ = self.mask_decoder.mask_decoder.decode(None, image_positional_embeddings, sparse, None, ident,
-                                                         want_iou=False, src_rows=src, hw=(he, we), src_is_identity=True)
-        mask_pred = masks.view(B, Nq, masks.shape[-2], masks.shape[-1])
+                                                         want_iou=False, src_rows=src, hw=(he, we), src_is_identity=True,
+                                                         multimask_output=self.multimask_output)
+        mask_pred = masks.view(B, -1, masks.shape[-2], masks.shape[-1])
         trace.update(mask_pred_plus=mpp, sparse_embeddings=sparse)
         return cls, mask_pred, trace
 
@@ -542,7 +549,7 @@ class RSMaskFormerFusionHead(HIPModule):
         if not isinstance(mask_pred_results, LazyUpsampledMasks):
             raise TypeError('expected the LazyUpsampledMasks returned by RSMask2FormerHead.predict')
         low = mask_pred_results.low_res
-        B, Nq = low.shape[:2]
+        B, Nq = mask_cls_results.shape[:2]                  # maskformer_fusion_head.py:143 `num_queries = mask_cls.shape[0]`
         nc = self.num_classes
         k = min(cfg.get('max_per_image', 100), Nq * nc)
         scores, flat = ops.query_topk(mask_cls_results.contiguous(), k)

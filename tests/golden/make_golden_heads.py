@@ -73,6 +73,19 @@ def main():
         cases.append(dict(cls=cls, reg=reg, sizes=sizes, img_shape=(128, 160), nms_pre=nms_pre, max_per_img=max_per_img,
                           min_bbox_size=min_size, iou_thr=0.7, bboxes=r.bboxes, scores=r.scores, labels=r.labels))
     out['rpn_predict_single'] = cases
+    # softmax objectness (anchor_head.py:73-77 use_sigmoid=False -> [fg, bg] per anchor; rpn_head.py:193-200)
+    fake2 = types.SimpleNamespace(bbox_coder=coder, cls_out_channels=2, use_sigmoid_cls=False, test_cfg=None)
+    fake2._bbox_post_process = lambda **kw: rpn.RPNHead._bbox_post_process(fake2, **kw)
+    cases = []
+    for seed, (nms_pre, max_per_img, min_size) in enumerate(((300, 200, 0), (80, 40, 2))):
+        g = torch.Generator().manual_seed(160 + seed)
+        cls = [torch.randn(12, h, w, generator=g) * 2 for h, w in sizes]
+        reg = [torch.randn(24, h, w, generator=g) * 0.5 for h, w in sizes]
+        cfg = Cfg(nms_pre=nms_pre, max_per_img=max_per_img, nms=Cfg(type='nms', iou_threshold=0.7), min_bbox_size=min_size)
+        r = rpn.RPNHead._predict_by_feat_single(fake2, cls, reg, None, priors, dict(img_shape=(128, 160)), cfg, rescale=False)
+        cases.append(dict(cls=cls, reg=reg, sizes=sizes, img_shape=(128, 160), nms_pre=nms_pre, max_per_img=max_per_img,
+                          min_bbox_size=min_size, iou_thr=0.7, bboxes=r.bboxes, scores=r.scores, labels=r.labels))
+    out['rpn_predict_single_softmax'] = cases
 
     # ------------------------------------------------------------------ multiclass_nms
     nmsm = mg._load('mmdet/models/layers/bbox_nms.py', '_ref_bbox_nms')

@@ -5,6 +5,8 @@ builds on) exactly as make_golden_forwards.py does for the shipped configuration
   enforce_decoder_input_project=True                               mask2former_head.py:118-128; models.py:405-406
   with_sincos=False                                                models.py:315-318, 346-347
   decoder_plus=False (one image: :365 expands by img_bs)           models.py:303-307, 361-385
+  multimask_output=True (three masks folded into the query axis)   models.py:369-380; with decoder_plus=False the real class
+                                                                   raises in its first decoder layer: the error is recorded
 Run in the build container:  python tests/golden/make_golden_query_options.py -> tests/golden/reference_vectors_query_options.pt
 Weights and inputs are pure functions of (seed, key, shape); only outputs are stored (strided)."""
 import os
@@ -26,6 +28,7 @@ CASES = dict(
     levels4_proj=(dict(levels=4, input_proj=True), 2),
     no_sincos=(dict(with_sincos=False), 2),
     no_decoder_plus=(dict(decoder_plus=False), 1),
+    multimask=(dict(multimask_output=True), 2),
 )
 
 
@@ -49,6 +52,7 @@ def main():
         ph['enforce_decoder_input_project'] = kw.get('input_proj', False)
         ph['with_sincos'] = kw.get('with_sincos', True)
         ph['decoder_plus'] = kw.get('decoder_plus', True)
+        ph['multimask_output'] = kw.get('multimask_output', False)
         head = mf.seeded(models.RSMask2FormerHead(**ph), 30 + n)
         xs_spec = [(200 + 10 * n + i, (Bq, 256, s, s)) for i, s in enumerate((64, 32, 16, 8, 4))]
         emb_spec, pe_spec = (260 + n, (Bq, 256, 16, 16)), (270 + n, (1, 256, 16, 16))
@@ -67,6 +71,17 @@ def main():
             g['mask_pred_all'] = [m[:, :, ::4, ::4].clone() for m in mask_l]
         out[name] = g
         print(name, len(g['keys']), 'state_dict keys,', len(memories), 'memories, mask_pred', tuple(mask_l[-1].shape))
+    # multimask_output=True with decoder_plus=False: what the real class does (the folded [B, 3 Nq, h, w] masks become the
+    # cross-attention mask of Nq queries)
+    ph['decoder_plus'] = False
+    head = mf.seeded(models.RSMask2FormerHead(**ph), 40)
+    try:
+        head([x[:1] for x in xs], None, emb[:1], pe[:1])
+        raised = None
+    except Exception as e:  # noqa: BLE001
+        raised = dict(type=type(e).__name__, message=str(e)[:200])
+    out['multimask_no_decoder_plus'] = dict(raised=raised)
+    print('multimask_output=True, decoder_plus=False:', raised)
     torch.save(out, OUT)
     print('wrote', OUT, os.path.getsize(OUT) // 1024, 'KiB')
 

@@ -63,8 +63,11 @@ def main():
         fake = types.SimpleNamespace(class_agnostic=False)
         masks = fcn.FCNMaskHead._predict_by_feat_single(fake, logits.clone(), b_in, labels, meta,
                                                        mf.CD(dict(mask_thr_binary=0.5)), rescale=rescale)
+        # :390-394 `threshold < 0`: the pasted probabilities as (p * 255) -> uint8
+        soft = fcn.FCNMaskHead._predict_by_feat_single(fake, logits.clone(), boxes.clone(), labels, meta,
+                                                      mf.CD(dict(mask_thr_binary=-1)), rescale=rescale)
         cases.append(dict(logits=logits, boxes=boxes, labels=labels, meta=meta, rescale=rescale, masks=masks,
-                          boxes_out=b_in))
+                          masks_soft=soft, boxes_out=b_in))
     out['predict_single'] = cases
     g = torch.Generator().manual_seed(9)
     probs = torch.rand(4, 1, 28, 28, generator=g)

@@ -126,6 +126,8 @@ def _check_query(model, oracle, imgs, metas, dev, tag, fp64_floor=False):
     rng = float(tr['mask_pred'].abs().max())
     print(f'{tag}: free-running SAM mask logits err {e_mask:.2e} (range {rng:.1f}), class logits err {e_cls:.2e} vs the fp32 oracle')
     per_q = (ours - tr['mask_pred']).abs().flatten(2).amax(2)                                       # [B, Nq]
+    if per_q.shape[1] != cls.shape[1]:
+        per_q = per_q.view(n_img, cls.shape[1], -1).amax(2)     # multimask_output=True: masks 3 q .. 3 q + 2 belong to prompt set q
     trace = model.panoptic_head._last_trace
     flips, flipped_q, tie_z = _flips_are_ties(trace['attn_masks'], tr, n_img)
     top = per_q.flatten().topk(5).values.tolist()
@@ -407,12 +409,15 @@ def test_config4_query_vith_lora_batch4(dev):
 
 
 @pytest.mark.parametrize('opts', [dict(decoder_plus=False), dict(with_sincos=False), dict(enforce_decoder_input_project=True),
-                                  dict(levels=2), dict(levels=4, enforce_decoder_input_project=True)])
+                                  dict(levels=2), dict(levels=4, enforce_decoder_input_project=True),
+                                  dict(multimask_output=True)])
 def test_query_head_option_branches(dev, opts):
     """RSMask2FormerHead branches no shipped config selects (models.py:303-307 / 361-385 decoder_plus=False: the SAM decoder
     runs in all 7 stages and its masks drive the attention masks; :315-318 / 346-347 with_sincos=False;
     mask2former_head.py:93-100 enforce_decoder_input_project; num_transformer_feat_level = pixel-decoder num_levels != 3,
-    mask2former_head.py:103-135 / models.py:404-409, 438, 457) on the device against the oracle (pinned on the real class
+    mask2former_head.py:103-135 / models.py:404-409, 438, 457; multimask_output=True, models.py:369-380: the three masks of
+    every prompt set folded into the query axis, [B, 3 Nq, h, w], and the fusion head reading mask `query index` of them;
+    with decoder_plus=False the reference itself raises and so does the head) on the device against the oracle (pinned on the real class
     run with the same arguments: test_oracle_forwards.py), ViT-B, 1 tile (2 until round 6: the CPU oracle), Nq = 30."""
     from oracle.query import QueryOracle
     from rsprompter_amd.default_configs import rsprompter_query
@@ -427,11 +432,20 @@ def test_query_head_option_branches(dev, opts):
     ph['pixel_decoder']['encoder']['layer_cfg']['self_attn_cfg']['num_levels'] = levels
     ph['pixel_decoder']['num_outs'] = max(levels, 3)
     hk = dict(decoder_plus=opts.get('decoder_plus', True), with_sincos=opts.get('with_sincos', True),
-              input_proj=opts.get('enforce_decoder_input_project', False), levels=levels)
+              input_proj=opts.get('enforce_decoder_input_project', False), levels=levels,
+              multimask_output=opts.get('multimask_output', False))
     oracle = QueryOracle('base', 1, NQ, max_per_image=20, head_kwargs=hk)
     model = _build(cfg, oracle, dev, seed=5)
     imgs, metas = synth_images(1, seed=11), synth_metas(1)
     _check_query(model, oracle, imgs, metas, dev, tag)
+    if opts.get('multimask_output'):
+        assert tuple(model._last_head_out[1].low_res.shape[:2]) == (1, 3 * NQ)
+        bad = rsprompter_query('base', 1, (NQ, 5), max_per_image=20)
+        bad['panoptic_head'].update(multimask_output=True, decoder_plus=False)
+        import rsprompter_amd as ra
+        with pytest.raises(ValueError), warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            ra.build_model(bad)
 
 
 def _planes_f32(pl):

@@ -167,6 +167,62 @@ def test_box_coder_branches_on_the_real_heads_vectors(dev):
         print(f'coder {name}: RPN {c["labels"].shape[0]} / head detections match the real heads')
 
 
+def test_rpn_softmax_objectness_on_the_real_heads_vectors(dev):
+    """RPNHead(loss_cls.use_sigmoid=False): two scores [fg, bg] per anchor, `softmax(-1)[:, :-1]` (anchor_head.py:73-77,
+    rpn_head.py:193-200) = sigmoid(fg - bg).  The head folds the difference into its packed 1x1 convolution (column a of
+    the head GEMM = W[2a] - W[2a + 1]) and keeps the raw scores for forward(); the selection on the real RPNHead's vectors
+    (tests/golden/make_golden_heads.py, use_sigmoid_cls=False) then runs the sigmoid kernels unchanged."""
+    from rsprompter_amd import ops
+    from rsprompter_amd.anchor_heads import AnchorGenerator, DeltaXYWHBBoxCoder, RPNHead
+    from rsprompter_amd.synth import synth_state_dict
+    ag = dict(type='AnchorGenerator', strides=[4, 8, 16, 32, 64], ratios=[0.5, 1.0, 2.0], scales=[4, 8])
+    m = RPNHead(in_channels=32, feat_channels=32, anchor_generator=ag, loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False),
+                test_cfg=dict(nms_pre=300, max_per_img=200, nms=dict(type='nms', iou_threshold=0.7), min_bbox_size=0))
+    A = m.num_base_priors
+    assert not m.use_sigmoid_cls and m.cls_out_channels == 2 and tuple(m.rpn_cls.weight.shape) == (2 * A, 32, 1, 1) and m.LD == 64
+    assert RPNHead(in_channels=32, feat_channels=32, anchor_generator=ag).use_sigmoid_cls          # the default loss_cls
+    assert not RPNHead(in_channels=32, feat_channels=32, anchor_generator=ag, loss_cls=dict(type='CrossEntropyLoss')).use_sigmoid_cls
+    m.load_state_dict(synth_state_dict(m, seed=5))
+    m = m.to(dev)
+    gq = torch.Generator().manual_seed(91)
+    feats = [torch.randn(2, 32, s, s + 4, generator=gq) for s in (16, 8)]
+    cls, reg = m([f.to(dev).contiguous(memory_format=torch.channels_last) for f in feats])
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    for f, c, r in zip(feats, cls, reg):
+        t = F.relu(F.conv2d(f, sd['rpn_conv.weight'], sd['rpn_conv.bias'], padding=1))
+        want_c = F.conv2d(t, sd['rpn_cls.weight'], sd['rpn_cls.bias'])
+        assert tuple(c.shape) == tuple(want_c.shape) == (2, 2 * A, f.shape[2], f.shape[3])
+        assert _err(c, want_c) < 1e-4 and _err(r, F.conv2d(t, sd['rpn_reg.weight'], sd['rpn_reg.bias'])) < 1e-4
+    heads, _ = m._heads([f.to(dev).contiguous(memory_format=torch.channels_last) for f in feats])
+    for h, c in zip(heads, cls):
+        obj = h.view(2, c.shape[2], c.shape[3], m.LD)[..., :A].permute(0, 3, 1, 2)
+        assert _err(obj, c[:, 0::2].cpu() - c[:, 1::2].cpu()) < 1e-4       # the folded column is fg - bg
+    # ---- selection against the real class
+    g = torch.load(os.path.join(HERE, 'golden', 'reference_vectors_heads.pt'), weights_only=False)
+    base = torch.stack(AnchorGenerator(strides=ag['strides'], ratios=ag['ratios'], scales=ag['scales']).base_anchors, 0)
+    for c in g['rpn_predict_single_softmax']:
+        LD, hs = 32, []
+        for cl, rg in zip(c['cls'], c['reg']):
+            _, H, W = cl.shape
+            h = torch.zeros((H, W, LD))
+            h[..., :A] = (cl[0::2] - cl[1::2]).permute(1, 2, 0)
+            h[..., A:5 * A] = rg.permute(1, 2, 0)
+            hs.append(h.reshape(H * W, LD).to(dev).contiguous())
+        sel = ops.RpnSelector(base, ag['strides'], c['nms_pre'], c['max_per_img'], c['iou_thr'], c['min_bbox_size'],
+                              DeltaXYWHBBoxCoder(), dev)
+        out = sel(hs, c['sizes'], LD, torch.tensor([c['img_shape']], dtype=torch.float32, device=dev))
+        k = int(out['count'][0])
+        assert k == c['scores'].shape[0]
+        gb, gs = out['boxes'][0, :k].cpu(), out['scores'][0, :k].cpu()
+        assert _err(gs, c['scores']) < 1e-6
+        bad = ((gb - c['bboxes']).abs().amax(1) > 2e-3).nonzero()[:, 0].tolist()
+        assert len(bad) <= 4                                   # rows may trade places at (near-)equal scores only
+        for i in bad:
+            d = (c['bboxes'] - gb[i]).abs().amax(1)
+            j = int(d.argmin())
+            assert float(d[j]) < 2e-3 and abs(float(c['scores'][j]) - float(gs[i])) < 1e-6
+
+
 def test_bbox_post_many_classes(dev):
     """multiclass_nms of a many-class head (bbox_nms.py:12-105; 500 RoIs x 80 classes = 40000 (RoI, class) pairs, above the
     16384 candidates the NMS sorts in LDS): ops.bbox_post sizes the NMS by the pairs that pass score_thr and the in-memory

@@ -28,6 +28,13 @@ def test_paste_masks_kernel_matches_reference_vectors(dev):
         mism = float((got.cpu() != c['masks']).float().mean())
         print(f'paste {meta}: mismatch {mism:.2e}')
         assert mism < 1e-4          # pixels whose pasted probability sits within fp32 noise of the threshold
+        # mask_thr_binary < 0 (fcn_mask_head.py:390-394): the probabilities as uint8, against the real file's output
+        soft = ops.paste_masks(c['logits'].permute(0, 2, 3, 1).contiguous().to(dev), c['labels'].to(dev),
+                               c['boxes_out'].to(dev), (h, w), -1.0).cpu()
+        assert soft.dtype == torch.uint8 and soft.shape == c['masks_soft'].shape
+        d = (soft.int() - c['masks_soft'].int()).abs()
+        print(f'soft paste {meta}: {float((d != 0).float().mean()):.2e} of the bytes differ, max {int(d.max())}')
+        assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 2e-3   # p * 255 within fp32 noise of an integer
 
 
 def test_samseg_maskrcnn_end_to_end(dev):

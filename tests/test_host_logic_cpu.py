@@ -245,12 +245,14 @@ def _set_feat_levels(head_cfg, levels):
 
 
 @pytest.mark.parametrize('opts', [dict(decoder_plus=False), dict(with_sincos=False), dict(enforce_decoder_input_project=True),
-                                  dict(levels=2), dict(levels=4, enforce_decoder_input_project=True)])
+                                  dict(levels=2), dict(levels=4, enforce_decoder_input_project=True),
+                                  dict(multimask_output=True)])
 def test_query_head_option_branches_host_logic(mocked, opts):
     """Branches of RSMask2FormerHead that no shipped config selects but the reference implements (VERDICT r3 missing 3):
     decoder_plus=False (models.py:303-307, 361-385: no mask-embedding MLP, the SAM decoder runs in every stage with the
     no-mask dense prompt and ITS masks drive the attention masks), with_sincos=False (models.py:315-318, 346-347) and
-    enforce_decoder_input_project=True (mask2former_head.py:93-100) -- state_dict layout and predict against the oracle."""
+    enforce_decoder_input_project=True (mask2former_head.py:93-100), multimask_output=True (models.py:369-380: [B, 3 Nq, h, w]
+    masks, mask 3 q + j = mask token j + 1 of prompt set q) -- state_dict layout and predict against the oracle."""
     import warnings
     import rsprompter_amd as ra
     from oracle import glue
@@ -268,7 +270,8 @@ def test_query_head_option_branches_host_logic(mocked, opts):
         warnings.simplefilter('ignore')
         model = ra.build_model(cfg)
     hk = dict(decoder_plus=opts.get('decoder_plus', True), with_sincos=opts.get('with_sincos', True),
-              input_proj=opts.get('enforce_decoder_input_project', False), levels=levels)
+              input_proj=opts.get('enforce_decoder_input_project', False), levels=levels,
+              multimask_output=opts.get('multimask_output', False))
     oracle = QueryOracle('base', 1, num_queries=NQ, max_per_image=6, head_kwargs=hk)
     sd = synth_state_dict(oracle, 0)
     oracle.load_state_dict(sd)
@@ -285,6 +288,7 @@ def test_query_head_option_branches_host_logic(mocked, opts):
     out = model.test_step(dict(inputs=imgs, data_samples=[DetDataSample(metainfo=dict(m)) for m in metas]))
     cls, lazy = model._last_head_out
     assert _err(cls, tr['cls_pred']) < 1e-3 and _err(lazy.low_res, tr['mask_pred']) < 2e-3
+    assert lazy.low_res.shape[1] == (3 * NQ if opts.get('multimask_output') else NQ)
     pi, r = out[0].pred_instances, ref[0]
     same = pi.query_indices.long() == r['query_indices']
     assert int((~same).sum()) <= 2

@@ -111,13 +111,20 @@ def test_query_head_matches_real_class(gold):
 
 
 @torch.no_grad()
-@pytest.mark.parametrize('name', ['levels2', 'levels4_proj', 'no_sincos', 'no_decoder_plus'])
+@pytest.mark.parametrize('name', ['levels2', 'levels4_proj', 'no_sincos', 'no_decoder_plus', 'multimask'])
 def test_query_head_option_branches_match_real_class(name):
     """The RSMask2FormerHead branches no shipped config selects (num_transformer_feat_level != 3,
-    enforce_decoder_input_project, with_sincos=False, decoder_plus=False) against the REAL class run with those arguments
-    (tests/golden/make_golden_query_options.py): state_dict layout and every stage's outputs."""
+    enforce_decoder_input_project, with_sincos=False, decoder_plus=False, multimask_output=True: [B, 3 Nq, h, w] masks)
+    against the REAL class run with those arguments (tests/golden/make_golden_query_options.py): state_dict layout and
+    every stage's outputs."""
     from oracle.query import QueryHead
-    g = torch.load(os.path.join(os.path.dirname(GOLD), 'reference_vectors_query_options.pt'), weights_only=False)[name]
+    allg = torch.load(os.path.join(os.path.dirname(GOLD), 'reference_vectors_query_options.pt'), weights_only=False)
+    g = allg[name]
+    if name == 'multimask':
+        # with decoder_plus=False the real class fails in its first decoder layer (the folded masks as attention mask)
+        assert allg['multimask_no_decoder_plus']['raised']['type'] == 'RuntimeError'
+        with pytest.raises(ValueError):
+            QueryHead(g['num_classes'], g['num_queries'], multimask_output=True, decoder_plus=False)
     m = load(QueryHead(g['num_classes'], g['num_queries'], **g['head_kwargs']), g)
     xs = [rnd(s) for s in g['xs']]
     emb = rnd(g['emb'])
@@ -134,7 +141,7 @@ def test_query_head_option_branches_match_real_class(name):
     stage = g.get('mask_pred_plus_all', g.get('mask_pred_all'))     # what each stage cuts its attention mask from
     for a, b in zip(tr['mask_pred_plus_all'], stage):
         assert err(a[:, :, ::4, ::4], b) < 2e-4
-    assert err(mask[:, :, ::2, ::2], g['mask_pred']) < 2e-4
+    assert mask.shape[:2] == g['mask_pred'].shape[:2] and err(mask[:, :, ::2, ::2], g['mask_pred']) < 2e-4
 
 
 @torch.no_grad()

@@ -225,10 +225,12 @@ def test_detection_glue_restatements_match_reference_vectors():
     import os
     from oracle import glue
     d = torch.load(os.path.join(os.path.dirname(__file__), 'golden', 'reference_vectors_heads.pt'))
-    for c in d['rpn_predict_single']:
+    # the second group: softmax objectness ([fg, bg] per anchor, rpn_head.py:193-200) on the real class with use_sigmoid_cls=False
+    for c, sig in [(c, True) for c in d['rpn_predict_single']] + [(c, False) for c in d['rpn_predict_single_softmax']]:
         priors = glue.grid_priors(c['sizes'], [4, 8, 16, 32, 64], [4, 8], [0.5, 1.0, 2.0])
         r = glue.rpn_predict_single(c['cls'], c['reg'], priors, c['img_shape'], nms_pre=c['nms_pre'],
-                                    max_per_img=c['max_per_img'], iou_thr=c['iou_thr'], min_bbox_size=c['min_bbox_size'])
+                                    max_per_img=c['max_per_img'], iou_thr=c['iou_thr'], min_bbox_size=c['min_bbox_size'],
+                                    use_sigmoid_cls=sig)
         assert r['bboxes'].shape == c['bboxes'].shape, (r['bboxes'].shape, c['bboxes'].shape)
         assert torch.equal(r['scores'], c['scores'])
 

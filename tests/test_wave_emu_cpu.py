@@ -127,6 +127,7 @@ SWEEP = [
     ('test_gpu_query', 'test_query_kernels_unit', ()),
     ('test_gpu_samdet', 'test_bbox_post_matches_real_bbox_head_with_and_without_rescale', ()),
     ('test_gpu_samdet', 'test_resnet_leaf_kernels', ()),
+    ('test_gpu_samdet', 'test_rpn_softmax_objectness_on_the_real_heads_vectors', ()),   # [fg, bg] folded into the packed 1x1 head
     ('test_gpu_samdet', 'test_box_prompt_mask_post_and_scale_boxes', ()),     # box prompts' sin / cos, mask_post_logits
     ('test_gpu_apis', 'test_resize_pad_kernel_matches_cv2_restatement', ()),
     ('test_gpu_kernels', 'test_vit_attention', (14, 2, 80, 3)),               # the fp32-fed attention entry points

@@ -502,7 +502,8 @@ def paste_masks(logits_nhwc, labels, boxes, img_hw, thr=0.5):
     if labels is not None and lg.shape[1] > 1:
         lg = lg[range(k), labels.long()][:, None]
     meta = dict(ori_shape=(int(img_hw[0]), int(img_hw[1])), scale_factor=(1.0, 1.0))
-    return samseg.fcn_predict_single(lg, boxes, None, meta, thr, rescale=True, class_agnostic=True)[0]
+    masks, _, probs = samseg.fcn_predict_single(lg, boxes, None, meta, thr, rescale=True, class_agnostic=True)
+    return masks if thr >= 0 else (probs * 255).to(torch.uint8)
 
 
 # ----------------------------------------------------------------------------- the fused decoder forms (product since round 5)
