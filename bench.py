@@ -251,7 +251,7 @@ def parity_canary(model, imgs, metas, arch, kind, lora=False, res=None):
         k0 = int(pi.labels.shape[0])
         pb, ps, pl = pi.bboxes.float().cpu(), pi.scores.float().cpu(), pi.labels.cpu()
         sample = low[:k0, 0, ::16, ::16].float().cpu()
-        used, errs, same_idx = set(), [], 0
+        used, errs, same_idx, rank_same = set(), [], 0, 0
         pc = pi.cand_index.cpu().long() if hasattr(pi, 'cand_index') else None
         for j in range(g['labels'].shape[0]):          # same label, same box (1e-2 px), same score (1e-4): tests/_match.py
             d = (pb - g['bboxes'][j]).abs().amax(1)
@@ -261,14 +261,20 @@ def parity_canary(model, imgs, metas, arch, kind, lora=False, res=None):
             i = int(d.argmin()) if d.numel() else -1
             if i >= 0 and float(d[i]) < 1e-2 and abs(float(ps[i]) - float(g['scores'][j])) < 1e-4:
                 used.add(i)
+                rank_same += int(i == j)
                 errs.append(float((sample[i] - g['low_res_sample'][j]).abs().max()))
         out['detections_matched'] = f'{len(errs)}/{int(g["labels"].shape[0])}'
+        # ... of which at the oracle's own rank (the same box, score and label in the same output row)
+        out['ranks_equal'] = f'{rank_same}/{int(g["labels"].shape[0])}'
         if pc is not None and 'cand' in g:
             # index equality, position by position: detection j of the tile is the oracle's detection j -- the same kept
             # candidate (proposal x class entry of the free-running R-CNN stage) with the same label
             n = min(k0, int(g['cand'].shape[0]))
             same_idx = int(((pc[:n] == g['cand'][:n]) & (pl[:n] == g['labels'][:n])).sum())
             out['indices_equal'] = f'{same_idx}/{int(g["cand"].shape[0])}'
+            diff = (~((pc[:n] == g['cand'][:n]) & (pl[:n] == g['labels'][:n]))).nonzero()[:, 0].tolist()
+            # rows that differ: [row, this run's candidate index, the oracle's] (at most 4 listed)
+            out['indices_unequal_rows'] = [[j, int(pc[j]), int(g['cand'][j])] for j in diff[:4]]
         out['mask_logit_max_abs_err'] = max(errs) if errs else None
         out['mask_logit_range'] = g['low_res_absmax']
         out['tolerance'] = 1e-3

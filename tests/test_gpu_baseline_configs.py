@@ -259,7 +259,7 @@ def _vith_anchor_shared(dev):
         oracle = AnchorOracle('huge', 10)
         model = _build(rsprompter_anchor('huge', 10), oracle, dev)
         imgs, metas = synth_images(8, seed=1234), synth_metas(8)
-        pick = [1, 7]
+        pick = [1]                      # rounds 2-5: [1, 7]; tile 7 is now held against a batch-1 step of the model (25 s of CPU oracle less)
         x = glue.data_preprocess([imgs[b] for b in pick], MEAN, STD, True, 32)
         ref, tr = oracle.predict(x, [metas[b] for b in pick])
         _SHARED['vith_anchor'] = dict(oracle=oracle, model=model, imgs=imgs, metas=metas, pick=pick, ref=ref, tr=tr)
@@ -319,6 +319,20 @@ def test_config3_anchor_vith_bench_batch8(dev):
     assert low.shape[0] == sum(ks) and bool(torch.isfinite(low).all()) and bool(torch.isfinite(emb).all())
     _check_anchor_tiles('bench batch (anchor ViT-H, 8 tiles)', out, low, emb, ks, list(enumerate(sh['pick'])), sh['ref'], sh['tr'])
     _bench_canary(model, out, imgs_dev, metas, 'huge', 'anchor')
+    # the last tile of the batch against the same model stepping on that tile alone: images are independent, so row maps,
+    # batch offsets and the RoI -> image map of the batch-8 step must give the batch-1 answer
+    one = model.test_step(dict(inputs=[imgs_dev[7]], data_samples=_samples([metas[7]])))[0].pred_instances
+    low1 = model.roi_head._last_mask_trace['mask_preds'].cpu()
+    p8 = out[7].pred_instances
+    pairs = match_detections(p8.bboxes, p8.scores, p8.labels, one.bboxes.cpu(), one.scores.cpu(), one.labels.cpu())
+    # (the batch-1 step runs other GEMM kernels -- fewer tiles --, so the two answers agree to rounding, not bit for bit,
+    # and a detection at the score threshold may exist in one of them only)
+    assert len(pairs) >= max(ks[7], int(one.labels.shape[0])) - 2
+    ii = torch.tensor([i for i, _ in pairs]); jj = torch.tensor([j for _, j in pairs])
+    e_low = _maxerr(low[sum(ks[:7]) + ii], low1[jj])
+    mism = float((p8.masks.cpu()[ii] != one.masks.cpu()[jj]).float().mean())
+    print(f'bench batch tile 7 against a batch-1 step: {len(pairs)} of {ks[7]} matched, low_res_masks err {e_low:.2e}, mask mismatch {mism:.2e}')
+    assert e_low < LOGIT_TOL and mism < 1e-3
 
 
 def test_config2_query_vitl_batch16_r1600(dev):
@@ -437,6 +451,18 @@ def test_query_head_option_branches(dev, opts):
     oracle = QueryOracle('base', 1, NQ, max_per_image=20, head_kwargs=hk)
     model = _build(cfg, oracle, dev, seed=5)
     imgs, metas = synth_images(1, seed=11), synth_metas(1)
+    # encoder, aggregator and FPN do not depend on the head's options and the synthetic weights are functions of (seed, key,
+    # shape): the oracle's features of this image are computed by the first parameter set and reused by the others (round 6:
+    # 8 s of CPU oracle per parameter set out of the GPU suite)
+    feat_keys = sorted(k for k in oracle.state_dict() if not k.startswith('panoptic_head.'))
+    sig = (tuple(feat_keys), float(sum(oracle.state_dict()[k].double().sum() for k in feat_keys[:8])))
+    plain = oracle.extract_feat
+
+    def cached_extract_feat(x):
+        if _SHARED.get('query_opts_feat_sig') != sig:
+            _SHARED['query_opts_feat'], _SHARED['query_opts_feat_sig'] = plain(x), sig
+        return _SHARED['query_opts_feat']
+    oracle.extract_feat = cached_extract_feat
     _check_query(model, oracle, imgs, metas, dev, tag)
     if opts.get('multimask_output'):
         assert tuple(model._last_head_out[1].low_res.shape[:2]) == (1, 3 * NQ)
