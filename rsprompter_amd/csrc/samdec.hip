@@ -311,10 +311,13 @@ __global__ __launch_bounds__(256) void sam_fold_expand_kernel(const float* __res
     const int h = col / T, t = col - h * T;
     if ((c >> 4) == h) {
       v = *reinterpret_cast<const f32x4*>(tq + (r * T + t) * 128 + c);
-      v = v * scale;
     }
   }
-  rsp_store_planes4(hi, lo, ((int64_t)(c >> 5) * rows + row) * 32 + (c & 31), v * pscale, false);
+  // element by element: `v * scale` on the vector type becomes v_pk_mul_f32 with the scalar cross-selected through op_sel,
+  // the instruction class DESIGN 9.1 keeps out of every kernel that shares a SIMD (tests/test_isa_guard_cpu.py)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (v[e] * scale) * pscale;
+  rsp_store_planes4(hi, lo, ((int64_t)(c >> 5) * rows + row) * 32 + (c & 31), v, false);
 }
 
 __global__ __launch_bounds__(256) void sam_fold_gather_kernel(const float* __restrict__ full, float* __restrict__ ao, int64_t n4, int T) {

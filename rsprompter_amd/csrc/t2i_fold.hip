@@ -1,3 +1,4 @@
+// hipcc-flags: -fslp-vectorize
 // SAM two-way transformer, token -> image attention with the K | V projections of the per-RoI keys FOLDED into the kernel
 // (HF:326-331 / 397-400: q = tokens + pe_q through q_proj, k = k_proj(keys + pe), v = v_proj(keys), 8 heads x 16).
 //

@@ -1,3 +1,4 @@
+// hipcc-flags: -fslp-vectorize
 // Last stage of the SAM mask decoder's upscaler (HF:521-531), streaming form:
 //   masks[r, 2y+dy, 2x+dx] = sum_c GELU( ConvTranspose2d(64 -> 32, k2, s2)(u)[r, c, 2y+dy, 2x+dx] ) * hyper_in[r, c]
 // As a GEMM this is M = R*(2h)(2w) rows (13 M at R = 800), K = 64, N = 128 = (dy, dx, c): two K tiles only, so the
@@ -32,8 +33,15 @@ struct Up2P {
 // allocations on the GPU, poisoned LDS on the lane emulator), the copy to the host, the cross-half exchange instruction
 // (ds_bpermute_b32 and v_permlane32_swap both fail), GELU / transcendentals, the bias loads (through LDS: still fails), the
 // MFMA -> accumulator-read distance (32 more wait states: still fails), a write-after-read on MFMA sources
-// (tools/probes/mfma_war_probe.hip: 0 of 10^11).  The mechanism inside the CU is not known; both conditions are removed
-// here: the sums are pinned scalar per sub-pixel, and the grid is one persistent block per CU.
+// (tools/probes/mfma_war_probe.hip: 0 of 10^11).  Both conditions are removed here: the sums are pinned scalar per sub-pixel,
+// and the grid is one persistent block per CU.  Found afterwards by patching the failing build's assembly
+// (tools/probes/up2_isa_bisect.py): every wrong value is the exact sum minus the ONE addend hipcc forms as
+//     v_pk_mul_f32 vD, vA, vB op_sel:[0,1]            (low result = A.lo x B.HI)
+// in lanes 48..63; with those eight instructions replaced by two v_mul_f32 each the failing build never fails (0 of 3000, and
+// 0 of 200 under the s_nop stress that makes every launch of the unpatched build wrong).  The library is therefore built
+// with -fno-slp-vectorize and tests/test_isa_guard_cpu.py keeps packed-fp32 instructions with a set op_sel bit out of every
+// kernel that can share a SIMD; this FILE keeps the vectoriser (first line: the fused kernel below gains 0.5 ms per step
+// from it and runs one wave per SIMD), which the pinned sums of this kernel make harmless here.
 __global__ __launch_bounds__(256) void sam_upscale2_kernel(const Up2P p) {
   // weight image in LDS: [plane][kb][128 rows][64 B], 16-byte chunks XOR-swizzled with (row >> 2) & 3 (the fragment
   // reads of 32 consecutive rows would otherwise be 4-way bank conflicts, as in gemm_dma.hip)

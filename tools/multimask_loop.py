@@ -106,7 +106,7 @@ def main():
         got, want = to_ref_form(k, first)
         if got is not None:
             print(f'iteration 0: {k} err {float((got - want).abs().max()):.2e}', flush=True)
-    bad = wrong = 0
+    bad = wrong = n_wrong_vals = n_hist = 0
     wrong += float((first['masks'].cpu() - refs['masks']).abs().max()) > 1e-3
     pats = [0xFF, 0x00, 0x7B, None]
     for it in range(1, a.iters):
@@ -114,10 +114,57 @@ def main():
         if pattern[0] is None and a.empty_cache:
             torch.cuda.empty_cache()
         out = run()
-        torch.cuda.synchronize()
+        if os.environ.get('RSP_LOOP_SELFTEST') == '1':          # developer check of the analysis below: drop one addend by hand
+            import torch.nn.functional as F
+            with torch.no_grad():
+                y_ = F.gelu(dec.upscale_conv2(ref['up']))
+            out['masks'][1, 0, 5, 34] -= float(y_[1, 13, 5, 34] * refs['hyper0'][1, 13])
+        else:
+            torch.cuda.synchronize()
         moved = [k for k, v in out.items() if not torch.equal(v, first[k])]
         e_ref = float((out['masks'].cpu() - refs['masks']).abs().max())
         wrong += e_ref > 1e-3                        # against the HF reference: independent of what iteration 0 produced
+        if e_ref > 1e-3:
+            # WHERE, in the terms of sam_upscale2_kernel: sub-pixel j = 2 (Y & 1) + (X & 1) of output (Y, X), lane quarter of
+            # the input pixel x = X >> 1 inside its 32-pixel wave tile, mask token
+            w = ((out['masks'].cpu() - refs['masks']).abs() > 1e-3)
+            n_wrong_vals += int(w.sum())
+            if n_hist < 3:
+                n_hist += 1
+                idx = w.nonzero()
+                Y, X = idx[:, -2], idx[:, -1]
+                j = (2 * (Y & 1) + (X & 1)).bincount(minlength=4).tolist()
+                q = (((X >> 1) & 31) >> 4).bincount(minlength=2).tolist()
+                tok = idx[:, 1].bincount(minlength=w.shape[1]).tolist() if w.dim() == 4 else None
+                print(f'iteration {it}: {int(w.sum())} mask values off the HF reference by > 1e-3: by sub-pixel j {j}, by lane quarter '
+                      f'(pixels 0-15 / 16-31 of the wave tile) {q}, by mask token {tok}, by RoI {idx[:, 0].bincount(minlength=w.shape[0]).tolist()}',
+                      flush=True)
+                if w.dim() == 4 and 'up' in ref:
+                    # WHAT the wrong value is, in terms of the kernel's sum: the output is sum_c GELU(ConvT2(up)[c]) hyper[c] over 32
+                    # channels, 16 in the storing half wave (channels 8 g + 4 hh + e, hh = Y & 1) and 16 from its partner; which
+                    # addends are missing from the value that was stored?
+                    import torch.nn.functional as F
+                    with torch.no_grad():
+                        y = F.gelu(dec.upscale_conv2(ref['up']))                       # [R, 32, 4h, 4w]
+                    from collections import Counter
+                    votes = Counter()
+                    for (r, t, Y_, X_) in idx[:48].tolist():
+                        pc = y[r, :, Y_, X_] * refs[f'hyper{t}'][r]                  # the 32 addends
+                        got, tot = float(out['masks'][r, t, Y_, X_]), float(pc.sum())
+                        hh_ = Y_ & 1
+                        own = [8 * g_ + 4 * hh_ + e_ for g_ in range(4) for e_ in range(4)]
+                        oth = [c + 4 - 8 * hh_ for c in own]
+                        cands = {'own half only': float(pc[own].sum()), 'partner half only': float(pc[oth].sum())}
+                        for c in range(32):
+                            cands[f'all but channel {c} ({"own" if c in own else "partner"} half, position {(own if c in own else oth).index(c)})'] = tot - float(pc[c])
+                        for g_ in range(4):
+                            cands[f'all but own group {g_}'] = tot - float(pc[own[4 * g_:4 * g_ + 4]].sum())
+                            cands[f'all but partner group {g_}'] = tot - float(pc[oth[4 * g_:4 * g_ + 4]].sum())
+                            cands[f'own groups 0..{g_} + partner'] = float(pc[oth].sum()) + float(pc[own[:4 * g_ + 4]].sum())
+                            cands[f'partner groups 0..{g_} + own'] = float(pc[own].sum()) + float(pc[oth[:4 * g_ + 4]].sum())
+                        best = min(cands, key=lambda k_: abs(cands[k_] - got))
+                        votes[best if abs(cands[best] - got) < 2e-4 else 'none of the candidates'] += 1
+                    print(f'  what the first {min(48, idx.shape[0])} wrong values equal: {dict(votes)}', flush=True)
         if not moved:
             continue
         bad += 1
@@ -136,7 +183,8 @@ def main():
                   f'got {c1[d][:6].tolist()} first {f[d][:6].tolist()}; flat offsets {(d.flatten().nonzero().flatten()[:4]).tolist()} '
                   f'data_ptr {v.data_ptr():#x} nan {int(torch.isnan(c1.float()).sum())}', flush=True)
     print(f'multimask={mm} fused={a.fused} hw={hw} R={R}: {bad} of {a.iters} iterations differ from the first; '
-          f'{wrong} of {a.iters} off the HF reference by more than 1e-3 (iteration 0 included)', flush=True)
+          f'{wrong} of {a.iters} off the HF reference by more than 1e-3 (iteration 0 included), {n_wrong_vals} wrong values in all',
+          flush=True)
 
 
 if __name__ == '__main__':
