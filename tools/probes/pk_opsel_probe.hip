@@ -89,6 +89,8 @@ template <int MODE>
 void run(const float* din, unsigned* dbad, int threads, int blocks, int iters, const char* what) {
   hipMemset(dbad, 0, 8 * sizeof(unsigned));
   hipLaunchKernelGGL((probe<MODE>), dim3(blocks), dim3(threads), 0, 0, din, dbad, iters);
+  const hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+  if (e1 != hipSuccess || e2 != hipSuccess) printf("LAUNCH FAILED: %s / %s\n", hipGetErrorString(e1), hipGetErrorString(e2));
   unsigned h[8];
   hipMemcpy(h, dbad, sizeof(h), hipMemcpyDeviceToHost);
   printf("mode %d (%s), %4d threads x %4d blocks: low sums wrong per lane quarter %u %u %u %u, high sums %u %u %u %u  (of %llu sums each)\n",
