@@ -54,6 +54,19 @@
                  "v70", "v71", "v72", "v73", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10",     \
                  "a11", "a12", "a13", "a14", "a15")
 
+// the same chain, but the source pair v[52:53] is written by a GLOBAL LOAD (as the hyper values of the kernel are) instead of v_mov:
+// in the kernel, copying those two registers onto themselves with v_mov right in front of the multiply cut the failures 1500-fold
+#define BODY_VMEM(PRE, L)                                                                                             \
+  asm volatile("global_load_dwordx4 v[52:55], %[p], off\nv_mov_b32 v56, 0\nv_mov_b32 v57, 0\n"                         \
+               "v_mov_b32 v66, 0\nv_mov_b32 v67, 0\nv_mov_b32 v68, 0\nv_mov_b32 v69, 0\n"                             \
+               "v_mov_b32 v70, 0\nv_mov_b32 v71, 0\nv_mov_b32 v72, 0\nv_mov_b32 v73, 0\ns_waitcnt vmcnt(0)\n" PRE L L L L L L L L \
+               "s_waitcnt vmcnt(0) lgkmcnt(0)\ns_nop 7\nv_mov_b32 %[o0], v56\nv_mov_b32 %[o1], v57\n"                      \
+               : [o0] "=&v"(o0), [o1] "=&v"(o1)                                                                        \
+               : [a] "v"(a), [b] "v"(b), [p] "v"(gp), [q] "v"(lp)                                                      \
+               : "memory", "v52", "v53", "v54", "v55", "v56", "v57", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
+                 "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81",   \
+                 "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15")
+
 // bad[0 + q]: wrong LOW sums per lane quarter, bad[4 + q]: wrong HIGH sums per lane quarter
 template <int MODE>
 __global__ void probe(const float* in, unsigned* bad, int iters) {
@@ -76,8 +89,13 @@ __global__ void probe(const float* in, unsigned* bad, int iters) {
     if constexpr (MODE == 5) BODY(MFMAS, LINK_INPLACE("s_nop 0\n"));
     if constexpr (MODE == 6) BODY("", LINK_MEM("s_nop 0\n"));             // loads and LDS reads returning meanwhile
     if constexpr (MODE == 7) BODY(MFMAS, LINK_MEM("s_nop 0\n"));
-    const float w0 = (MODE == 3) ? 8.f * a * h0 : 8.f * a * h1;           // low sums: a x src1.HI (control: x src1.lo)
-    const float w1 = (MODE == 3) ? 8.f * b * h0 : 8.f * b * h1;           // high sums: b x src1.HI (control: op_sel_hi 0 -> x src1.lo)
+    if constexpr (MODE == 8) BODY_VMEM("", LINK_OPSEL("s_nop 0\n"));      // source pair written by a global load
+    if constexpr (MODE == 9) BODY_VMEM(MFMAS, LINK_OPSEL("s_nop 0\n"));
+    if constexpr (MODE == 10) BODY_VMEM("", LINK_MEM("s_nop 0\n"));       // ... with more loads / LDS reads in flight
+    if constexpr (MODE == 11) BODY_VMEM(MFMAS, LINK_INPLACE("s_nop 0\n"));
+    const float hs = (MODE >= 8) ? gp[1] : h1;                            // modes 8+: v53 = the second float of the loaded 16 bytes
+    const float w0 = (MODE == 3) ? 8.f * a * h0 : 8.f * a * hs;           // low sums: a x src1.HI (control: x src1.lo)
+    const float w1 = (MODE == 3) ? 8.f * b * h0 : 8.f * b * hs;           // high sums: b x src1.HI (control: op_sel_hi 0 -> x src1.lo)
     nlo += (o0 != w0);
     nhi += (o1 != w1);
   }
@@ -115,6 +133,10 @@ int main() {
     run<5>(din, dbad, s.threads, s.blocks, iters, "in-place form behind two MFMAs");
     run<6>(din, dbad, s.threads, s.blocks, iters, "op_sel:[0,1] chain with a global load and an LDS read in flight per link");
     run<7>(din, dbad, s.threads, s.blocks, iters, "... behind two MFMAs");
+    run<8>(din, dbad, s.threads, s.blocks, iters, "source pair written by a global load, s_nop behind every instruction");
+    run<9>(din, dbad, s.threads, s.blocks, iters, "... behind two MFMAs");
+    run<10>(din, dbad, s.threads, s.blocks, iters, "... with a global load and an LDS read in flight per link");
+    run<11>(din, dbad, s.threads, s.blocks, iters, "... in-place form behind two MFMAs");
   }
   hipFree(din); hipFree(dbad);
   return 0;

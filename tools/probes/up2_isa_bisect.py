@@ -105,6 +105,14 @@ def main():
                                              f'{m.group(1)}v_mul_f32_e32 v{m.group(3)}, v{m.group(5)}, v{m.group(7)}', text)
                 n += k
                 continue
+            if part == 'refresh':
+                # in front of every  v_pk_mul_f32 vD, vA, vB op_sel:[0,1] : both registers of vB copied onto themselves -- the
+                # hyper values were written by a global load long before; now their last writer is the VALU
+                pat = re.compile(r'^(\s+)(v_pk_mul_f32 v\[\d+:\d+\], v\[\d+:\d+\], v\[(\d+):(\d+)\] op_sel:\[0,1\])\s*$', re.M)
+                text, k = pat.subn(lambda m: f'{m.group(1)}v_mov_b32_e32 v{m.group(3)}, v{m.group(3)}\n'
+                                             f'{m.group(1)}v_mov_b32_e32 v{m.group(4)}, v{m.group(4)}\n{m.group(1)}{m.group(2)}', text)
+                n += k
+                continue
             if part == 'onecu':
                 # 96 KB of static LDS in the kernel descriptor and the metadata: ONE block per CU, i.e. one wave per SIMD,
                 # with the instruction stream untouched
