@@ -20,7 +20,7 @@ FLAGS = [
     # round 6: hipcc's SLP vectoriser pairs scalar fp32 work into v_pk_*_f32 whose LOW result takes the HIGH
     # register of a source pair (op_sel) -- the instruction form that dropped addends in sam_upscale2_kernel whenever two waves
     # shared a SIMD.  Off for the library; `// hipcc-flags: -fslp-vectorize` re-enables it per file where it was measured to pay
-    # AND the kernels that get such forms run one wave per SIMD (tests/test_isa_guard_cpu.py holds every kernel to that)
+    # and the form does not appear (tests/test_isa_guard_cpu.py scans the device assembly of every kernel for it)
     "-fno-slp-vectorize",
     "-Wno-unused-result",
 ]

@@ -40,8 +40,8 @@ struct Up2P {
 // in lanes 48..63; with those eight instructions replaced by two v_mul_f32 each the failing build never fails (0 of 3000, and
 // 0 of 200 under the s_nop stress that makes every launch of the unpatched build wrong).  The library is therefore built
 // with -fno-slp-vectorize and tests/test_isa_guard_cpu.py keeps packed-fp32 instructions with a set op_sel bit out of every
-// kernel that can share a SIMD; this FILE keeps the vectoriser (first line: the fused kernel below gains 0.5 ms per step
-// from it and runs one wave per SIMD), which the pinned sums of this kernel make harmless here.
+// kernel; this FILE keeps the vectoriser (first line: the fused kernel below gains 0.5 ms per step from it), which the pinned
+// sums of this kernel and the pinned dot of the fused one keep from forming that instruction.
 __global__ __launch_bounds__(256) void sam_upscale2_kernel(const Up2P p) {
   // weight image in LDS: [plane][kb][128 rows][64 B], 16-byte chunks XOR-swizzled with (row >> 2) & 3 (the fragment
   // reads of 32 consecutive rows would otherwise be 4-way bank conflicts, as in gemm_dma.hip)
@@ -359,6 +359,10 @@ __global__ __launch_bounds__(256) void sam_upscale_fused_kernel(const UpFP p) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) dot += t4[e] * hy[g][e];
         }
+        // (as in sam_upscale2_kernel: without this hipcc's SLP vectoriser packs the dots of two sub-pixels and multiplies element 1
+        // of every hyper group with  v_pk_mul_f32 ... op_sel:[0,1]  -- the instruction form of DESIGN 9.1; this kernel runs one
+        // wave per SIMD, where the form never failed, but the library keeps it out of every kernel: tests/test_isa_guard_cpu.py)
+        asm volatile("" : "+v"(dot));
         dot += __shfl_xor(dot, 32, 64);
         res[pos][jb] = dot;
         __builtin_amdgcn_sched_barrier(0);                  // (keeps the next block's loads from piling up registers)
