@@ -24,7 +24,11 @@ def test_scanner_recognises_the_instruction_form(tmp_path):
 
 def test_no_cross_selected_packed_fp32_in_kernels_that_share_a_simd():
     """every .hip of the library compiled to device assembly with the library's own flags (26 s on 8 cores)"""
+    import pytest
     import isa_guard
+    from rsprompter_amd import build
+    if not os.path.exists(build.HIPCC):
+        pytest.skip('hipcc is not installed here: nothing to compile the kernels with')
     table, viol = isa_guard.run()
     for row in table:
         print(row)
