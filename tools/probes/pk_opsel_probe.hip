@@ -40,6 +40,25 @@
   "v_mov_b32 v60, %[a]\n" NOP "v_mov_b32 v61, %[b]\n" NOP                                            \
   "v_pk_mul_f32 v[62:63], v[60:61], v[52:53] op_sel:[0,1]\n" NOP                                     \
   "v_pk_add_f32 v[56:57], v[56:57], v[62:63]\n" NOP
+// ... with a matrix instruction issued inside EVERY link (the kernel's scheduler interleaves the next sub-pixel's MFMAs with this
+// sub-pixel's sums; without its MFMAs the stressed kernel does not fail: up2_isa_bisect.py nomfma+pk, 0 of 300)
+#define LINK_MFMA_A(NOP) "v_mfma_f32_32x32x16_f16 a[0:15], v[66:69], v[70:73], a[0:15]\n" NOP LINK_OPSEL(NOP)
+#define LINK_MFMA_V(NOP) "v_mfma_f32_32x32x16_f16 v[100:115], v[66:69], v[70:73], v[100:115]\n" NOP LINK_OPSEL(NOP)
+// minimal-set variants of the reproducing modes 12 / 13: the control form, the two-v_mul_f32 workaround, the wait state only
+// behind the MFMA
+#define LINK_MFMA_V_LOLO(NOP) "v_mfma_f32_32x32x16_f16 v[100:115], v[66:69], v[70:73], v[100:115]\n" NOP LINK_LOLO(NOP)
+#define LINK_MFMA_V_MUL(NOP)                                                                          \
+  "v_mfma_f32_32x32x16_f16 v[100:115], v[66:69], v[70:73], v[100:115]\n" NOP                          \
+  "v_mov_b32 v60, %[a]\n" NOP "v_mov_b32 v61, %[b]\n" NOP                                            \
+  "v_mul_f32 v62, v60, v53\n" NOP "v_mul_f32 v63, v61, v53\n" NOP                                    \
+  "v_pk_add_f32 v[56:57], v[56:57], v[62:63]\n" NOP
+#define LINK_MFMA_V_NOP1 "v_mfma_f32_32x32x16_f16 v[100:115], v[66:69], v[70:73], v[100:115]\ns_nop 0\n" LINK_OPSEL("")
+#define LINK_MFMA_V_NOPSEL                                                                            \
+  "v_mfma_f32_32x32x16_f16 v[100:115], v[66:69], v[70:73], v[100:115]\n"                              \
+  "v_mov_b32 v60, %[a]\nv_mov_b32 v61, %[b]\ns_nop 0\n"                                              \
+  "v_pk_mul_f32 v[62:63], v[60:61], v[52:53] op_sel:[0,1]\ns_nop 0\n"                                \
+  "v_pk_add_f32 v[56:57], v[56:57], v[62:63]\n"
+#define ZERO_V100 "v_mov_b32 v100, 0\nv_mov_b32 v101, 0\nv_mov_b32 v102, 0\nv_mov_b32 v103, 0\nv_mov_b32 v104, 0\nv_mov_b32 v105, 0\nv_mov_b32 v106, 0\nv_mov_b32 v107, 0\nv_mov_b32 v108, 0\nv_mov_b32 v109, 0\nv_mov_b32 v110, 0\nv_mov_b32 v111, 0\nv_mov_b32 v112, 0\nv_mov_b32 v113, 0\nv_mov_b32 v114, 0\nv_mov_b32 v115, 0\n"
 #define MFMAS "v_mfma_f32_32x32x16_f16 a[0:15], v[66:69], v[70:73], 0\nv_mfma_f32_32x32x16_f16 a[0:15], v[66:69], v[70:73], a[0:15]\n"
 
 #define BODY(PRE, L)                                                                                                  \
@@ -51,6 +70,8 @@
                : [a] "v"(a), [b] "v"(b), [h0] "v"(h0), [h1] "v"(h1), [p] "v"(gp), [q] "v"(lp)                          \
                : "memory", "v52", "v53", "v56", "v57", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69",   \
                  "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81",                                             \
+                 "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
+                 "v114", "v115",                                                                                     \
                  "v70", "v71", "v72", "v73", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10",     \
                  "a11", "a12", "a13", "a14", "a15")
 
@@ -65,6 +86,8 @@
                : [a] "v"(a), [b] "v"(b), [p] "v"(gp), [q] "v"(lp)                                                      \
                : "memory", "v52", "v53", "v54", "v55", "v56", "v57", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", \
                  "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81",   \
+                 "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", \
+                 "v114", "v115",                                                                                     \
                  "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15")
 
 // bad[0 + q]: wrong LOW sums per lane quarter, bad[4 + q]: wrong HIGH sums per lane quarter
@@ -93,9 +116,18 @@ __global__ void probe(const float* in, unsigned* bad, int iters) {
     if constexpr (MODE == 9) BODY_VMEM(MFMAS, LINK_OPSEL("s_nop 0\n"));
     if constexpr (MODE == 10) BODY_VMEM("", LINK_MEM("s_nop 0\n"));       // ... with more loads / LDS reads in flight
     if constexpr (MODE == 11) BODY_VMEM(MFMAS, LINK_INPLACE("s_nop 0\n"));
-    const float hs = (MODE >= 8) ? gp[1] : h1;                            // modes 8+: v53 = the second float of the loaded 16 bytes
-    const float w0 = (MODE == 3) ? 8.f * a * h0 : 8.f * a * hs;           // low sums: a x src1.HI (control: x src1.lo)
-    const float w1 = (MODE == 3) ? 8.f * b * h0 : 8.f * b * hs;           // high sums: b x src1.HI (control: op_sel_hi 0 -> x src1.lo)
+    if constexpr (MODE == 12) BODY_VMEM(MFMAS, LINK_MFMA_A("s_nop 0\n"));   // an MFMA into AGPRs in every link, source pair from a load
+    if constexpr (MODE == 13) BODY_VMEM(ZERO_V100, LINK_MFMA_V("s_nop 0\n"));
+    if constexpr (MODE == 14) BODY_VMEM(MFMAS, LINK_MFMA_A(""));             // ... without the s_nops
+    if constexpr (MODE == 15) BODY(ZERO_V100, LINK_MFMA_V("s_nop 0\n"));         // as 13, the source pair written by v_mov
+    if constexpr (MODE == 16) BODY_VMEM(ZERO_V100, LINK_MFMA_V_LOLO("s_nop 0\n")); // as 13, control form op_sel_hi:[1,0] (expects x src1.lo)
+    if constexpr (MODE == 17) BODY_VMEM(ZERO_V100, LINK_MFMA_V_MUL("s_nop 0\n")); // as 13, two v_mul_f32 instead of the packed multiply
+    if constexpr (MODE == 18) BODY_VMEM(ZERO_V100, LINK_MFMA_V_NOP1);              // as 13, ONE wait state, right behind the MFMA
+    if constexpr (MODE == 19) BODY_VMEM(ZERO_V100, LINK_MFMA_V_NOPSEL);            // as 13, wait states only around the packed multiply
+    const float hs = (MODE >= 8 && MODE != 15) ? gp[1] : h1;                            // modes 8+: v53 = the second float of the loaded 16 bytes
+    const float hl = (MODE == 16) ? gp[0] : h0;                           // the controls multiply with src1.lo
+    const float w0 = (MODE == 3 || MODE == 16) ? 8.f * a * hl : 8.f * a * hs;   // low sums: a x src1.HI
+    const float w1 = (MODE == 3 || MODE == 16) ? 8.f * b * hl : 8.f * b * hs;   // high sums: b x src1.HI
     nlo += (o0 != w0);
     nhi += (o1 != w1);
   }
@@ -123,7 +155,7 @@ int main() {
   hipMalloc(&din, h.size() * 4); hipMalloc(&dbad, 8 * sizeof(unsigned));
   hipMemcpy(din, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   const int iters = 20000;
-  struct { int threads, blocks; } shapes[] = {{256, 256}, {256, 512}, {512, 256}, {1024, 256}, {256, 2048}};   // 1, 2, 2, 4 waves per SIMD; many blocks
+  struct { int threads, blocks; } shapes[] = {{256, 256}, {256, 512}, {512, 256}, {256, 2048}};   // 1, 2, 2 waves per SIMD; many blocks (1024 threads do not fit the registers of the MFMA modes)
   for (auto s : shapes) {
     run<0>(din, dbad, s.threads, s.blocks, iters, "op_sel:[0,1] chain, back to back");
     run<1>(din, dbad, s.threads, s.blocks, iters, "op_sel:[0,1] chain, s_nop behind every instruction");
@@ -137,6 +169,14 @@ int main() {
     run<9>(din, dbad, s.threads, s.blocks, iters, "... behind two MFMAs");
     run<10>(din, dbad, s.threads, s.blocks, iters, "... with a global load and an LDS read in flight per link");
     run<11>(din, dbad, s.threads, s.blocks, iters, "... in-place form behind two MFMAs");
+    run<12>(din, dbad, s.threads, s.blocks, iters, "load-written source pair, an MFMA into AGPRs inside every link");
+    run<13>(din, dbad, s.threads, s.blocks, iters, "... an MFMA into VGPRs inside every link");
+    run<14>(din, dbad, s.threads, s.blocks, iters, "... AGPR form without the s_nops");
+    run<15>(din, dbad, s.threads, s.blocks, iters, "as 13, the source pair written by v_mov instead of a load");
+    run<16>(din, dbad, s.threads, s.blocks, iters, "as 13, control: op_sel_hi:[1,0] form");
+    run<17>(din, dbad, s.threads, s.blocks, iters, "as 13, two v_mul_f32 instead of the packed multiply");
+    run<18>(din, dbad, s.threads, s.blocks, iters, "as 13, one wait state only, right behind the MFMA");
+    run<19>(din, dbad, s.threads, s.blocks, iters, "as 13, wait states only around the packed multiply");
   }
   hipFree(din); hipFree(dbad);
   return 0;

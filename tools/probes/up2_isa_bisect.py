@@ -113,6 +113,32 @@ def main():
                                              f'{m.group(1)}v_mov_b32_e32 v{m.group(4)}, v{m.group(4)}\n{m.group(1)}{m.group(2)}', text)
                 n += k
                 continue
+            if part in ('nomfma', 'noexp', 'nopkfma'):
+                # reduction of the reproducer (the kernel alone under the stress, tools/upscale2_loop.py: launches that differ from
+                # the first): one ingredient replaced by constant writes to its destination registers -- the arithmetic becomes
+                # meaningless but stays deterministic, addresses and control flow are untouched
+                def regs(m_lo, m_hi, kind):
+                    return [f'{kind}{i}' for i in range(int(m_lo), int(m_hi) + 1)]
+                i0 = text.index(KERNEL + ':')
+                i1 = text.index('.amdhsa_kernel ' + KERNEL)
+                head, text, tail = text[:i0], text[i0:i1], text[i1:]         # this kernel's text only
+                if part == 'nomfma':
+                    # the first MFMA of a chain (C = 0) defines its 16 destination registers: constants there; the accumulating
+                    # ones become a wait state
+                    pat = re.compile(r'^(\s+)v_mfma_f32_32x32x16_f16 ([av])\[(\d+):(\d+)\], (.*)$', re.M)
+                    text, k = pat.subn(lambda m: ('\n'.join(
+                        f'{m.group(1)}' + (f'v_accvgpr_write_b32 {r}, 1.0' if m.group(2) == 'a' else f'v_mov_b32_e32 {r}, 1.0')
+                        for r in regs(m.group(3), m.group(4), m.group(2))) if m.group(5).rstrip().endswith(', 0')
+                        else f'{m.group(1)}s_nop 0'), text)
+                elif part == 'noexp':
+                    pat = re.compile(r'^(\s+)v_exp_f32_e\d+ (v\d+), .*$', re.M)
+                    text, k = pat.subn(lambda m: f'{m.group(1)}v_mov_b32_e32 {m.group(2)}, 1.0', text)
+                else:
+                    pat = re.compile(r'^(\s+)v_pk_fma_f32 v\[(\d+):(\d+)\],.*$', re.M)
+                    text, k = pat.subn(lambda m: f'{m.group(1)}v_mov_b32_e32 v{m.group(2)}, 0.5\n{m.group(1)}v_mov_b32_e32 v{m.group(3)}, 0.25', text)
+                text = head + text + tail
+                n += k
+                continue
             if part == 'onecu':
                 # 96 KB of static LDS in the kernel descriptor and the metadata: ONE block per CU, i.e. one wave per SIMD,
                 # with the instruction stream untouched
