@@ -4,8 +4,9 @@ The box-dependent wrong answer of round 5 was ONE instruction form: `v_pk_mul_f3
 operation whose LOW result takes the HIGH register of a source pair -- losing its low product in lanes 48..63 when a second
 wave of the same SIMD had an instruction issued next to it (tools/probes/up2_isa_bisect.py: the failing build with exactly
 those eight instructions replaced by two v_mul_f32 each never fails, 0 of 3000 launches and 0 of 200 under the stress that
-made every launch wrong; with one wave per SIMD the unchanged stream never fails either).  hipcc emits the form from its SLP
-vectoriser and from `vector * scalar` on ext-vector types; nothing in the sources asks for it.
+made every launch wrong; with one wave per SIMD the unchanged stream never fails either; tools/probes/pk_opsel_probe.hip
+reproduces it with ten instructions: the form behind an MFMA of the same wave, the issue slot given up in between).  hipcc
+emits the form from its SLP vectoriser and from `vector * scalar` on ext-vector types; nothing in the sources asks for it.
 
 This script compiles every .hip with the library's flags to device assembly and lists, per kernel, the packed-fp32
 instructions with a set `op_sel` bit and the occupancy the compiler reports.  A kernel that has such instructions AND can
